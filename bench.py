@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: boundary-MPS PEPS contraction, ms per sweep, chimera L=2048, chi=64 (BASELINE.json).
+
+One step = one sweep = one `_setup_rhoT` (reference tnac4o.py:1674-1695): for each of the 16 rows, build the row
+MPO, absorb it into the boundary MPS and compress back to chi=64 with the defaults of search_ground_state
+(graduate_truncation, tolS=1e-16, tolV=1e-10, max_sweeps=20).  Synthetic chimera couplings (seed 20260004,
+SURVEY.md §8d).  With N GPUs each rank sweeps its own lattice rotation (rank mod 4) of the same couplings — the
+reference's 4-rotation loop (examples/e06:97-109) sharded with no data-path collective ("weak" scaling);
+`value` = wall ms divided by the number of sweeps all ranks completed.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the kernel family with the largest summed duration, timed
+with HIP events on its launch stream inside the timed region; `cpu_baseline` times the CPU oracle on a bounded
+sample (the bottom rows of the same sweep) on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+FAMILIES = ['gemm_kernel<128,128>', 'gemm_kernel<128,32>', 'gemm_kernel<32,128>', 'gemm_kernel<64,64>',
+            'splitk_reduce_kernel', 'absorb_kernel', 'gram_partial_kernel', 'eig_small_kernel',
+            'rows_times_small_kernel', 'small_t_times_vecs_kernel']
+MFMA_FAM = {0, 1, 2, 3}
+PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X fp64 matrix peak (vendor figure quoted in SURVEY.md §7; not in the microarch guide)
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def profile_totals(lib):
+    out = []
+    for f in range(len(FAMILIES)):
+        calls, ms, fl, by = C.c_uint64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        lib.tn_profile_get(f, C.byref(calls), C.byref(ms), C.byref(fl), C.byref(by))
+        out.append(dict(kernel=FAMILIES[f], calls=int(calls.value), ms=ms.value, flops=fl.value, bytes=by.value))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--L', type=int, default=2048, choices=[128, 512, 2048])
+    ap.add_argument('--chi', type=int, default=64)
+    ap.add_argument('--cpu-rows', type=int, default=2, help='bottom rows timed on the CPU oracle (0 disables)')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    import tnac4o_amd
+    from tnac4o_amd import _lib
+    from tnac4o_amd.auxx import synthetic_chimera
+    lib = _lib.lib()
+    n = {128: 4, 512: 8, 2048: 16}[args.L]
+    seed = {128: 20260002, 512: 20260003, 2048: 20260004}[args.L]
+    J = synthetic_chimera(n, n, seed)
+    rot = rank % 4
+    kw = dict(graduate_truncation=True, Dmax=args.chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
+
+    def make():
+        s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=J, beta=3.0)
+        if rot:
+            s.rotate_graph(rot)
+        return s
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    solver = make()
+    for _ in range(args.warmup):
+        solver._setup_rhoT(**kw)
+    if not args.no_profile:
+        lib.tn_profile_reset()
+        lib.tn_profile_enable((1 << len(FAMILIES)) - 1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver._setup_rhoT(**kw)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = None
+    if not args.no_profile:
+        prof = profile_totals(lib)
+        lib.tn_profile_enable(0)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+
+    if rank == 0:
+        out = {
+            'metric': 'PEPS-contraction ms/sweep, chimera L=%d chi=%d (boundary-MPS sweep _setup_rhoT)' % (args.L, args.chi),
+            'value': ms_per_step / world, 'unit': 'ms/sweep', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'chimera L=%d (Nx=Ny=%d, Nc=8) synthetic couplings seed %d, beta=3, chi=%d, one sweep = %d '
+                                   'rows of MPO absorb + compress_mps' % (args.L, n, seed, args.chi, n),
+                       'sweeps_per_step_all_ranks': world, 'parallelism': 'rotation-per-rank x%d, no data-path collective' % world,
+                       'rhoT_discarded_max': float(max(solver.rhoT_discarded)),
+                       'rhoT_overlap_min': float(min(solver.rhoT_overlap)),
+                       'bond_dims_mid_row': [int(d) for d in solver.rhoT[n // 2].D]},
+        }
+        if prof is not None:
+            tot = sum(p['ms'] for p in prof)
+            dom = max(range(len(prof)), key=lambda i: prof[i]['ms'])
+            d = prof[dom]
+            avg_ms = d['ms'] / max(1, d['calls'])
+            if dom in MFMA_FAM:
+                ach = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+                roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': ach / PEAK_F64_MFMA_TFLOPS}
+            else:
+                ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9 if d['ms'] > 0 else 0.0
+                roof = {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS}
+            roof.update({'traffic': None, 'kernel': d['kernel'], 'launches': d['calls'], 'avg_launch_ms': avg_ms,
+                         'share_of_event_time': d['ms'] / tot if tot > 0 else 0.0,
+                         'algorithmic_flops_per_launch': d['flops'] / max(1, d['calls']),
+                         'algorithmic_bytes_per_launch': d['bytes'] / max(1, d['calls'])})
+            out['roofline'] = roof
+            out['kernel_time_ms_per_step'] = {p['kernel']: round(p['ms'] / args.steps, 3) for p in prof}
+            out['kernel_launches_per_step'] = {p['kernel']: p['calls'] // args.steps for p in prof}
+            out['event_time_fraction_of_wall'] = tot / (1e3 * dt) if dt > 0 else 0.0
+            ab = prof[5]
+            if ab['ms'] > 0:
+                out['absorb_hbm'] = {'achieved': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                     'frac': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        if args.cpu_rows > 0:
+            out['cpu_baseline'] = cpu_baseline(J, n, args, solver, kw)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(J, n, args, solver, kw):
+    """CPU oracle ("port" of the reference algorithm, numpy/scipy on OpenBLAS) on the bottom `cpu_rows` rows of the
+    same sweep, and the GPU time for the same rows; the full-sweep CPU figure is the measured GPU ms/sweep scaled by
+    that ratio (a full CPU sweep at L=2048 chi=64 takes tens of minutes)."""
+    from oracle import solver_ref as sr
+    from oracle import mps_ref as mr
+    rows = min(args.cpu_rows, n)
+    b = sr.RefSolver(mode='Ising', Nx=n, Ny=n, Nc=8, J=J, beta=3.0)
+    t0 = time.perf_counter()
+    psi = mr.RefMPS(d=1, L=n, Dmax=1)
+    for ny in range(n - 1, n - 1 - rows, -1):
+        psi = psi.copy()
+        psi.apply_mpo(b._row_mpo(ny), Hconj=True)
+        psi.compress_mps(Dmax=kw['Dmax'], tolS=kw['tolS'], tolV=kw['tolV'], max_sweeps=kw['max_sweeps'],
+                         graduate_truncation=True)
+    cpu_ms = 1e3 * (time.perf_counter() - t0)
+    # the same rows on the GPU
+    from tnac4o_amd import mps
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    phi = mps.MPS(d=1, L=n, Dmax=1, initial='X')
+    for ny in range(n - 1, n - 1 - rows, -1):
+        phi = phi.copy()
+        phi.apply_mpo(solver._row_mpo(ny), Hconj=True)
+        phi.compress_mps(Dmax=kw['Dmax'], tolS=kw['tolS'], tolV=kw['tolV'], max_sweeps=kw['max_sweeps'],
+                         graduate_truncation=True)
+    torch.cuda.synchronize()
+    gpu_ms = 1e3 * (time.perf_counter() - t0)
+    try:
+        import threadpoolctl
+        threads = max([p['num_threads'] for p in threadpoolctl.threadpool_info()] or [os.cpu_count()])
+    except Exception:
+        threads = os.cpu_count()
+    return {'value': cpu_ms, 'unit': 'ms for the sample', 'cores': int(threads), 'kind': 'port',
+            'sample': 'bottom %d of %d rows of the same sweep (rows %d..%d): MPO absorb + compress_mps, oracle/ numpy+scipy; '
+                      'GPU time for the same rows: %.1f ms' % (rows, n, n - 1, n - rows, gpu_ms),
+            'gpu_same_sample_ms': gpu_ms, 'speedup_on_sample': cpu_ms / gpu_ms if gpu_ms > 0 else None}
+
+
+if __name__ == '__main__':
+    main()

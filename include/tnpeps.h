@@ -1,0 +1,99 @@
+/* libtnpeps — C-ABI of the MI355X boundary-MPS PEPS contraction kernels.
+ *
+ * The reference (marekrams/tnac4o) has no FFI layer; its hot path is the module surface of tnac4o/mps.py as
+ * consumed by tnac4o/tnac4o.py.  Each entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float64 data unless its name ends in `_host`;
+ *   - matrices are passed with explicit element strides (rs = row stride, cs = column stride), so transposed
+ *     or sliced views never need a copy;
+ *   - the caller owns every buffer including workspaces (sizes from the *_ws_bytes queries); nothing is
+ *     allocated or freed by the library; outputs never alias inputs unless stated;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.  tn_svd_trunc / tn_svdvals
+ *     synchronise the stream internally (rank decisions are made on the host), the rest is asynchronous;
+ *   - return 0 = ok, < 0 = argument error (nothing launched), > 0 = HIP runtime error code.  The message is
+ *     available from tn_last_error() (thread-local).  Numerical events (non-convergence) are reported through
+ *     `info` outputs, never as errors.
+ */
+#ifndef TNPEPS_H
+#define TNPEPS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int tn_version(void);
+/* copies the calling thread's last error text into buf (NUL-terminated); returns its length */
+int tn_last_error(char* buf, int n);
+
+/* ---- K2: strided (batched) GEMM.  C = alpha * A[M,K] * B[K,N] + beta * C.
+ * Replaces every np.tensordot of mps.py (_mps_CA/_mps_AC :740-746, _mps_RL/_RR :655-663, _mps_RAR :748-751,
+ * projector application :579-580, bond_env/expectation :694-698, :765-769) and tnac4o.py:532, 1779-1780, 1792-1794.
+ * ws may be NULL (disables split-K). */
+int tn_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
+            const double* B, int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc,
+            int64_t batch, int64_t bsa, int64_t bsb, int64_t bsc, void* ws, int64_t ws_bytes, void* stream);
+int64_t tn_gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch);
+
+/* ---- K1: MPO.MPS absorption of one site.  Replaces MPS.apply_mpo (mps.py:353-359) -> _mps_HA (:753-763).
+ * A: (Dl, pold, Dr) C-order.  W: (ba, po, bb, pi) C-order, legs (left, out, right, in).
+ * hconj=1: out (Dl*ba, pi, Dr*bb), MPS index major;  hconj=0: out (ba*Dl, po, bb*Dr), MPO index major. */
+int tn_absorb(const double* A, const double* W, double* out, int64_t Dl, int64_t pold, int64_t Dr, int64_t ba,
+              int64_t po, int64_t bb, int64_t pi, int hconj, void* stream);
+
+/* ---- K3: economic QR, diag(R) >= 0.  Replaces mps.qr (mps.py:43-59) as used by _mps_decompose_AC/CA (:772-800).
+ * A (m x n) is DESTROYED.  Q: m x min(m,n), R: min(m,n) x n.  nb in {32, 64} is the panel width. */
+int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs, int64_t qcs, double* R,
+          int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, void* stream);
+int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb);
+
+/* ---- K4: truncated SVD of a centre matrix.  Replaces mps.svd (mps.py:24-40, sign gauge included) +
+ * _mps_truncateC (:802-811): keep = min(#(S > S0*max(eps,tol)), Dmax), discarded = sqrt(sum S[keep:]^2)/S0.
+ * C: k x n.  U: k x keep, S: keep values, Vt: keep x n are written for the first `keep` vectors only; buffers must
+ * hold min(k, n, Dmax) vectors.  keep_host/discarded_host/sweeps_host/info_host are HOST pointers (may be NULL
+ * except keep_host).  info: 0 converged, 1 sweep cap reached. */
+int tn_svd_trunc(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol, double* U,
+                 int64_t urs, int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_host,
+                 double* discarded_host, int* sweeps_host, int* info_host, void* ws, int64_t ws_bytes, void* stream);
+/* ---- K5: singular values only, sorted descending, min(k,n) values written to HOST memory.
+ * Replaces mps.svd_S (mps.py:62-73) as used by MPS.update_S (:550-560). */
+int tn_svdvals(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* S_host, int* sweeps_host,
+               int* info_host, void* ws, int64_t ws_bytes, void* stream);
+int64_t tn_svd_ws_bytes(int64_t k, int64_t n, int vectors);
+
+/* ---- K6: out2[0] = 2^floor(log2 max|x|), out2[1] = 1/out2[0] (device).  Replaces mps.nfactor (mps.py:76-85).
+ * slot8: 8 bytes of device scratch. */
+int tn_nfactor(const double* x, int64_t n, double* out2, void* slot8, void* stream);
+/* x[i] *= scalar_dev[0]  (used with out2+1 of tn_nfactor: mps.py:782, 797; tnac4o.py:533, 1781) */
+int tn_scale_by(double* x, int64_t n, const double* scalar_dev, void* stream);
+/* A[dl, s, dr] *= diag[s] (inv=0) or /= diag[s] (inv=1).  Replaces MPS.apply_diagonalO (mps.py:361-366). */
+int tn_scale_phys(double* A, int64_t Dl, int64_t p, int64_t Dr, const double* diag, int inv, void* stream);
+
+/* ---- K8: conditional probabilities of one cell for a batch of branches.  Replaces the per-branch loop
+ * tnac4o.py:444-448 around _calculate_Pn (:1786-1807), including the negative-probability rule.
+ *   T1: (npref, p, Dr)  left environment times the top MPS site, one row block per distinct prefix
+ *   RR: (nsuf, Dr, br)  right environments per distinct suffix
+ *   F : (q, nl, nu)     non-zero factor of the PEPS tensor, T[s,l,d,r,u] = F[s,l,u] [d=dmap[s]] [r=rmap[s]]
+ *   per branch kk: pref[kk], suf[kk], lidx[kk], uidx[kk] (int32).  Out: P (nb, q) normalised, minP (nb). */
+int tn_calc_pn(const double* T1, const double* RR, const double* F, const int32_t* dmap, const int32_t* rmap,
+               const int32_t* pref, const int32_t* suf, const int32_t* lidx, const int32_t* uidx, int64_t nb,
+               int64_t q, int64_t nl, int64_t nu, int64_t p, int64_t Dr, int64_t br, double* P, double* minP,
+               void* stream);
+/* ---- K9: per-item power-of-two normalisation of a batch of environments (tnac4o.py:533, 1781):
+ * each of the `batch` contiguous blocks of `len` doubles is divided by its own nfactor. */
+int tn_nfactor_batched(double* x, int64_t batch, int64_t len, void* stream);
+
+/* ---- measurement: bracket every launch of the selected kernel families with HIP events on the launch stream.
+ * family ids: 0-3 gemm_kernel<128,128> / <128,32> / <32,128> / <64,64> (all operand layouts), 4 splitk_reduce,
+ * 5 absorb, 6 gram_partial, 7 eig_small, 8 rows_times_small, 9 small_t_times_vecs.
+ * mask bit f enables family f.  tn_profile_get synchronises the recorded events and returns totals since the last
+ * reset: launches, summed duration (ms), algorithmic flops and bytes (SURVEY.md §8d counts). */
+void tn_profile_enable(unsigned mask);
+void tn_profile_reset(void);
+int tn_profile_get(int family, uint64_t* calls_host, double* ms_host, double* flops_host, double* bytes_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

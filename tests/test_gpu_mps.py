@@ -1,0 +1,254 @@
+"""GPU parity tests at the level of the reference's call surface: MPS.compress_mps (G3), the boundary sweep
+(G5), conditional probabilities (G6) and search_ground_state end results (G7), through tnac4o_amd (HIP path)
+against the golden vectors captured from the reference and against the CPU oracle.  Tolerances:
+energies 1e-10, log2-probabilities 1e-9, Pn relative 1e-10, overlap 1e-12, discarded rel 1e-6 / abs 1e-14."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+from oracle import mps_ref as mr
+from oracle import solver_ref as sr
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def load(name):
+    return np.load(os.path.join(gi.GOLDEN_DIR, name))
+
+
+def host_chain(psi):
+    """Oracle-side MPS holding the device tensors of a tnac4o_amd.mps.MPS (for gauge-invariant overlaps)."""
+    As = [a.detach().cpu().numpy() for a in psi.A]
+    o = mr.RefMPS(d=[a.shape[1] for a in As], L=len(As), Dmax=1, canonise=None)
+    o.A = As
+    return o
+
+
+def ref_chain(As):
+    o = mr.RefMPS(d=[a.shape[1] for a in As], L=len(As), Dmax=1, canonise=None)
+    o.A = [np.array(a) for a in As]
+    return o
+
+
+def fidelity(a, b):
+    return abs(mr.mps_dot(a, b)) / np.sqrt(mr.mps_dot(a, a) * mr.mps_dot(b, b))
+
+
+def gpu_solver(L=128, ins=1, rot=0, beta=3.0, pre=False, J=None):
+    import tnac4o_amd
+    n = {128: 4, 512: 8, 2048: 16}[L]
+    s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=J if J is not None else gi.droplet_J(L, ins), beta=beta)
+    if rot:
+        s.rotate_graph(rot)
+    if pre:
+        s.precondition(mode='balancing')
+    return s
+
+
+# ------------------------------------------------------------------------------------------------ G3
+@pytest.mark.parametrize('case', [0, 1])
+def test_compress_golden(case):
+    from tnac4o_amd import mps
+    g = load('g3_compress.npz')
+    L, D, p, b, chi = [(6, 6, 4, 4, 8), (8, 8, 16, 16, 16)][case]
+    As = gi.rand_chain(31 + case, [1] + [D] * (L - 1) + [1], [p] * L)
+    Ws = gi.rand_mpo(41 + case, L, b, p, p)
+    for hconj in (True, False):
+        for grad in (True, False):
+            psi = mps.MPS(d=[p] * L, L=L, Dmax=1, canonise=None)
+            psi.A = [mps._t(a) for a in As]
+            psi.D = [1] + [a.shape[2] for a in As]
+            mpo = mps.MPO(L=L)
+            for n in range(L):
+                mpo.set_direct(Ws[n], n)
+            psi.apply_mpo(mpo, Hconj=hconj)
+            ov = psi.compress_mps(Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20, graduate_truncation=grad)
+            tag = 'rand%d_h%d_g%d' % (case, int(hconj), int(grad))
+            assert ov == pytest.approx(g[tag + '_overlap'][0], abs=1e-12)
+            assert psi.D == list(g[tag + '_D'])
+            np.testing.assert_allclose(np.array(psi.discarded, dtype=float), g[tag + '_discarded'], rtol=1e-6, atol=1e-14)
+            for n in range(L + 1):
+                np.testing.assert_allclose(psi.S[n], g[tag + '_S%d' % n], rtol=0, atol=1e-12)
+            # left-canonical result: every site is an isometry
+            for n in range(L):
+                A = psi.A[n].detach().cpu().numpy()
+                M = A.reshape(-1, A.shape[2])
+                assert np.abs(M.T @ M - np.eye(M.shape[1])).max() < 1e-12
+            if case == 0:
+                assert fidelity(ref_chain([g[tag + '_A%d' % n] for n in range(L)]), host_chain(psi)) > 1 - 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ G5
+@pytest.mark.parametrize('rot,chi', [(0, 8), (1, 8), (2, 8), (3, 8), (0, 32), (1, 32), (2, 32), (3, 32)])
+def test_sweep_L128(rot, chi):
+    g = load('g5_sweep.npz')
+    s = gpu_solver(rot=rot)
+    s._setup_rhoT(graduate_truncation=True, Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
+    tag = 'L128_r%d_chi%d' % (rot, chi)
+    np.testing.assert_allclose(np.array(s.rhoT_overlap, dtype=float), g[tag + '_overlap'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.array(s.rhoT_discarded, dtype=float), g[tag + '_discarded'], rtol=1e-6, atol=1e-14)
+    want_D = g[tag + '_D']
+    got_D = np.array([m.D for m in s.rhoT])
+    # bond dimensions are pinned where they are not decided at the eps noise floor (SURVEY.md §7 "hard parts")
+    assert got_D.shape == want_D.shape and np.abs(got_D - want_D).max() <= (0 if chi == 8 else 2)
+    if chi == 8:
+        for ny in range(s.Ny + 1):
+            phi = ref_chain([g[tag + '_A_%d_%d' % (ny, nx)] for nx in range(s.Nx)])
+            assert fidelity(phi, host_chain(s.rhoT[ny])) > 1 - 1e-12
+
+
+@pytest.mark.parametrize('hconj', [True, False])
+def test_sweep_vs_oracle_rhoB(hconj):
+    """rhoB uses the other absorption orientation (Hconj=False); compare one top-down sweep with the oracle."""
+    a = gpu_solver(ins=2)
+    b = sr.RefSolver(mode='Ising', Nx=4, Ny=4, Nc=8, J=gi.droplet_J(128, 2), beta=3.0)
+    kw = dict(graduate_truncation=False, Dmax=8, tolS=1e-16, tolV=1e-10, max_sweeps=4)
+    if hconj:
+        a._setup_rhoT(**kw), b._setup_rhoT(**kw)
+        ga, gb, oa, ob = a.rhoT, b.rhoT, a.rhoT_overlap, b.rhoT_overlap
+    else:
+        a._setup_rhoB(**kw), b._setup_rhoB(**kw)
+        ga, gb, oa, ob = a.rhoB, b.rhoB, a.rhoB_overlap, b.rhoB_overlap
+    np.testing.assert_allclose(np.array(oa, dtype=float), np.array(ob, dtype=float), atol=1e-12)
+    for x, y in zip(ga, gb):
+        assert fidelity(y, host_chain(x)) > 1 - 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ G6 / G7
+def g7():
+    with open(os.path.join(gi.GOLDEN_DIR, 'g7_search.json')) as f:
+        return json.load(f)
+
+
+_SENS = {}
+
+
+def oracle_sensitivity(L, ins, rot, chi, pre):
+    """|d log2P| of the CPU oracle itself when every QR input is perturbed by 1e-16 relative: the conditioning of
+    the reference algorithm on this instance (the survey's gesdd->gesvd probe gives the same order).  Ill-conditioned
+    instances (negative conditional probabilities, e.g. droplet #2) amplify rounding by ~1e8."""
+    key = (L, ins, rot, chi, pre)
+    if key not in _SENS:
+        n = {128: 4, 512: 8}[L]
+        out = []
+        for perturb in (False, True):
+            orig = mr.qr_pos
+            if perturb:
+                rng = np.random.default_rng(0)
+                mr.qr_pos = lambda T: orig(T * (1 + 1e-16 * rng.standard_normal(T.shape)))
+            try:
+                b = sr.RefSolver(mode='Ising', Nx=n, Ny=n, Nc=8, J=gi.droplet_J(L, ins), beta=3.0)
+                if rot:
+                    b.rotate_graph(rot)
+                if pre:
+                    b.precondition()
+                b.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi)
+                out.append(b.probability[0])
+            finally:
+                mr.qr_pos = orig
+        _SENS[key] = abs(out[0] - out[1])
+    return _SENS[key]
+
+
+def check_result(s, want, states=True, sens=0.0):
+    assert s.energy[0] == pytest.approx(want['energy'], abs=1e-10)
+    assert int(s.degeneracy) == want['degeneracy']
+    # 1e-9 or 100x the reference algorithm's own rounding sensitivity on this instance
+    assert s.probability[0] == pytest.approx(want['probability'], abs=max(1e-9, 100 * sens))
+    assert s.discarded_probability == pytest.approx(want['discarded_probability'], abs=max(1e-8, 100 * sens))
+    assert s.negative_probability == pytest.approx(want['negative_probability'], rel=1e-2, abs=1e-12)
+    if states:
+        assert len(s.energy) == want['n_states']
+        assert [int(x) for x in s.states[0]] == want['state0']
+        assert [int(x) for x in s.binary_states()[0]] == want['bits0']
+
+
+G7_CASES = [(128, 1, 0, 8, False), (128, 1, 3, 8, False), (128, 1, 0, 32, False), (128, 2, 1, 8, False),
+            (128, 3, 2, 8, False), (128, 2, 0, 32, False), (128, 1, 0, 8, True), (128, 3, 2, 32, True)]
+
+
+@pytest.mark.parametrize('L,ins,rot,chi,pre', G7_CASES)
+def test_search_golden(L, ins, rot, chi, pre):
+    want = g7()['L%d_i%d_r%d_chi%d_pre%d' % (L, ins, rot, chi, int(pre))]
+    s = gpu_solver(L=L, ins=ins, rot=rot, pre=pre)
+    s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi)
+    check_result(s, want, sens=oracle_sensitivity(L, ins, rot, chi, pre))
+    E, bits = gi.golden_groundstate(L, ins)                    # the reference's own golden file
+    assert s.energy[0] == pytest.approx(E, abs=1e-5)
+    assert np.array_equal(s.binary_states()[0], bits)
+    from tnac4o_amd import energy_Jij
+    assert energy_Jij(gi.droplet_J(L, ins), s.binary_states()[:1])[0] == pytest.approx(s.energy[0], abs=1e-9)
+
+
+def test_search_L512_golden():
+    want = g7()['L512_i1_r0_chi32_pre0']
+    s = gpu_solver(L=512)
+    s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=32)
+    check_result(s, want)
+    E, bits = gi.golden_groundstate(512, 1)
+    assert s.energy[0] == pytest.approx(E, abs=1e-5) and np.array_equal(s.binary_states()[0], bits)
+
+
+def test_search_rmf():
+    import tnac4o_amd
+    J = gi.minimal_rmf()
+    for rot in (0, 1):
+        s = tnac4o_amd.tnac4o(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=2.0)
+        if rot:
+            s.rotate_graph(rot)
+        s.search_ground_state(M=64, relative_P_cutoff=1e-8, Dmax=8)
+        check_result(s, g7()['RMF_r%d' % rot])
+        assert tnac4o_amd.energy_RMF(J, s.states[:1])[0] == pytest.approx(s.energy[0], abs=1e-10)
+
+
+def test_calc_pn_negative_rule():
+    """The negative-probability rule of tnac4o.py:1795-1807 on synthetic inputs, against the oracle's function."""
+    from tnac4o_amd import ops
+    rng = np.random.default_rng(3)
+    q, nl, nu, p, Dr, br, npref, nsuf, nb = 256, 4, 3, 16, 5, 16, 3, 4, 9
+    F = rng.uniform(0, 1, (q, nl, nu))
+    T1 = rng.standard_normal((npref, p, Dr))
+    RR = rng.standard_normal((nsuf, Dr, br))
+    RR[0] = 0.0                                                   # an all-zero branch -> uniform, flag -1
+    T1[2] = np.abs(T1[2])
+    RR[3] = np.abs(RR[3])                                         # an all-positive branch
+    dmap, rmap = rng.integers(0, p, q), rng.integers(0, br, q)
+    pref, suf = rng.integers(0, npref, nb), rng.integers(0, nsuf, nb)
+    suf[0], pref[1], suf[1] = 0, 2, 3
+    lidx, uidx = rng.integers(0, nl, nb), rng.integers(0, nu, nb)
+    dv = lambda x: torch.as_tensor(np.ascontiguousarray(x)).cuda()      # noqa: E731
+    P, mP = ops.calc_pn(dv(T1), dv(RR), dv(F), dv(dmap.astype(np.int32)), dv(rmap.astype(np.int32)),
+                        dv(pref.astype(np.int32)), dv(suf.astype(np.int32)), dv(lidx.astype(np.int32)),
+                        dv(uidx.astype(np.int32)))
+    P, mP = P.cpu().numpy(), mP.cpu().numpy()
+    for k in range(nb):
+        T2 = T1[pref[k]] @ RR[suf[k]]
+        Pn = F[:, lidx[k], uidx[k]] * T2[dmap, rmap]
+        m = Pn.min()
+        if m < 0:
+            low = Pn < abs(m)
+            Pn[low] = abs(m)
+            m *= low.sum()
+        no = Pn.sum()
+        if no > 0:
+            Pn, m = Pn / no, m / no
+        else:
+            Pn, m = Pn + 1.0 / q, -1
+        np.testing.assert_allclose(P[k], Pn, rtol=1e-12, atol=1e-300)
+        assert mP[k] == pytest.approx(m, rel=1e-10, abs=1e-300)
+    assert mP[0] == -1 and mP[1] >= 0
+
+
+def test_product_path_uses_hip_library():
+    """The loaded shared object is the in-tree libtnpeps.so and the product modules never import the oracle."""
+    import sys
+    import tnac4o_amd
+    from tnac4o_amd import _lib
+    assert os.path.samefile(_lib.lib()._name, os.path.join(os.path.dirname(tnac4o_amd.__file__), 'libtnpeps.so'))
+    for name in ('tnac4o_amd.tnac4o', 'tnac4o_amd.mps', 'tnac4o_amd.ops', 'tnac4o_amd._lib', 'tnac4o_amd.auxx'):
+        src = open(sys.modules[name].__file__).read()
+        assert 'oracle' not in src.replace("'oracle' not in", '')

@@ -1,0 +1,85 @@
+"""CPU-only checks of the product's host-side logic (coupling split, rotations, PEPS factor tables, energy
+bookkeeping) against the oracle, and of the C-ABI library's exports.  No GPU compute here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+from oracle import solver_ref as sr
+
+
+def test_library_exports_every_declared_symbol():
+    from tnac4o_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    header = open(os.path.join(os.path.dirname(_lib.HERE), 'include', 'tnpeps.h')).read()
+    declared = set(re.findall(r'\b(tn_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _lib.lib().tn_version() >= 1
+    # argument errors are reported without touching a GPU
+    rc = _lib.lib().tn_qr(None, 1, 1, 4, 4, None, 1, 1, None, 1, 1, 32, None, 0, None)
+    assert rc < 0
+    buf = ctypes.create_string_buffer(256)
+    _lib.lib().tn_last_error(buf, 256)
+    assert b'null operand' in buf.value
+
+
+def test_product_refuses_cpu_tensors():
+    import torch
+    from tnac4o_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.mm(torch.zeros(2, 2, dtype=torch.float64), torch.zeros(2, 2, dtype=torch.float64))
+
+
+@pytest.mark.parametrize('rot', [0, 1, 2, 3])
+def test_host_tables_match_oracle(rot):
+    import tnac4o_amd
+    J = gi.droplet_J(128, 2)
+    a = tnac4o_amd.tnac4o(mode='Ising', Nx=4, Ny=4, Nc=8, J=J, beta=3.0)
+    b = sr.RefSolver(mode='Ising', Nx=4, Ny=4, Nc=8, J=J, beta=3.0)
+    if rot:
+        a.rotate_graph(rot)
+        b.rotate_graph(rot)
+    assert np.array_equal(a.J, b.J) and np.array_equal(a.order, b.order) and np.array_equal(a.order_i, b.order_i)
+    assert a.rotation == b.rotation
+    rng = np.random.default_rng(rot)
+    a.Xu = b.Xu = rng.uniform(0.5, 2, a.Xu.shape)
+    a.Xd = b.Xd = rng.uniform(0.5, 2, a.Xd.shape)
+    for ny in range(4):
+        for nx in range(4):
+            Fa, da, ra, pda, bra = a._peps_factor(ny, nx)
+            Fb, db, rb, pdb, brb = b.peps_factor(ny, nx)
+            assert np.array_equal(Fa, Fb) and np.array_equal(da, db) and np.array_equal(ra, rb) and (pda, bra) == (pdb, brb)
+            assert np.array_equal(a._mpo_site(ny, nx), b.mpo_site(ny, nx))
+            st = rng.integers(0, 256, (7, 16)).astype(np.int8)
+            assert np.array_equal(a._update_Eng(st, ny, nx), b._update_Eng(st, ny, nx))
+            assert np.array_equal(a._ind_bond_down(st[:, 0], ny, nx), b._ind_bond_down(st[:, 0], ny, nx))
+            assert np.array_equal(a._ind_bond_right(st[:, 0], ny, nx), b._ind_bond_right(st[:, 0], ny, nx))
+
+
+def test_host_tables_rmf():
+    import tnac4o_amd
+    J = gi.minimal_rmf()
+    a = tnac4o_amd.tnac4o(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=2.0)
+    b = sr.RefSolver(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=2.0)
+    a.rotate_graph(1)
+    b.rotate_graph(1)
+    for ny in range(a.Ny):
+        for nx in range(a.Nx):
+            assert np.array_equal(a._mpo_site(ny, nx), b.mpo_site(ny, nx))
+
+
+def test_synthetic_chimera_topology():
+    from tnac4o_amd.auxx import synthetic_chimera
+    J = synthetic_chimera(4, 4, 20260003)
+    ref = np.loadtxt(os.path.join(gi.INST_DIR, 'chimera128_001.txt'))
+    assert len(J) == len(ref)
+    assert sorted((i, j) for i, j, _ in J) == sorted((int(r[0]) - 1, int(r[1]) - 1) for r in ref)
+    assert all(v != 0 and abs(round(v * 75) - v * 75) < 1e-9 for _, _, v in J)
+    assert synthetic_chimera(4, 4, 20260003) == J

@@ -1,0 +1,12 @@
+"""tnac4o_amd — MI355X-native boundary-MPS PEPS contraction engine behind the tnac4o call surface.
+
+    import tnac4o_amd as tnac4o
+    ins = tnac4o.tnac4o(mode='Ising', Nx=16, Ny=16, Nc=8, J=J, beta=3)
+    ins.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=64)
+
+Re-exports mirror the reference's tnac4o/__init__.py:1-2.  All compute runs in libtnpeps.so (hand-written HIP for
+gfx950); importing works without a GPU, running anything does not.
+"""
+from .auxx import load_Jij, round_Jij, minus_Jij, Jij_f2p, energy_Jij, energy_RMF  # noqa: F401
+from . import mps  # noqa: F401
+from .tnac4o import tnac4o  # noqa: F401

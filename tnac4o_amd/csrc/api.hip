@@ -1,0 +1,125 @@
+// extern "C" surface of libtnpeps (declared in include/tnpeps.h) + thread-local error text.
+#include <stdarg.h>
+
+#include "../../include/tnpeps.h"
+#include "common.h"
+
+namespace tn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// implemented in the other translation units
+int absorb(hipStream_t, const double*, const double*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
+int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
+              void*, int64_t);
+int64_t qr_ws_bytes(int64_t, int64_t, int);
+int svd_trunc(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double, double*, int64_t, int64_t, double*,
+              double*, int64_t, int64_t, int64_t*, double*, int*, int*, void*, int64_t);
+int svd_vals(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, double*, int*, int*, void*, int64_t);
+int64_t svd_ws_bytes(int64_t, int64_t, int);
+int nfactor(hipStream_t, const double*, int64_t, double*, void*);
+int scale_by(hipStream_t, double*, int64_t, const double*);
+int scale_phys(hipStream_t, double*, int64_t, int64_t, int64_t, const double*, int);
+int calc_pn(hipStream_t, const double*, const double*, const double*, const int32_t*, const int32_t*, const int32_t*,
+            const int32_t*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, double*,
+            double*);
+int nfactor_batched(hipStream_t, double*, int64_t, int64_t);
+
+}  // namespace tn
+
+using namespace tn;
+#define ST ((hipStream_t)stream)
+
+extern "C" {
+
+int tn_version(void) { return 1; }
+
+void tn_profile_enable(unsigned mask) { prof_set_mask(mask); }
+void tn_profile_reset(void) { prof_reset(); }
+int tn_profile_get(int family, uint64_t* calls_host, double* ms_host, double* flops_host, double* bytes_host) {
+    TN_CHECK_ARG(family >= 0 && family < PROF_NFAM, "unknown kernel family");
+    TN_CHECK_ARG(calls_host && ms_host && flops_host && bytes_host, "null output");
+    prof_get(family, calls_host, ms_host, flops_host, bytes_host);
+    return 0;
+}
+
+int tn_last_error(char* buf, int n) {
+    const char* e = get_error();
+    int len = (int)strlen(e);
+    if (buf && n > 0) {
+        int c = len < n - 1 ? len : n - 1;
+        memcpy(buf, e, c);
+        buf[c] = 0;
+    }
+    return len;
+}
+
+int tn_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa, const double* B,
+            int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc, int64_t batch, int64_t bsa,
+            int64_t bsb, int64_t bsc, void* ws, int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "negative dimension");
+    TN_CHECK_ARG(A && B && C, "null operand");
+    return gemm(ST, M, N, K, alpha, A, rsa, csa, B, rsb, csb, beta, C, rsc, csc, batch, bsa, bsb, bsc, (double*)ws, ws_bytes);
+}
+int64_t tn_gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch) { return gemm_ws_bytes(M, N, K, batch); }
+
+int tn_absorb(const double* A, const double* W, double* out, int64_t Dl, int64_t pold, int64_t Dr, int64_t ba, int64_t po,
+              int64_t bb, int64_t pi, int hconj, void* stream) {
+    TN_CHECK_ARG(A && W && out, "null operand");
+    return absorb(ST, A, W, out, Dl, pold, Dr, ba, po, bb, pi, hconj);
+}
+
+int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs, int64_t qcs, double* R, int64_t rrs,
+          int64_t rcs, int nb, void* ws, int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(A && Q && R && ws, "null operand");
+    return qr_factor(ST, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes);
+}
+int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_ws_bytes(m, n, nb); }
+
+int tn_svd_trunc(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol, double* U,
+                 int64_t urs, int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_host,
+                 double* discarded_host, int* sweeps_host, int* info_host, void* ws, int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(C && U && S && Vt && ws && keep_host, "null operand");
+    return svd_trunc(ST, C, crs, ccs, k, n, Dmax, tol, U, urs, ucs, S, Vt, vrs, vcs, keep_host, discarded_host, sweeps_host,
+                     info_host, ws, ws_bytes);
+}
+int tn_svdvals(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* S_host, int* sweeps_host,
+               int* info_host, void* ws, int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(C && S_host && ws, "null operand");
+    return svd_vals(ST, C, crs, ccs, k, n, S_host, sweeps_host, info_host, ws, ws_bytes);
+}
+int64_t tn_svd_ws_bytes(int64_t k, int64_t n, int vectors) { return svd_ws_bytes(k, n, vectors); }
+
+int tn_nfactor(const double* x, int64_t n, double* out2, void* slot8, void* stream) {
+    TN_CHECK_ARG(x && out2 && slot8, "null operand");
+    return nfactor(ST, x, n, out2, slot8);
+}
+int tn_scale_by(double* x, int64_t n, const double* scalar_dev, void* stream) {
+    TN_CHECK_ARG(x && scalar_dev, "null operand");
+    return scale_by(ST, x, n, scalar_dev);
+}
+int tn_scale_phys(double* A, int64_t Dl, int64_t p, int64_t Dr, const double* diag, int inv, void* stream) {
+    TN_CHECK_ARG(A && diag, "null operand");
+    return scale_phys(ST, A, Dl, p, Dr, diag, inv);
+}
+
+int tn_calc_pn(const double* T1, const double* RR, const double* F, const int32_t* dmap, const int32_t* rmap,
+               const int32_t* pref, const int32_t* suf, const int32_t* lidx, const int32_t* uidx, int64_t nb, int64_t q,
+               int64_t nl, int64_t nu, int64_t p, int64_t Dr, int64_t br, double* P, double* minP, void* stream) {
+    TN_CHECK_ARG(T1 && RR && F && dmap && rmap && pref && suf && lidx && uidx && P && minP, "null operand");
+    return calc_pn(ST, T1, RR, F, dmap, rmap, pref, suf, lidx, uidx, nb, q, nl, nu, p, Dr, br, P, minP);
+}
+int tn_nfactor_batched(double* x, int64_t batch, int64_t len, void* stream) {
+    TN_CHECK_ARG(x, "null operand");
+    return nfactor_batched(ST, x, batch, len);
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Shared helpers for libtnpeps (gfx950 only).  Internal header — the public C-ABI is include/tnpeps.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace tn {
+
+// thread-local error text, retrievable through tn_last_error()
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+inline int hip_fail(hipError_t e, const char* what) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e > 0 ? (int)e : 1;
+}
+
+#define TN_CHECK_ARG(cond, msg)                \
+    do {                                       \
+        if (!(cond)) {                         \
+            tn::set_error("%s: %s", __func__, msg); \
+            return -1;                         \
+        }                                      \
+    } while (0)
+
+#define TN_CHECK_LAUNCH(what)                          \
+    do {                                               \
+        hipError_t e__ = hipGetLastError();            \
+        if (e__ != hipSuccess) return tn::hip_fail(e__, what); \
+    } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+
+// ---- optional event timing per kernel family (prof.hip) ---------------------------------------------
+enum { PROF_GEMM_128x128 = 0, PROF_GEMM_128x32, PROF_GEMM_32x128, PROF_GEMM_64x64, PROF_SPLITK_REDUCE, PROF_ABSORB,
+       PROF_GRAM, PROF_EIG, PROF_ROWS_SMALL, PROF_VECS_SMALL, PROF_NFAM };
+bool prof_on(int fam);
+void prof_begin(hipStream_t st, int fam);
+void prof_end(hipStream_t st, int fam, double flops, double bytes);
+void prof_set_mask(unsigned mask);
+void prof_reset();
+void prof_get(int fam, uint64_t* calls, double* ms, double* flops, double* bytes);
+
+// ---- strided matrix view (element strides) -------------------------------------------------
+struct Mat {
+    double* p;
+    int64_t rs, cs;     // row stride, column stride (in doubles)
+};
+static inline Mat mat(double* p, int64_t rs, int64_t cs) { return Mat{p, rs, cs}; }
+static inline Mat sub(Mat a, int64_t i, int64_t j) { return Mat{a.p + i * a.rs + j * a.cs, a.rs, a.cs}; }
+static inline Mat tr(Mat a) { return Mat{a.p, a.cs, a.rs}; }
+
+// ---- internal GEMM entry (gemm_f64.hip) --------------------------------------------------------
+// C[M,N] = alpha * A[M,K] * B[K,N] + beta * C, arbitrary element strides, optional batch.
+// ws/ws_bytes: optional split-K scratch (may be null -> no split).
+int gemm(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
+         const double* B, int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc,
+         int64_t batch = 1, int64_t bsa = 0, int64_t bsb = 0, int64_t bsc = 0, double* ws = nullptr,
+         int64_t ws_bytes = 0);
+int64_t gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch);
+
+static inline int gemm(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, Mat A, Mat B, double beta, Mat C,
+                       double* ws = nullptr, int64_t ws_bytes = 0) {
+    return gemm(st, M, N, K, alpha, A.p, A.rs, A.cs, B.p, B.rs, B.cs, beta, C.p, C.rs, C.cs, 1, 0, 0, 0, ws, ws_bytes);
+}
+
+// ---- small dense kernels (small.hip) ------------------------------------------------------------
+constexpr int NBMAX = 64;      // largest panel / Jacobi pair width handled by the single-workgroup kernels
+
+// Partial Gram matrices of `nvec` vectors of length L:  G[i][j] = sum_c X(i,c) X(j,c).
+// Vector v, element c lives at X + vec_off[v] + c*es  where vec_off is given by (blk0,blk1,w,vs):
+//   v <  w : (blk0*w + v) * vs ;  v >= w : (blk1*w + v - w) * vs.   pairs==nullptr -> single group blk0=0,blk1=1.
+// Output: part[(g*nchunk + chunk)*nvec*nvec + i*nvec + j].
+int gram_partial(hipStream_t st, const double* X, int64_t vs, int64_t es, int64_t L, int nvec, int w, const int* pairs,
+                 int ngroups, int nchunk, double* part);
+int gram_nchunk(int64_t L);
+
+// Sum partials, (optionally) scale to unit diagonal, diagonalise with parallel-order Jacobi.
+// mode 0: QR panel step  -> out = D^-1 J         (columns with squared norm <= dead_thresh are flagged in
+//         dead[g*nvec+i] and get a zero row/column in out)
+// mode 1: normalise only -> out = D^-1
+// mode 2: SVD pair step  -> out = J (orthogonal), unscaled Gram; nrot[g] = rotations applied, maxoff[g] = largest
+//         relative off-diagonal seen before rotating.
+int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngroups, int mode, int max_sweeps,
+              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff);
+
+// In place:  X(r, 0:b) <- X(r, 0:b) * S   for r < nrows  (S is b x b row-major in global memory).
+int rows_times_small(hipStream_t st, double* X, int64_t rs, int64_t cs, int64_t nrows, int b, const double* S);
+
+// Out(v, c) = sum_u S[u][v] * In(u, c)  for the nvec vectors of each group (same addressing as gram_partial),
+// c < L; in place when Out == In.  If nrot != nullptr groups with nrot[g]==0 are skipped.
+int small_t_times_vecs(hipStream_t st, const double* S, double* X, int64_t vs, int64_t es, int64_t L, int nvec, int w,
+                       const int* pairs, int ngroups, const int* nrot);
+
+}  // namespace tn

@@ -1,0 +1,240 @@
+// fp64 GEMM on the gfx950 matrix cores (v_mfma_f64_16x16x4_f64), arbitrary element strides.
+//
+// K2 of SURVEY.md §8a: every tensordot of the reference's mps.py (attach_CA/AC :740-746, _mps_RL/_RR
+// :655-663, _mps_RAR :748-751, projector application :579-580) is a strided view of this kernel, so no
+// transposed copies are ever materialised.
+//
+// Tile: BM x BN per 256-thread workgroup (4 waves as 2 x 2), BK = 16.  Operands are staged through LDS
+// k-major (As[k][m], Bs[k][n]) with pitch = B? + 16 doubles and an XOR swizzle of the low 4 column bits by
+// k, which makes both the fragment reads (ds_read_b64, 16 consecutive doubles per k) and the transposed
+// stores of k-contiguous operands bank-conflict free.  The next K-tile is prefetched into registers while
+// the current one is multiplied.  MFMA f64 lane maps (cdna_hip_programming.md §3): A[l&15][l>>4],
+// B[l>>4][l&15], D reg r -> row (l>>4)+4r, col l&15.
+#include "common.h"
+
+namespace tn {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct GemmP {
+    const double* A;
+    const double* B;
+    double* C;
+    int64_t M, N, K;
+    int64_t rsa, csa, rsb, csb, rsc, csc;
+    int64_t bsa, bsb, bsc;
+    double alpha, beta;
+    int splitk;
+    int64_t kchunk;     // K range per split (multiple of 16)
+    double* ws;         // split-K partials [(batch*splitk+s)][M][N]
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 16;
+
+template <int BM, int BN, bool AKFAST, bool BKFAST>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
+    constexpr int PA = BM + 16, PB = BN + 16;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;     // elements per thread per tile
+    __shared__ double As[BK * PA];
+    __shared__ double Bs[BK * PB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: consecutive tiles of one output row-panel land on the same XCD (L2 reuse of A)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm0 = (bid / g.tiles_n) * BM, tn0 = (bid % g.tiles_n) * BN;
+    const int zb = blockIdx.z / g.splitk, zs = blockIdx.z % g.splitk;
+    const double* A = g.A + zb * g.bsa;
+    const double* B = g.B + zb * g.bsb;
+    const int64_t k_lo = zs * g.kchunk;
+    const int64_t k_hi = (k_lo + g.kchunk < g.K) ? k_lo + g.kchunk : g.K;
+
+    double ra[EA], rb[EB];
+    auto load_tiles = [&](int64_t k0) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            const int idx = tid + 256 * e;
+            const int m = AKFAST ? idx / BK : idx % BM;
+            const int k = AKFAST ? idx % BK : idx / BM;
+            const int64_t gm = tm0 + m, gk = k0 + k;
+            ra[e] = (gm < g.M && gk < k_hi) ? A[gm * g.rsa + gk * g.csa] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int idx = tid + 256 * e;
+            const int n = BKFAST ? idx / BK : idx % BN;
+            const int k = BKFAST ? idx % BK : idx / BN;
+            const int64_t gn = tn0 + n, gk = k0 + k;
+            rb[e] = (gn < g.N && gk < k_hi) ? B[gk * g.rsb + gn * g.csb] : 0.0;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            const int idx = tid + 256 * e;
+            const int m = AKFAST ? idx / BK : idx % BM;
+            const int k = AKFAST ? idx % BK : idx / BM;
+            As[k * PA + (m ^ k)] = ra[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int idx = tid + 256 * e;
+            const int n = BKFAST ? idx / BK : idx % BN;
+            const int k = BKFAST ? idx % BK : idx / BN;
+            Bs[k * PB + (n ^ k)] = rb[e];
+        }
+    };
+
+    d4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const int lr = lane & 15, lk = lane >> 4;
+    if (k_lo < k_hi) load_tiles(k_lo);
+    for (int64_t k0 = k_lo; k0 < k_hi; k0 += BK) {
+        store_tiles();
+        __syncthreads();
+        if (k0 + BK < k_hi) load_tiles(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int k = kk * 4 + lk;
+            double a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[k * PA + ((wm * WM + i * 16 + lr) ^ k)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[k * PB + ((wn * WN + j * 16 + lr) ^ k)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    if (g.splitk > 1) {
+        double* W = g.ws + (int64_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = tm0 + wm * WM + i * 16 + lk + 4 * r, col = tn0 + wn * WN + j * 16 + lr;
+                    if (row < g.M && col < g.N) W[row * g.N + col] = acc[i][j][r];
+                }
+    } else {
+        double* C = g.C + zb * g.bsc;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = tm0 + wm * WM + i * 16 + lk + 4 * r, col = tn0 + wn * WN + j * 16 + lr;
+                    if (row < g.M && col < g.N) {
+                        double* c = C + row * g.rsc + col * g.csc;
+                        double v = g.alpha * acc[i][j][r];
+                        if (g.beta != 0.0) v += g.beta * *c;
+                        *c = v;
+                    }
+                }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP g) {
+    const int64_t mn = g.M * g.N;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int zb = blockIdx.y;
+    if (e >= mn) return;
+    const double* W = g.ws + (int64_t)zb * g.splitk * mn + e;
+    double s = 0.0;
+    for (int k = 0; k < g.splitk; ++k) s += W[(int64_t)k * mn];
+    const int64_t row = e / g.N, col = e % g.N;
+    double* c = g.C + zb * g.bsc + row * g.rsc + col * g.csc;
+    double v = g.alpha * s;
+    if (g.beta != 0.0) v += g.beta * *c;
+    *c = v;
+}
+
+template <int BM, int BN>
+static void launch_tile(hipStream_t st, const GemmP& g, dim3 grid, bool ak, bool bk) {
+    if (ak && bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, dim3(256), 0, st, g);
+    else if (ak) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false>), grid, dim3(256), 0, st, g);
+    else if (bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, dim3(256), 0, st, g);
+}
+
+static void pick_tile(int64_t M, int64_t N, int& bm, int& bn) {
+    if (M > 64 && N > 64) { bm = 128; bn = 128; }
+    else if (N <= 32 && M > 64) { bm = 128; bn = 32; }
+    else if (M <= 32 && N > 64) { bm = 32; bn = 128; }
+    else { bm = 64; bn = 64; }
+}
+
+static int pick_splitk(int64_t M, int64_t N, int64_t K, int64_t batch) {
+    int bm, bn;
+    pick_tile(M, N, bm, bn);
+    const int64_t tiles = cdiv(M, bm) * cdiv(N, bn) * batch;
+    if (tiles >= 192 || K < 512) return 1;
+    int64_t s = cdiv(512, tiles);
+    const int64_t smax = K / 128;     // keep at least 128 of K per split
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    return s < 2 ? 1 : (int)s;
+}
+
+int64_t gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch) {
+    const int s = pick_splitk(M, N, K, batch);
+    return s > 1 ? (int64_t)s * batch * M * N * 8 : 0;
+}
+
+int gemm(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
+         const double* B, int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc, int64_t batch,
+         int64_t bsa, int64_t bsb, int64_t bsc, double* ws, int64_t ws_bytes) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    TN_CHECK_ARG(K >= 0, "negative K");
+    GemmP g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.rsa = rsa; g.csa = csa; g.rsb = rsb; g.csb = csb; g.rsc = rsc; g.csc = csc;
+    g.bsa = bsa; g.bsb = bsb; g.bsc = bsc; g.alpha = alpha; g.beta = beta; g.ws = ws;
+    int bm, bn;
+    pick_tile(M, N, bm, bn);
+    g.tiles_m = (int)cdiv(M, bm); g.tiles_n = (int)cdiv(N, bn);
+    int s = pick_splitk(M, N, K, batch);
+    if (s > 1 && (ws == nullptr || ws_bytes < (int64_t)s * batch * M * N * 8)) s = 1;
+    g.splitk = s;
+    g.kchunk = s > 1 ? align_up(cdiv(K, s), BK) : (K > 0 ? align_up(K, BK) : BK);
+    if (s > 1) g.splitk = s = (int)cdiv(K, g.kchunk);
+    TN_CHECK_ARG(batch * s <= 65535, "batch*splitk exceeds grid.z");
+    const bool ak = (csa == 1 && rsa != 1), bk = (rsb == 1 && csb != 1);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, (unsigned)(batch * s));
+    const int fam = (bm == 128 && bn == 128) ? PROF_GEMM_128x128 : (bm == 128) ? PROF_GEMM_128x32
+                    : (bm == 32) ? PROF_GEMM_32x128 : PROF_GEMM_64x64;
+    prof_begin(st, fam);
+    if (bm == 128 && bn == 128) launch_tile<128, 128>(st, g, grid, ak, bk);
+    else if (bm == 128 && bn == 32) launch_tile<128, 32>(st, g, grid, ak, bk);
+    else if (bm == 32 && bn == 128) launch_tile<32, 128>(st, g, grid, ak, bk);
+    else launch_tile<64, 64>(st, g, grid, ak, bk);
+    TN_CHECK_LAUNCH("gemm_kernel");
+    // algorithmic work of SURVEY.md §8d: 2MNK flops, 8(MK + KN + MN) bytes
+    prof_end(st, fam, 2.0 * M * N * K * batch, 8.0 * batch * ((double)M * K + (double)K * N + (double)M * N));
+    if (s > 1) {
+        dim3 rg((unsigned)cdiv(M * N, 256), (unsigned)batch);
+        prof_begin(st, PROF_SPLITK_REDUCE);
+        hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, st, g);
+        TN_CHECK_LAUNCH("splitk_reduce_kernel");
+        prof_end(st, PROF_SPLITK_REDUCE, (double)s * M * N * batch, 8.0 * batch * ((double)s + 1.0) * M * N);
+    }
+    return 0;
+}
+
+}  // namespace tn

@@ -1,0 +1,82 @@
+// K6 and small elementwise helpers: power-of-two normalisation factor (reference mps.py:76-85), scaling by its
+// inverse (mps.py:782, 797; tnac4o.py:533, 1781), diagonal operator on the physical leg (mps.py:361-366).
+#include "common.h"
+
+namespace tn {
+
+// max |x| via atomicMax on the bit pattern (non-negative doubles order like unsigned integers)
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const double* __restrict__ x, int64_t n,
+                                                          unsigned long long* __restrict__ slot) {
+    __shared__ unsigned long long red[256];
+    const int tid = threadIdx.x;
+    unsigned long long m = 0ULL;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(x[i]));
+        m = b > m ? b : m;
+    }
+    red[tid] = m;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) red[tid] = red[tid] > red[tid + k] ? red[tid] : red[tid + k];
+        __syncthreads();
+    }
+    if (tid == 0) atomicMax(slot, red[0]);
+}
+
+// out[0] = 2^floor(log2(max|x|)) from the exponent field (2^-1023 for zero/subnormal input, like the reference);
+// out[1] = its reciprocal.  NaN/Inf input propagates an Inf factor.
+__global__ void nfactor_finish_kernel(const unsigned long long* __restrict__ slot, double* __restrict__ out) {
+    const long long e = (long long)(slot[0] >> 52) - 1023;
+    const double f = ldexp(1.0, (int)e);
+    out[0] = f;
+    out[1] = 1.0 / f;
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(double* __restrict__ x, int64_t n, const double* __restrict__ s) {
+    const double f = s[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= f;
+}
+
+int nfactor(hipStream_t st, const double* x, int64_t n, double* out2, void* slot8) {
+    TN_CHECK_ARG(n >= 1, "empty input");
+    hipError_t e = hipMemsetAsync(slot8, 0, 8, st);
+    if (e != hipSuccess) return hip_fail(e, "memset slot");
+    int64_t nb = cdiv(n, 256 * 8);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, n, (unsigned long long*)slot8);
+    TN_CHECK_LAUNCH("absmax_bits_kernel");
+    hipLaunchKernelGGL(nfactor_finish_kernel, dim3(1), dim3(1), 0, st, (const unsigned long long*)slot8, out2);
+    TN_CHECK_LAUNCH("nfactor_finish_kernel");
+    return 0;
+}
+
+int scale_by(hipStream_t st, double* x, int64_t n, const double* scalar_dev) {
+    if (n <= 0) return 0;
+    int64_t nb = cdiv(n, 256 * 4);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, n, scalar_dev);
+    TN_CHECK_LAUNCH("scale_by_kernel");
+    return 0;
+}
+
+// A[dl, s, dr] *= diag[s]   (inv != 0: divide)
+__global__ __launch_bounds__(256) void scale_phys_kernel(double* __restrict__ A, int64_t Dl, int64_t p, int64_t Dr,
+                                                         const double* __restrict__ diag, int inv) {
+    const int64_t n = Dl * p * Dr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double d = diag[(i / Dr) % p];
+        A[i] = inv ? A[i] / d : A[i] * d;
+    }
+}
+
+int scale_phys(hipStream_t st, double* A, int64_t Dl, int64_t p, int64_t Dr, const double* diag, int inv) {
+    const int64_t n = Dl * p * Dr;
+    if (n <= 0) return 0;
+    int64_t nb = cdiv(n, 256 * 4);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(scale_phys_kernel, dim3((unsigned)nb), dim3(256), 0, st, A, Dl, p, Dr, diag, inv);
+    TN_CHECK_LAUNCH("scale_phys_kernel");
+    return 0;
+}
+
+}  // namespace tn

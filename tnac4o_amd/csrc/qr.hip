@@ -1,0 +1,359 @@
+// K3 — economic QR with non-negative diagonal of R (reference mps.py:43-59; call sites orth_left/right :532-548).
+//
+// Blocked Householder QR designed for launch-level parallelism instead of LAPACK's column-serial panel:
+//   for each panel (nb columns of the trailing matrix):
+//     1. orthonormalise the panel by 4 rounds of "scaled Gram -> Jacobi eigenvectors -> W <- W D^-1 J"
+//        (one-sided block Jacobi on the panel; columns that are exactly zero or collapse to rounding noise are
+//        refilled with hash noise so the basis is complete), then normalise;
+//     2. Householder reconstruction (Ballard et al. 2014): sign-choosing LU of the top block gives Y (unit lower
+//        trapezoidal) and T with  H = I - Y T Y^T,  H[:, :nb] = Q1 S;
+//     3. trailing update  A <- H^T A  as three GEMMs on the MFMA kernel.
+//   Q = H_1 ... H_P [Z; 0] accumulated backwards with GEMMs; the dense nb x nb diagonal blocks left by step 1 are
+//   triangularised by small Householder QRs (Z), which also fixes diag(R) >= 0.
+// Every transformation applied to A is orthogonal to rounding (the Gram matrices only steer the rotations), so the
+// factorisation is column-wise backward stable like dgeqrf even for the numerically rank-deficient, strongly graded
+// matrices this path produces (validated against LAPACK on matrices captured from the droplet sweeps).
+#include <stdlib.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace tn {
+
+// ------------------------------------------------------------------------------------------ helpers
+__global__ __launch_bounds__(256) void copy_mat_kernel(const double* __restrict__ S, int64_t srs, int64_t scs,
+                                                       double* __restrict__ D, int64_t drs, int64_t dcs, int64_t m,
+                                                       int64_t n, int colfast) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * n) return;
+    const int64_t i = colfast ? e / n : e % m, j = colfast ? e % n : e / m;
+    D[i * drs + j * dcs] = S[i * srs + j * scs];
+}
+
+int copy_mat(hipStream_t st, const double* S, int64_t srs, int64_t scs, double* D, int64_t drs, int64_t dcs, int64_t m,
+             int64_t n) {
+    if (m <= 0 || n <= 0) return 0;
+    const int colfast = (dcs == 1 || scs == 1) ? 1 : 0;
+    hipLaunchKernelGGL(copy_mat_kernel, dim3((unsigned)cdiv(m * n, 256)), dim3(256), 0, st, S, srs, scs, D, drs, dcs, m,
+                       n, colfast);
+    TN_CHECK_LAUNCH("copy_mat_kernel");
+    return 0;
+}
+
+__device__ __forceinline__ double hash_unit(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return ((double)(x >> 11) * (1.0 / 9007199254740992.0)) - 0.5;
+}
+
+// columns of the panel flagged dead (exactly zero) get deterministic pseudo-random content
+__global__ __launch_bounds__(256) void refill_dead_kernel(double* __restrict__ W, int64_t rs, int64_t cs, int64_t m,
+                                                          int b, const int* __restrict__ dead, uint64_t seed) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    for (int j = 0; j < b; ++j)
+        if (dead[j]) W[r * rs + j * cs] = hash_unit(seed + (uint64_t)r * 64 + j);
+}
+
+// ------------------------------------------------------------------------------------------ reconstruction
+// One workgroup.  In: top b x b block of the orthonormal panel (strided).  Out: Y1 (unit lower triangular, written
+// back in place with explicit zeros/ones), Uinv (b x b), T (b x b upper).
+template <int NB>
+__global__ __launch_bounds__(256) void lu_reconstruct_kernel(double* __restrict__ Ytop, int64_t rs, int64_t cs, int b,
+                                                             double* __restrict__ Uinv, double* __restrict__ T) {
+    constexpr int P = NB + 1;
+    __shared__ double B[NB * P];
+    __shared__ double Li[NB * P];
+    __shared__ double Ui[NB * P];
+    __shared__ double sg[NB];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < b * b; e += 256) {
+        const int i = e / b, j = e % b;
+        B[i * P + j] = Ytop[i * rs + j * cs];
+    }
+    for (int e = tid; e < NB * P; e += 256) { Li[e] = 0.0; Ui[e] = 0.0; }
+    __syncthreads();
+    for (int i = 0; i < b; ++i) {
+        if (tid == 0) {
+            const double s = (B[i * P + i] >= 0.0) ? -1.0 : 1.0;
+            sg[i] = s;
+            B[i * P + i] -= s;
+        }
+        __syncthreads();
+        const double piv = B[i * P + i];
+        for (int r = i + 1 + tid; r < b; r += 256) B[r * P + i] /= piv;
+        __syncthreads();
+        const int rem = b - i - 1;
+        for (int e = tid; e < rem * rem; e += 256) {
+            const int r = i + 1 + e / rem, c = i + 1 + e % rem;
+            B[r * P + c] -= B[r * P + i] * B[i * P + c];
+        }
+        __syncthreads();
+    }
+    if (tid < b) {                               // column tid of U^-1 (back substitution)
+        const int j = tid;
+        Ui[j * P + j] = 1.0 / B[j * P + j];
+        for (int i = j - 1; i >= 0; --i) {
+            double s = 0.0;
+            for (int k = i + 1; k <= j; ++k) s += B[i * P + k] * Ui[k * P + j];
+            Ui[i * P + j] = -s / B[i * P + i];
+        }
+    } else if (tid >= 64 && tid < 64 + b) {      // column of L1^-1 (forward substitution), second wave
+        const int j = tid - 64;
+        Li[j * P + j] = 1.0;
+        for (int i = j + 1; i < b; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s += B[i * P + k] * Li[k * P + j];
+            Li[i * P + j] = -s;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < b * b; e += 256) {
+        const int i = e / b, j = e % b;
+        double t = 0.0;
+        if (i <= j) {
+            for (int k = i; k <= j; ++k) t += B[i * P + k] * sg[k] * Li[j * P + k];
+            t = -t;
+        }
+        T[e] = t;
+        Uinv[e] = Ui[i * P + j];
+        Ytop[i * rs + j * cs] = (i > j) ? B[i * P + j] : (i == j ? 1.0 : 0.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ diagonal blocks
+// One workgroup per diagonal block: Householder QR  D = Z Tri  with diag(Tri) >= 0.
+template <int NB>
+__global__ __launch_bounds__(256) void diag_qr_kernel(const double* __restrict__ A, int64_t rs, int64_t cs, int nb,
+                                                      int64_t k, double* __restrict__ Zbuf, double* __restrict__ Tri) {
+    constexpr int P = NB + 1;
+    __shared__ double D[NB * P];
+    __shared__ double Z[NB * P];
+    __shared__ double tau[NB];
+    const int tid = threadIdx.x, p = blockIdx.x;
+    const int64_t j0 = (int64_t)p * nb;
+    const int b = (int)((k - j0 < nb) ? k - j0 : nb);
+    for (int e = tid; e < b * b; e += 256) {
+        const int i = e / b, j = e % b;
+        D[i * P + j] = A[(j0 + i) * rs + (j0 + j) * cs];
+        Z[i * P + j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < b; ++j) {
+        if (tid == 0) {
+            double sigma = 0.0, amax = 0.0;
+            for (int r = j + 1; r < b; ++r) amax = fmax(amax, fabs(D[r * P + j]));
+            const double alpha = D[j * P + j];
+            double t = 0.0;
+            if (amax > 0.0) {
+                // everything in units of sc, so that repeated cancellation (entries down to the subnormal range for
+                // exactly dependent columns) can neither overflow 1/(alpha - beta) nor underflow the norm
+                const double sc = fmax(amax, fabs(alpha));
+                for (int r = j + 1; r < b; ++r) { const double x = D[r * P + j] / sc; sigma += x * x; }
+                const double as = alpha / sc;
+                const double bs = -copysign(sqrt(as * as + sigma), as);
+                t = (bs - as) / bs;
+                const double invs = 1.0 / (as - bs);
+                for (int r = j + 1; r < b; ++r) D[r * P + j] = (D[r * P + j] / sc) * invs;
+                D[j * P + j] = bs * sc;
+            }
+            tau[j] = t;
+        }
+        __syncthreads();
+        const double t = tau[j];
+        if (t != 0.0) {
+            for (int c = j + 1 + tid; c < b; c += 256) {
+                double w = D[j * P + c];
+                for (int r = j + 1; r < b; ++r) w += D[r * P + j] * D[r * P + c];
+                w *= t;
+                D[j * P + c] -= w;
+                for (int r = j + 1; r < b; ++r) D[r * P + c] -= D[r * P + j] * w;
+            }
+        }
+        __syncthreads();
+    }
+    for (int j = b - 1; j >= 0; --j) {            // Z = H_0 ... H_{b-1}
+        const double t = tau[j];
+        if (t != 0.0) {
+            for (int c = tid; c < b; c += 256) {
+                double w = Z[j * P + c];
+                for (int r = j + 1; r < b; ++r) w += D[r * P + j] * Z[r * P + c];
+                w *= t;
+                Z[j * P + c] -= w;
+                for (int r = j + 1; r < b; ++r) Z[r * P + c] -= D[r * P + j] * w;
+            }
+        }
+        __syncthreads();
+    }
+    double* zo = Zbuf + (int64_t)p * nb * nb;
+    double* to = Tri + (int64_t)p * nb * nb;
+    for (int e = tid; e < b * b; e += 256) {
+        const int i = e / b, j = e % b;
+        const double sj = (D[j * P + j] < 0.0) ? -1.0 : 1.0, si = (D[i * P + i] < 0.0) ? -1.0 : 1.0;
+        zo[i * nb + j] = Z[i * P + j] * sj;                  // column j of Z scaled
+        to[i * nb + j] = (i <= j) ? D[i * P + j] * si : 0.0; // row i of Tri scaled
+    }
+}
+
+// R[i][j]: 0 left of the diagonal block, Tri inside it, Z^T A to the right.
+__global__ __launch_bounds__(256) void assemble_R_kernel(const double* __restrict__ A, int64_t rs, int64_t cs, int nb,
+                                                         int64_t k, int64_t n, const double* __restrict__ Zbuf,
+                                                         const double* __restrict__ Tri, double* __restrict__ R,
+                                                         int64_t rrs, int64_t rcs) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= k * n) return;
+    const int64_t i = e / n, j = e % n;
+    const int64_t p = i / nb, j0 = p * nb;
+    const int b = (int)((k - j0 < nb) ? k - j0 : nb);
+    const int il = (int)(i - j0);
+    double v = 0.0;
+    if (j >= j0 + b) {
+        const double* z = Zbuf + p * nb * nb;
+        for (int r = 0; r < b; ++r) v += z[r * nb + il] * A[(j0 + r) * rs + j * cs];
+    } else if (j >= j0) {
+        v = Tri[p * nb * nb + il * nb + (j - j0)];
+    }
+    R[i * rrs + j * rcs] = v;
+}
+
+__global__ __launch_bounds__(256) void init_Q_kernel(double* __restrict__ Q, int64_t rs, int64_t cs, int64_t m, int64_t k,
+                                                     int nb, const double* __restrict__ Zbuf, int colfast) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * k) return;
+    const int64_t i = colfast ? e / k : e % m, j = colfast ? e % k : e / m;
+    double v = 0.0;
+    if (i < k && i / nb == j / nb) {
+        const int64_t p = i / nb;
+        v = Zbuf[p * nb * nb + (i - p * nb) * nb + (j - p * nb)];
+    }
+    Q[i * rs + j * cs] = v;
+}
+
+// ------------------------------------------------------------------------------------------ driver
+// TN_DEBUG=1: synchronise after each stage and report the first non-finite intermediate (diagnostics only)
+static bool dbg_on() { static int v = -1; if (v < 0) { const char* e = getenv("TN_DEBUG"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
+static void dbg_check(hipStream_t st, const double* p, int64_t rs, int64_t cs, int64_t m, int64_t n, const char* what, int panel, int it) {
+    if (!dbg_on()) return;
+    std::vector<double> h((size_t)(m * n));
+    hipStreamSynchronize(st);
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < n; ++j) hipMemcpy(&h[i * n + j], p + i * rs + j * cs, 8, hipMemcpyDeviceToHost);
+    double mx = 0, mn = 1e300; int bad = 0;
+    for (double v : h) { if (!(v == v) || v > 1e300 || v < -1e300) ++bad; else { double a = v < 0 ? -v : v; if (a > mx) mx = a; if (a < mn) mn = a; } }
+    fprintf(stderr, "[tn_qr dbg] panel %d it %d %-10s %lldx%lld nonfinite=%d max=%.3e min|.|=%.3e\n", panel, it, what, (long long)m, (long long)n, bad, mx, mn);
+}
+
+struct QrWs {
+    double *Y, *T, *X, *X2, *part, *Js, *Uinv, *Z, *Tri, *gemm_ws;
+    int* dead;
+    int64_t gemm_ws_bytes;
+};
+
+static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
+    const int64_t k = m < n ? m : n, P = cdiv(k, nb);
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { int64_t o = off; off += align_up(bytes, 256); return base ? base + o : nullptr; };
+    double* Y = (double*)take(m * k * 8);
+    double* T = (double*)take(P * nb * nb * 8);
+    double* X = (double*)take((int64_t)nb * (n > k ? n : k) * 8);
+    double* X2 = (double*)take((int64_t)nb * (n > k ? n : k) * 8);
+    double* part = (double*)take((int64_t)64 * nb * nb * 8);
+    double* Js = (double*)take((int64_t)nb * nb * 8);
+    double* Uinv = (double*)take((int64_t)nb * nb * 8);
+    double* Z = (double*)take(P * nb * nb * 8);
+    double* Tri = (double*)take(P * nb * nb * 8);
+    int* dead = (int*)take(nb * 4);
+    // split-K scratch for the tall TN products (b x n, K = m)
+    int64_t gw = gemm_ws_bytes(nb, n > k ? n : k, m, 1);
+    if (gw < 0) gw = 0;
+    double* gws = (double*)take(gw + 256);
+    if (w) { w->Y = Y; w->T = T; w->X = X; w->X2 = X2; w->part = part; w->Js = Js; w->Uinv = Uinv; w->Z = Z; w->Tri = Tri;
+             w->dead = dead; w->gemm_ws = gws; w->gemm_ws_bytes = gw; }
+    return off;
+}
+
+int64_t qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_layout(m, n, nb, nullptr, nullptr); }
+
+int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
+              int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes) {
+    TN_CHECK_ARG(m >= 1 && n >= 1, "empty matrix");
+    TN_CHECK_ARG(nb == 32 || nb == 64, "nb must be 32 or 64");
+    TN_CHECK_ARG(ws_bytes >= qr_ws_bytes(m, n, nb), "workspace too small");
+    QrWs w;
+    qr_layout(m, n, nb, (char*)ws, &w);
+    const int64_t k = m < n ? m : n;
+    const int P = (int)cdiv(k, nb);
+    // Y shares A's fast direction so panel kernels coalesce the same way
+    const bool rowmajor = (cs == 1 && rs != 1);
+    const int64_t yrs = rowmajor ? k : 1, ycs = rowmajor ? 1 : m;
+    Mat Am = mat(A, rs, cs), Ym = mat(w.Y, yrs, ycs);
+    int rc;
+    for (int p = 0; p < P; ++p) {
+        const int64_t j0 = (int64_t)p * nb;
+        const int b = (int)((k - j0 < nb) ? k - j0 : nb);
+        const int64_t mp = m - j0, ntr = n - j0;
+        Mat Ap = sub(Am, j0, j0), Yp = sub(Ym, j0, j0);
+        if ((rc = copy_mat(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b))) return rc;
+        // --- panel orthonormalisation: columns of Yp are the vectors (vs = ycs, es = yrs)
+        const int nchunk = gram_nchunk(mp);
+        for (int it = 0; it < 5; ++it) {
+            if ((rc = gram_partial(st, Yp.p, ycs, yrs, mp, b, b, nullptr, 1, nchunk, w.part))) return rc;
+            const int mode = (it < 4) ? 0 : 1;
+            // after the first round the columns are images of unit columns under an orthogonal J: a squared norm below
+            // 1e-26 there is rounding noise (possibly structured, e.g. all parallel), so the column is refilled
+            if ((rc = eig_small(st, w.part, nchunk, b, 1, mode, 12, it == 0 ? 0.0 : 1e-26, w.Js, mode == 0 ? w.dead : nullptr,
+                                nullptr, nullptr)))
+                return rc;
+            dbg_check(st, w.Js, b, 1, b, b, "Js", p, it);
+            if ((rc = rows_times_small(st, Yp.p, yrs, ycs, mp, b, w.Js))) return rc;
+            dbg_check(st, Yp.p, yrs, ycs, mp < 64 ? mp : 64, b, "W", p, it);
+            if (mode == 0) {
+                hipLaunchKernelGGL(refill_dead_kernel, dim3((unsigned)cdiv(mp, 256)), dim3(256), 0, st, Yp.p, yrs, ycs, mp,
+                                   b, w.dead, (uint64_t)(0x9E3779B97F4A7C15ULL * (uint64_t)(p * 4 + it + 1)));
+                TN_CHECK_LAUNCH("refill_dead_kernel");
+            }
+        }
+        // --- Householder reconstruction
+        double* Tp = w.T + (int64_t)p * nb * nb;
+        if (nb == 32) hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp);
+        else hipLaunchKernelGGL((lu_reconstruct_kernel<64>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp);
+        TN_CHECK_LAUNCH("lu_reconstruct_kernel");
+        dbg_check(st, Tp, b, 1, b, b, "T", p, 9);
+        dbg_check(st, w.Uinv, b, 1, b, b, "Uinv", p, 9);
+        if (mp > b)
+            if ((rc = rows_times_small(st, sub(Yp, b, 0).p, yrs, ycs, mp - b, b, w.Uinv))) return rc;
+        // --- trailing update  A[j0:, j0:] -= Y (T^T (Y^T A[j0:, j0:]))
+        Mat Xm = mat(w.X, ntr, 1), X2m = mat(w.X2, ntr, 1), Tm = mat(Tp, b, 1);
+        if ((rc = gemm(st, b, ntr, mp, 1.0, tr(Yp), Ap, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+        if ((rc = gemm(st, b, ntr, b, 1.0, tr(Tm), Xm, 0.0, X2m))) return rc;
+        if ((rc = gemm(st, mp, ntr, b, -1.0, Yp, X2m, 1.0, Ap))) return rc;
+    }
+    // --- triangularise the diagonal blocks, assemble R
+    if (nb == 32) hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri);
+    else hipLaunchKernelGGL((diag_qr_kernel<64>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri);
+    TN_CHECK_LAUNCH("diag_qr_kernel");
+    dbg_check(st, w.Z, nb, 1, (int64_t)P * nb, nb, "Z", -1, 0);
+    dbg_check(st, w.Tri, nb, 1, (int64_t)P * nb, nb, "Tri", -1, 0);
+    hipLaunchKernelGGL(assemble_R_kernel, dim3((unsigned)cdiv(k * n, 256)), dim3(256), 0, st, A, rs, cs, nb, k, n, w.Z,
+                       w.Tri, R, rrs, rcs);
+    TN_CHECK_LAUNCH("assemble_R_kernel");
+    // --- Q = H_1 ... H_P [Z; 0]
+    const int qcolfast = (qcs == 1) ? 1 : 0;
+    hipLaunchKernelGGL(init_Q_kernel, dim3((unsigned)cdiv(m * k, 256)), dim3(256), 0, st, Q, qrs, qcs, m, k, nb, w.Z,
+                       qcolfast);
+    TN_CHECK_LAUNCH("init_Q_kernel");
+    Mat Qm = mat(Q, qrs, qcs);
+    for (int p = P - 1; p >= 0; --p) {
+        const int64_t j0 = (int64_t)p * nb;
+        const int b = (int)((k - j0 < nb) ? k - j0 : nb);
+        const int64_t mp = m - j0, nq = k - j0;
+        Mat Qp = sub(Qm, j0, j0), Yp = sub(Ym, j0, j0);
+        Mat Xm = mat(w.X, nq, 1), X2m = mat(w.X2, nq, 1), Tm = mat(w.T + (int64_t)p * nb * nb, b, 1);
+        if ((rc = gemm(st, b, nq, mp, 1.0, tr(Yp), Qp, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+        if ((rc = gemm(st, b, nq, b, 1.0, Tm, Xm, 0.0, X2m))) return rc;
+        if ((rc = gemm(st, mp, nq, b, -1.0, Yp, X2m, 1.0, Qp))) return rc;
+    }
+    return 0;
+}
+
+}  // namespace tn

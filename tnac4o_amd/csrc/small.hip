@@ -1,0 +1,365 @@
+// Small dense building blocks shared by the QR (K3) and Jacobi SVD (K4/K5) drivers:
+//   gram_partial        partial Gram matrices of <= 64 long vectors (split over the long dimension)
+//   eig_small           sum partials + parallel-order two-sided Jacobi on the <= 64 x 64 Gram matrix (one workgroup)
+//   rows_times_small    X[r, :b] <- X[r, :b] . S      (tall panel times small matrix, in place)
+//   small_t_times_vecs  vecs <- S^T . vecs            (small matrix times a bundle of long vectors, in place)
+// All are HBM/LDS-streaming VALU kernels; the flops that matter live in gemm_f64.hip.
+#include "common.h"
+
+namespace tn {
+
+// ------------------------------------------------------------------------------------------ addressing
+__device__ __forceinline__ int64_t vec_offset(int v, int w, int blk0, int blk1, int64_t vs) {
+    return v < w ? ((int64_t)blk0 * w + v) * vs : ((int64_t)blk1 * w + (v - w)) * vs;
+}
+
+// ------------------------------------------------------------------------------------------ gram_partial
+template <int NV>
+__global__ __launch_bounds__(256) void gram_partial_kernel(const double* __restrict__ X, int64_t vs, int64_t es,
+                                                           int64_t L, int nvec, int w, const int* __restrict__ pairs,
+                                                           int nchunk, double* __restrict__ part) {
+    constexpr int KC = 64, NVP = NV + 1;
+    constexpr int TPR = 256 / NV;        // threads per Gram row
+    constexpr int JW = NV / TPR;         // Gram columns per thread
+    __shared__ double Xs[KC * NVP];
+    const int tid = threadIdx.x, chunk = blockIdx.x, grp = blockIdx.y;
+    const int blk0 = pairs ? pairs[2 * grp] : 0, blk1 = pairs ? pairs[2 * grp + 1] : 1;
+    const int64_t lc = ((L + nchunk - 1) / nchunk + KC - 1) / KC * KC;
+    const int64_t c_lo = (int64_t)chunk * lc, c_hi = (c_lo + lc < L) ? c_lo + lc : L;
+    const int i = tid / TPR, j0 = (tid % TPR) * JW;
+    double acc[JW];
+#pragma unroll
+    for (int j = 0; j < JW; ++j) acc[j] = 0.0;
+    const bool efast = (es == 1);
+    for (int64_t c0 = c_lo; c0 < c_hi; c0 += KC) {
+        for (int idx = tid; idx < NV * KC; idx += 256) {
+            const int v = efast ? idx / KC : idx % NV;
+            const int c = efast ? idx % KC : idx / NV;
+            double x = 0.0;
+            if (v < nvec && c0 + c < c_hi) x = X[vec_offset(v, w, blk0, blk1, vs) + (c0 + c) * es];
+            Xs[c * NVP + v] = x;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int c = 0; c < KC; ++c) {
+            const double xi = Xs[c * NVP + i];
+#pragma unroll
+            for (int j = 0; j < JW; ++j) acc[j] += xi * Xs[c * NVP + j0 + j];
+        }
+        __syncthreads();
+    }
+    double* out = part + ((int64_t)grp * nchunk + chunk) * nvec * nvec;
+    if (i < nvec)
+#pragma unroll
+        for (int j = 0; j < JW; ++j)
+            if (j0 + j < nvec) out[i * nvec + j0 + j] = acc[j];
+}
+
+int gram_nchunk(int64_t L) {
+    int64_t n = L / 256;
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return (int)n;
+}
+
+int gram_partial(hipStream_t st, const double* X, int64_t vs, int64_t es, int64_t L, int nvec, int w, const int* pairs,
+                 int ngroups, int nchunk, double* part) {
+    TN_CHECK_ARG(nvec >= 1 && nvec <= NBMAX, "nvec out of range");
+    if (ngroups <= 0) return 0;
+    dim3 grid(nchunk, ngroups);
+    prof_begin(st, PROF_GRAM);
+    if (nvec <= 32)
+        hipLaunchKernelGGL((gram_partial_kernel<32>), grid, dim3(256), 0, st, X, vs, es, L, nvec, w, pairs, nchunk, part);
+    else
+        hipLaunchKernelGGL((gram_partial_kernel<64>), grid, dim3(256), 0, st, X, vs, es, L, nvec, w, pairs, nchunk, part);
+    TN_CHECK_LAUNCH("gram_partial_kernel");
+    prof_end(st, PROF_GRAM, 2.0 * nvec * nvec * (double)L * ngroups, 8.0 * ngroups * ((double)nvec * L + (double)nchunk * nvec * nvec));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ eig_small
+// Round-robin ("circle") pairing of n (even) indices: step s in [0, n-1), slot a in [0, n/2).
+__device__ __forceinline__ void rr_pair(int n, int s, int a, int& p, int& q) {
+    if (a == 0) {
+        p = n - 1;
+        q = s;
+    } else {
+        p = (s + a) % (n - 1);
+        q = (s - a + (n - 1)) % (n - 1);
+    }
+    if (p > q) {
+        const int t = p;
+        p = q;
+        q = t;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict__ part, int nchunk, int nvec, int mode,
+                                                        int max_sweeps, double dead_thresh,
+                                                        double* __restrict__ out, int* __restrict__ dead,
+                                                        int* __restrict__ nrot_out, double* __restrict__ maxoff_out) {
+    constexpr int P = NB + 1;
+    __shared__ double G[NB * P];
+    __shared__ double J[NB * P];
+    __shared__ double dsc[NB];
+    __shared__ double rc[NB / 2], rsn[NB / 2];
+    __shared__ int rp[NB / 2], rq[NB / 2];
+    __shared__ int cnt, total;
+    __shared__ double red[256];
+    const int tid = threadIdx.x, grp = blockIdx.x;
+    const int n = (nvec + 1) & ~1;          // even working size (a padding index never rotates)
+    const double* pg = part + (int64_t)grp * nchunk * nvec * nvec;
+
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        double s = 0.0;
+        if (i < nvec && j < nvec)
+            for (int c = 0; c < nchunk; ++c) s += pg[(int64_t)c * nvec * nvec + i * nvec + j];
+        else if (i == j)
+            s = 1.0;
+        G[i * P + j] = s;
+        J[i * P + j] = (i == j) ? 1.0 : 0.0;
+    }
+    if (tid == 0) total = 0;
+    __syncthreads();
+    if (mode != 2) {
+        if (tid < NB) {
+            const double gii = G[tid * P + tid];
+            const bool ok = (gii > dead_thresh) && (gii < 1.7e308);
+            dsc[tid] = ok ? sqrt(gii) : 1.0;
+            if (tid < nvec && dead) dead[grp * nvec + tid] = ok ? 0 : 1;
+            if (!ok) dsc[tid] = 0.0;        // marks a dead column
+        }
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            const double di = dsc[i], dj = dsc[j];
+            double g;
+            if (di == 0.0 || dj == 0.0) g = (i == j) ? 1.0 : 0.0;
+            else g = (i == j) ? 1.0 : G[i * P + j] / (di * dj);
+            G[i * P + j] = g;
+        }
+        __syncthreads();
+    }
+    // largest relative off-diagonal before rotating (diagnostic / convergence measure)
+    {
+        double m = 0.0;
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            if (i < j && j < nvec) {
+                const double dd = fabs(G[i * P + i] * G[j * P + j]);
+                if (dd > 0.0) {
+                    const double r = fabs(G[i * P + j]) / sqrt(dd);
+                    m = r > m ? r : m;
+                }
+            }
+        }
+        red[tid] = m;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] = red[tid] > red[tid + s] ? red[tid] : red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0 && maxoff_out) maxoff_out[grp] = red[0];
+    }
+
+    if (mode != 1 && n >= 2) {
+        const double tol = 8.881784197001252e-16;      // 2^-50
+        for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+            if (tid == 0) cnt = 0;
+            __syncthreads();
+            for (int s = 0; s < n - 1; ++s) {
+                if (tid < n / 2) {
+                    int p, q;
+                    rr_pair(n, s, tid, p, q);
+                    const double gpq = G[p * P + q], gpp = G[p * P + p], gqq = G[q * P + q];
+                    double c = 1.0, sn = 0.0;
+                    if (gpq != 0.0 && fabs(gpq) > tol * sqrt(fabs(gpp * gqq))) {
+                        const double tau = (gqq - gpp) / (2.0 * gpq);
+                        double t;
+                        if (fabs(tau) > 1e150) t = 0.5 / tau;
+                        else t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        sn = t * c;
+                        atomicAdd(&cnt, 1);
+                    }
+                    rc[tid] = c; rsn[tid] = sn; rp[tid] = p; rq[tid] = q;
+                }
+                __syncthreads();
+                for (int e = tid; e < (n / 2) * n; e += 256) {          // rows: G <- R^T G
+                    const int a = e / n, j = e % n;
+                    const double c = rc[a], sn = rsn[a];
+                    if (sn != 0.0) {
+                        const int p = rp[a], q = rq[a];
+                        const double gp = G[p * P + j], gq = G[q * P + j];
+                        G[p * P + j] = c * gp - sn * gq;
+                        G[q * P + j] = sn * gp + c * gq;
+                    }
+                }
+                __syncthreads();
+                for (int e = tid; e < (n / 2) * n; e += 256) {          // columns: G <- G R, J <- J R
+                    const int a = e / n, i = e % n;
+                    const double c = rc[a], sn = rsn[a];
+                    if (sn != 0.0) {
+                        const int p = rp[a], q = rq[a];
+                        const double gp = G[i * P + p], gq = G[i * P + q];
+                        G[i * P + p] = c * gp - sn * gq;
+                        G[i * P + q] = sn * gp + c * gq;
+                        const double jp = J[i * P + p], jq = J[i * P + q];
+                        J[i * P + p] = c * jp - sn * jq;
+                        J[i * P + q] = sn * jp + c * jq;
+                    }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) total += cnt;
+            const int done = (cnt == 0);
+            __syncthreads();
+            if (done) break;
+        }
+    }
+    if (tid == 0 && nrot_out) nrot_out[grp] = total;
+    if (mode != 1 && total > 0) {
+        // One Newton-Schulz step J <- J (3I - J^T J)/2: the accumulated product of ~n*sweeps plane rotations drifts
+        // from orthogonality by ~sqrt(n*sweeps) eps; this squares the defect, so repeated application of J over many
+        // Jacobi rounds does not inflate vector norms (singular values) beyond rounding.
+        __shared__ double eigdiag[NB];
+        if (tid < NB) eigdiag[tid] = G[tid * P + tid];          // rotated diagonal = eigenvalues (needed below)
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += 256) {              // G <- J^T J
+            const int k = e / NB, j = e % NB;
+            double s = 0.0;
+            for (int i = 0; i < NB; ++i) s += J[i * P + k] * J[i * P + j];
+            G[k * P + j] = s;
+        }
+        __syncthreads();
+        constexpr int EPT = NB * NB / 256;
+        double nv[EPT];
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int e = tid + 256 * r, i = e / NB, j = e % NB;
+            double s = 0.0;
+            for (int k = 0; k < NB; ++k) s += J[i * P + k] * G[k * P + j];
+            nv[r] = 1.5 * J[i * P + j] - 0.5 * s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int e = tid + 256 * r;
+            J[(e / NB) * P + e % NB] = nv[r];
+        }
+        if (tid < NB) G[tid * P + tid] = eigdiag[tid];
+        __syncthreads();
+    }
+    double* o = out + (int64_t)grp * nvec * nvec;
+    for (int e = tid; e < nvec * nvec; e += 256) {
+        const int i = e / nvec, j = e % nvec;
+        double v = J[i * P + j];
+        if (mode != 2) {
+            const double di = dsc[i];
+            v = (di == 0.0) ? 0.0 : v / di;
+            if (dsc[j] == 0.0) v = 0.0;
+        }
+        o[e] = v;
+    }
+}
+
+int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngroups, int mode, int max_sweeps,
+              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff) {
+    TN_CHECK_ARG(nvec >= 1 && nvec <= NBMAX, "nvec out of range");
+    if (ngroups <= 0) return 0;
+    prof_begin(st, PROF_EIG);
+    if (nvec <= 32)
+        hipLaunchKernelGGL((eig_small_kernel<32>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,
+                           dead_thresh, out, dead, nrot, maxoff);
+    else
+        hipLaunchKernelGGL((eig_small_kernel<64>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,
+                           dead_thresh, out, dead, nrot, maxoff);
+    TN_CHECK_LAUNCH("eig_small_kernel");
+    prof_end(st, PROF_EIG, 0.0, 8.0 * ngroups * ((double)nchunk + 1.0) * nvec * nvec);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ rows_times_small
+template <int NB>
+__global__ __launch_bounds__(256) void rows_times_small_kernel(double* __restrict__ X, int64_t rs, int64_t cs,
+                                                               int64_t nrows, int b, const double* __restrict__ S) {
+    __shared__ double Ss[NB * NB];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        Ss[e] = (i < b && j < b) ? S[i * b + j] : 0.0;
+    }
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+    if (r >= nrows) return;
+    double* row = X + r * rs;
+    double x[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) x[i] = (i < b) ? row[i * cs] : 0.0;
+    for (int j = 0; j < b; ++j) {
+        double y = 0.0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) y += x[i] * Ss[i * NB + j];
+        row[j * cs] = y;
+    }
+}
+
+int rows_times_small(hipStream_t st, double* X, int64_t rs, int64_t cs, int64_t nrows, int b, const double* S) {
+    TN_CHECK_ARG(b >= 1 && b <= NBMAX, "b out of range");
+    if (nrows <= 0) return 0;
+    dim3 grid((unsigned)cdiv(nrows, 256));
+    prof_begin(st, PROF_ROWS_SMALL);
+    if (b <= 32) hipLaunchKernelGGL((rows_times_small_kernel<32>), grid, dim3(256), 0, st, X, rs, cs, nrows, b, S);
+    else hipLaunchKernelGGL((rows_times_small_kernel<64>), grid, dim3(256), 0, st, X, rs, cs, nrows, b, S);
+    TN_CHECK_LAUNCH("rows_times_small_kernel");
+    prof_end(st, PROF_ROWS_SMALL, 2.0 * nrows * b * b, 16.0 * nrows * b);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ small_t_times_vecs
+template <int NV>
+__global__ __launch_bounds__(256) void small_t_times_vecs_kernel(const double* __restrict__ S, double* __restrict__ X,
+                                                                 int64_t vs, int64_t es, int64_t L, int nvec, int w,
+                                                                 const int* __restrict__ pairs,
+                                                                 const int* __restrict__ nrot) {
+    __shared__ double Ss[NV * NV];
+    const int tid = threadIdx.x, grp = blockIdx.y;
+    if (nrot && nrot[grp] == 0) return;
+    const double* s = S + (int64_t)grp * nvec * nvec;
+    for (int e = tid; e < NV * NV; e += 256) {
+        const int u = e / NV, v = e % NV;
+        Ss[e] = (u < nvec && v < nvec) ? s[u * nvec + v] : 0.0;
+    }
+    __syncthreads();
+    const int blk0 = pairs ? pairs[2 * grp] : 0, blk1 = pairs ? pairs[2 * grp + 1] : 1;
+    const int64_t c = (int64_t)blockIdx.x * 256 + tid;
+    if (c >= L) return;
+    double x[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) x[u] = (u < nvec) ? X[vec_offset(u, w, blk0, blk1, vs) + c * es] : 0.0;
+    for (int v = 0; v < nvec; ++v) {
+        double y = 0.0;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) y += Ss[u * NV + v] * x[u];
+        X[vec_offset(v, w, blk0, blk1, vs) + c * es] = y;
+    }
+}
+
+int small_t_times_vecs(hipStream_t st, const double* S, double* X, int64_t vs, int64_t es, int64_t L, int nvec, int w,
+                       const int* pairs, int ngroups, const int* nrot) {
+    TN_CHECK_ARG(nvec >= 1 && nvec <= NBMAX, "nvec out of range");
+    if (ngroups <= 0 || L <= 0) return 0;
+    dim3 grid((unsigned)cdiv(L, 256), ngroups);
+    prof_begin(st, PROF_VECS_SMALL);
+    if (nvec <= 32)
+        hipLaunchKernelGGL((small_t_times_vecs_kernel<32>), grid, dim3(256), 0, st, S, X, vs, es, L, nvec, w, pairs, nrot);
+    else
+        hipLaunchKernelGGL((small_t_times_vecs_kernel<64>), grid, dim3(256), 0, st, S, X, vs, es, L, nvec, w, pairs, nrot);
+    TN_CHECK_LAUNCH("small_t_times_vecs_kernel");
+    prof_end(st, PROF_VECS_SMALL, 2.0 * nvec * nvec * (double)L * ngroups, 16.0 * nvec * (double)L * ngroups);
+    return 0;
+}
+
+}  // namespace tn

@@ -1,0 +1,276 @@
+// K4 / K5 — one-sided block-Jacobi SVD with the reference's truncation rule (mps.py:802-811), sign gauge
+// (mps.py:35-39) and a values-only variant (mps.py:62-73).
+//
+// The shorter side of C supplies the vectors (nv <= L).  Vectors whose norm is below 2^-56 of the largest are
+// deflated up front (they cannot move any singular value by more than sqrt(nv) 2^-56 S0, far below the eps S0
+// truncation threshold); the centre matrices of this path are numerically low-rank, so this typically shrinks a
+// 1024-vector problem to 100-300.  The live vectors X (nvp x L, blocks of w = 32) are orthogonalised by rounds of a
+// round-robin tournament over block pairs; each round is three launches over all pairs at once:
+//   gram_partial (64 x 64 Gram of a pair, split over L)  ->  eig_small (parallel-order Jacobi, orthogonal J)
+//   ->  small_t_times_vecs  (X_pair <- J^T X_pair, and the same on the accumulator P).
+// Rotations are exactly orthogonal to rounding; the Gram matrix only steers them, so small singular values keep the
+// one-sided Jacobi accuracy.  Host syncs: one for deflation, one per sweep (convergence), one for the kept rank.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace tn {
+
+constexpr int SVD_W = 32;
+
+__global__ __launch_bounds__(256) void vec_norm2_kernel(const double* __restrict__ X, int64_t vs, int64_t es, int64_t L,
+                                                        double* __restrict__ out) {
+    __shared__ double red[256];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const double* x = X + (int64_t)v * vs;
+    double s = 0.0;
+    for (int64_t c = tid; c < L; c += 256) { const double t = x[c * es]; s += t * t; }
+    red[tid] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) red[tid] += red[tid + k];
+        __syncthreads();
+    }
+    if (tid == 0) out[v] = red[0];
+}
+
+// X[i] <- M[live[i]] (zero rows beyond nvl); P[i] <- one-hot(live[i]) when P != nullptr
+__global__ __launch_bounds__(256) void svd_init_kernel(const double* __restrict__ M, int64_t vs, int64_t es, int64_t L,
+                                                       int64_t nv, const int* __restrict__ live, int nvl,
+                                                       double* __restrict__ X, double* __restrict__ P) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const bool on = i < nvl;
+    const int src = on ? live[i] : 0;
+    for (int64_t c = tid; c < L; c += 256) X[(int64_t)i * L + c] = on ? M[(int64_t)src * vs + c * es] : 0.0;
+    if (P)
+        for (int64_t c = tid; c < nv; c += 256) P[(int64_t)i * nv + c] = (on && c == src) ? 1.0 : 0.0;
+}
+
+// One block per kept vector j (source row order[j]):  left[:, j] = sgn * P[row, :],  right[j, :] = sgn * X[row, :] / S_j
+// with the reference's sign gauge: flip when in both vectors the most negative entry outweighs the most positive.
+__global__ __launch_bounds__(256) void svd_gather_kernel(const double* __restrict__ X, int64_t L, const double* __restrict__ P,
+                                                         int64_t nv, const int* __restrict__ order,
+                                                         const double* __restrict__ Ssorted, double* __restrict__ left,
+                                                         int64_t lrs, int64_t lcs, double* __restrict__ right, int64_t rrs,
+                                                         int64_t rcs) {
+    __shared__ double rmin[256], rmax[256];
+    __shared__ double sgn;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int row = order[j];
+    const double* x = X + (int64_t)row * L;
+    const double* p = P + (int64_t)row * nv;
+    double xmin = 0.0, xmax = 0.0, pmin = 0.0, pmax = 0.0;
+    bool first = true;
+    for (int64_t c = tid; c < L; c += 256) { const double t = x[c]; xmin = first ? t : fmin(xmin, t); xmax = first ? t : fmax(xmax, t); first = false; }
+    if (first) { xmin = 1e308; xmax = -1e308; }
+    rmin[tid] = xmin; rmax[tid] = xmax;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) { rmin[tid] = fmin(rmin[tid], rmin[tid + k]); rmax[tid] = fmax(rmax[tid], rmax[tid + k]); }
+        __syncthreads();
+    }
+    xmin = rmin[0]; xmax = rmax[0];
+    __syncthreads();
+    first = true;
+    for (int64_t c = tid; c < nv; c += 256) { const double t = p[c]; pmin = first ? t : fmin(pmin, t); pmax = first ? t : fmax(pmax, t); first = false; }
+    if (first) { pmin = 1e308; pmax = -1e308; }
+    rmin[tid] = pmin; rmax[tid] = pmax;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) { rmin[tid] = fmin(rmin[tid], rmin[tid + k]); rmax[tid] = fmax(rmax[tid], rmax[tid + k]); }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        pmin = rmin[0]; pmax = rmax[0];
+        // the sign of x/S equals the sign of x (S > 0), so the rule can be evaluated on x directly
+        sgn = (fabs(pmin) > pmax && fabs(xmin) > xmax) ? -1.0 : 1.0;
+    }
+    __syncthreads();
+    const double s = sgn, sv = Ssorted[j];
+    const double inv = sv > 0.0 ? s / sv : 0.0;
+    for (int64_t c = tid; c < L; c += 256) right[(int64_t)j * rrs + c * rcs] = x[c] * inv;
+    for (int64_t c = tid; c < nv; c += 256) left[c * lrs + (int64_t)j * lcs] = p[c] * s;
+}
+
+static void round_robin(int nblk, std::vector<int>& pairs) {     // (nblk-1) rounds x (nblk/2) pairs x 2
+    std::vector<int> idx(nblk);
+    for (int i = 0; i < nblk; ++i) idx[i] = i;
+    pairs.clear();
+    for (int r = 0; r < nblk - 1; ++r) {
+        for (int i = 0; i < nblk / 2; ++i) {
+            int a = idx[i], b = idx[nblk - 1 - i];
+            pairs.push_back(a < b ? a : b);
+            pairs.push_back(a < b ? b : a);
+        }
+        const int last = idx[nblk - 1];
+        for (int i = nblk - 1; i > 1; --i) idx[i] = idx[i - 1];
+        idx[1] = last;
+    }
+}
+
+struct SvdWs {
+    double *X, *P, *part, *Js, *maxoff, *norms, *Ssorted;
+    int *live, *pairs, *nrot, *order;
+};
+
+static int64_t svd_layout(int64_t nv, int64_t L, bool vectors, char* base, SvdWs* w) {
+    const int64_t nvp = align_up(nv, 2 * SVD_W), nblk = nvp / SVD_W, ng = nblk / 2, nr = nblk - 1;
+    const int nchunk = gram_nchunk(L);
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { int64_t o = off; off += align_up(bytes, 256); return base ? base + o : nullptr; };
+    double* X = (double*)take(nvp * L * 8);
+    double* P = (double*)take(vectors ? nvp * nv * 8 : 8);
+    double* part = (double*)take(ng * nchunk * 4 * SVD_W * SVD_W * 8);
+    double* Js = (double*)take(ng * 4 * SVD_W * SVD_W * 8);
+    double* maxoff = (double*)take(nr * ng * 8);
+    double* norms = (double*)take(nvp * 8);
+    double* Ss = (double*)take(nvp * 8);
+    int* live = (int*)take(nvp * 4);
+    int* pairs = (int*)take(nr * ng * 2 * 4);
+    int* nrot = (int*)take(ng * 4);
+    int* order = (int*)take(nvp * 4);
+    if (w) { w->X = X; w->P = P; w->part = part; w->Js = Js; w->maxoff = maxoff; w->norms = norms; w->Ssorted = Ss;
+             w->live = live; w->pairs = pairs; w->nrot = nrot; w->order = order; }
+    return off;
+}
+
+int64_t svd_ws_bytes(int64_t k, int64_t n, int vectors) {
+    const int64_t nv = k <= n ? k : n, L = k <= n ? n : k;
+    return svd_layout(nv, L, vectors != 0, nullptr, nullptr);
+}
+
+// Core: orthogonalise the rows of M (nv x L, strides vs/es).  On return hostS holds the singular values sorted
+// descending (length nvl), *nvl_out the number of live vectors, order[] (device) the matching row permutation.
+static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, int64_t nv, int64_t L, bool vectors,
+                       SvdWs& w, std::vector<double>& hostS, std::vector<int>& hostOrder, int* sweeps_out, int* info) {
+    hipError_t e;
+    int rc;
+    hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nv), dim3(256), 0, st, M, vs, es, L, w.norms);
+    TN_CHECK_LAUNCH("vec_norm2_kernel");
+    std::vector<double> hn(nv);
+    if ((e = hipMemcpyAsync(hn.data(), w.norms, nv * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy norms");
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync norms");
+    double nmax = 0.0;
+    for (int64_t i = 0; i < nv; ++i) {
+        if (!(hn[i] == hn[i]) || hn[i] > 1.7e308) { set_error("svd: non-finite input"); return -2; }
+        nmax = std::max(nmax, hn[i]);
+    }
+    std::vector<int> live;
+    const double thr = nmax * (1.9259299443872359e-34);      // (2^-56)^2 on squared norms
+    for (int64_t i = 0; i < nv; ++i)
+        if (hn[i] > thr) live.push_back((int)i);
+    if (live.empty()) live.push_back(0);                      // all-zero input: one (zero) vector
+    const int nvl = (int)live.size();
+    const int64_t nvp = align_up(nvl, 2 * SVD_W);
+    const int nblk = (int)(nvp / SVD_W), ng = nblk / 2, nr = nblk - 1;
+    if ((e = hipMemcpyAsync(w.live, live.data(), nvl * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy live");
+    hipLaunchKernelGGL(svd_init_kernel, dim3((unsigned)nvp), dim3(256), 0, st, M, vs, es, L, nv, w.live, nvl, w.X,
+                       vectors ? w.P : nullptr);
+    TN_CHECK_LAUNCH("svd_init_kernel");
+    std::vector<int> pairs;
+    round_robin(nblk, pairs);
+    if ((e = hipMemcpyAsync(w.pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy pairs");
+    // the host vectors above must outlive the async copies
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync init");
+
+    const int nchunk = gram_nchunk(L);
+    const int nvec = 2 * SVD_W;
+    std::vector<double> hoff((size_t)nr * ng);
+    int sweeps = 0;
+    bool converged = false;
+    for (int outer = 0; outer < 40 && !converged; ++outer) {
+        for (int r = 0; r < nr; ++r) {
+            const int* pr = w.pairs + (int64_t)r * ng * 2;
+            if ((rc = gram_partial(st, w.X, L, 1, L, nvec, SVD_W, pr, ng, nchunk, w.part))) return rc;
+            if ((rc = eig_small(st, w.part, nchunk, nvec, ng, 2, 4, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng))) return rc;
+            if ((rc = small_t_times_vecs(st, w.Js, w.X, L, 1, L, nvec, SVD_W, pr, ng, w.nrot))) return rc;
+            if (vectors)
+                if ((rc = small_t_times_vecs(st, w.Js, w.P, nv, 1, nv, nvec, SVD_W, pr, ng, w.nrot))) return rc;
+        }
+        ++sweeps;
+        if ((e = hipMemcpyAsync(hoff.data(), w.maxoff, hoff.size() * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy maxoff");
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync sweep");
+        double worst = 0.0;
+        for (double v : hoff) worst = std::max(worst, v);
+        converged = worst < 4.0e-15;
+    }
+    if (sweeps_out) *sweeps_out = sweeps;
+    if (info) *info = converged ? 0 : 1;
+    hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nvp), dim3(256), 0, st, w.X, L, 1, L, w.norms);
+    TN_CHECK_LAUNCH("vec_norm2_kernel");
+    std::vector<double> hs(nvp);
+    if ((e = hipMemcpyAsync(hs.data(), w.norms, nvp * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy S");
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync S");
+    hostOrder.resize(nvp);
+    for (int i = 0; i < nvp; ++i) hostOrder[i] = i;
+    std::stable_sort(hostOrder.begin(), hostOrder.end(), [&](int a, int b) { return hs[a] > hs[b]; });
+    hostS.resize(nvl);
+    hostOrder.resize(nvl);     // padding rows are exactly zero and sort last
+    for (int i = 0; i < nvl; ++i) hostS[i] = std::sqrt(hs[hostOrder[i]]);
+    return 0;
+}
+
+// C is k x n (element strides crs, ccs).  U: k x keep (urs, ucs), Vt: keep x n (vrs, vcs), S: keep values.
+// keep_out / discarded_out / hostS_out are host pointers.
+int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol,
+              double* U, int64_t urs, int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_out,
+              double* discarded_out, int* sweeps_out, int* info, void* ws, int64_t ws_bytes) {
+    TN_CHECK_ARG(k >= 1 && n >= 1 && Dmax >= 1, "bad dimensions");
+    TN_CHECK_ARG(ws_bytes >= svd_ws_bytes(k, n, 1), "workspace too small");
+    const bool rows = k <= n;
+    const int64_t nv = rows ? k : n, L = rows ? n : k;
+    const int64_t vs = rows ? crs : ccs, es = rows ? ccs : crs;
+    SvdWs w;
+    svd_layout(nv, L, true, (char*)ws, &w);
+    std::vector<double> hS;
+    std::vector<int> hO;
+    int rc = jacobi_core(st, C, vs, es, nv, L, true, w, hS, hO, sweeps_out, info);
+    if (rc) return rc;
+    const int nvl = (int)hS.size();
+    const double eps = 2.220446049250313e-16;
+    const double t = tol > eps ? tol : eps;
+    int64_t keep = 0;
+    for (int i = 0; i < nvl; ++i) keep += (hS[i] > hS[0] * t) ? 1 : 0;
+    if (keep > Dmax) keep = Dmax;
+    double d2 = 0.0;
+    for (int i = nvl - 1; i >= keep; --i) d2 += hS[i] * hS[i];
+    if (keep_out) *keep_out = keep;
+    if (discarded_out) *discarded_out = std::sqrt(d2) / hS[0];
+    if (keep == 0) return 0;
+    hipError_t e;
+    if ((e = hipMemcpyAsync(w.order, hO.data(), keep * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy order");
+    if ((e = hipMemcpyAsync(w.Ssorted, hS.data(), keep * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy S");
+    if ((e = hipMemcpyAsync(S, w.Ssorted, keep * 8, hipMemcpyDeviceToDevice, st)) != hipSuccess) return hip_fail(e, "copy S");
+    // rows: left = U (k x keep), right = Vt.  columns (C^T was factored): left = Vt^T, right = U^T.
+    if (rows)
+        hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, w.order, w.Ssorted, U,
+                           urs, ucs, Vt, vrs, vcs);
+    else
+        hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, w.order, w.Ssorted, Vt,
+                           vcs, vrs, U, ucs, urs);
+    TN_CHECK_LAUNCH("svd_gather_kernel");
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync gather");   // hS/hO go out of scope
+    return 0;
+}
+
+// Singular values only, sorted descending, min(k,n) of them (deflated ones reported as 0).  hostS: host pointer.
+int svd_vals(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* hostS,
+             int* sweeps_out, int* info, void* ws, int64_t ws_bytes) {
+    TN_CHECK_ARG(k >= 1 && n >= 1, "bad dimensions");
+    TN_CHECK_ARG(ws_bytes >= svd_ws_bytes(k, n, 0), "workspace too small");
+    const bool rows = k <= n;
+    const int64_t nv = rows ? k : n, L = rows ? n : k;
+    const int64_t vs = rows ? crs : ccs, es = rows ? ccs : crs;
+    SvdWs w;
+    svd_layout(nv, L, false, (char*)ws, &w);
+    std::vector<double> hS;
+    std::vector<int> hO;
+    int rc = jacobi_core(st, C, vs, es, nv, L, false, w, hS, hO, sweeps_out, info);
+    if (rc) return rc;
+    for (int64_t i = 0; i < nv; ++i) hostS[i] = i < (int64_t)hS.size() ? hS[i] : 0.0;
+    return 0;
+}
+
+}  // namespace tn

@@ -1,0 +1,366 @@
+"""Boundary-MPS algebra on MI355X — the call surface of the reference's ``tnac4o/mps.py`` that its solver
+consumes, with every tensor resident in HBM and every contraction / factorisation running in
+libtnpeps (hand-written HIP; include/tnpeps.h).  Method names, argument meaning and return values mirror the
+reference (file:line cited per method) so the solver code reads the same; PyTorch only owns the memory.
+
+Site tensors are contiguous float64 ``(Dl, p, Dr)`` CUDA tensors.  Host syncs happen only where the algorithm
+needs a number on the host: the kept rank in ``truncateC``, the Schmidt values in ``update_S`` and the overlap.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+EPS = float(np.finfo(np.float64).eps)
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise RuntimeError('tnac4o_amd needs a ROCm GPU: the HIP library is the only backend (no CPU fallback)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _t(x):
+    """Accept numpy arrays for convenience; everything is float64 on the current GPU."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device=_dev(), dtype=torch.float64)
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float64).to(_dev())
+
+
+# ------------------------------------------------------------------------------------------ module functions
+def nfactor(T):
+    """Largest |entry| floored to a power of two, as a Python float (reference mps.py:76-85).  Syncs."""
+    return float(ops.nfactor_dev(_t(T).contiguous())[0].item())
+
+
+def qr(T):
+    """Economic QR with diag(R) >= 0 (mps.py:43-59)."""
+    return ops.qr(_t(T))
+
+
+def svd(T):
+    """Thin SVD with the reference's sign gauge (mps.py:24-40).  Returns U, S, V (V rows are right vectors).
+    Vectors are returned for singular values above 2^-56 S0 (smaller ones are deflated by the Jacobi kernel)."""
+    T = _t(T)
+    U, S, V, _, _, _ = ops.svd_trunc(T, min(T.shape), 0.0)
+    return U, S, V
+
+
+def svd_S(T):
+    """Singular values only (mps.py:62-73), numpy array on the host."""
+    return ops.svdvals(_t(T))
+
+
+def dot(phi, psi):
+    """<phi|psi> (mps.py:88-93)."""
+    RL = torch.ones((1, 1), dtype=torch.float64, device=_dev())
+    for n in range(psi.L):
+        RL = psi._mps_RL(RL, psi.A[n], phi.A[n])
+    return float(RL.reshape(-1)[0].item())
+
+
+class MPO:
+    """MPO container (mps.py:818-865): ``W[n]`` has legs (left bond, out, right bond, in)."""
+
+    def __init__(self, d=2, dout=None, L=2):
+        self.L = L
+        one = torch.ones((1, 1, 1, 1), dtype=torch.float64, device=_dev())
+        self.W = [one] * L
+        self.support = [0] * L
+
+    def set_direct(self, W, n):
+        """mps.py:859-865."""
+        self.W[n] = _t(W).contiguous()
+        self.support[n] = 1
+
+
+class MPS:
+    """Boundary MPS with an explicit orthogonality centre C at bond pC (mps.py:96-173).
+
+    Only the maximally mixed start state ``initial='X'`` is provided — the one the solver uses (tnac4o.py:1682).
+    """
+
+    def __init__(self, d=2, L=2, Dmax=2, initial='X', canonise='left'):
+        if initial != 'X':
+            raise NotImplementedError("only initial='X' is on the contraction path")
+        d = [d] if isinstance(d, int) else list(d)
+        d = (d * ((L + len(d) - 1) // len(d)))[:L]
+        self.L, self.d = L, d
+        self.zero = EPS
+        self.dtype = 'float64'
+        dev = _dev()
+        self.D = self._Dset(Dmax, d)
+        self.A = []
+        for n in range(L):                                                   # mps.py:635-638
+            A = torch.zeros((self.D[n], d[n], self.D[n + 1]), dtype=torch.float64, device=dev)
+            A[0, :, 0] = 1.0 / np.sqrt(d[n])
+            self.A.append(A)
+        self.C = torch.ones((1, 1), dtype=torch.float64, device=dev)
+        self.pC = L
+        self._nfs = []                   # device pairs [nf, 1/nf]; normC is their product (kept lazily)
+        self.reset_R()
+        self.reset_S()
+        self.discarded = [0] * (L + 1)
+        if canonise == 'left':
+            self.canonise_left()
+        elif canonise == 'right':
+            self.canonise_right()
+        self._nfs = []
+
+    # -- bookkeeping --------------------------------------------------------------------------------------
+    @property
+    def normC(self):
+        """Accumulated power-of-two norm factor (mps.py:122, 537, 546).  Syncs; not used on the hot path."""
+        out = 1.0
+        for f in self._nfs:
+            out *= float(f[0].item())
+        return out
+
+    @staticmethod
+    def _Dset(Dmax, d):
+        """mps.py:644-653."""
+        L = len(d)
+        D = [1] * (L + 1)
+        for n in range(L):
+            D[n + 1] = min(D[n] * d[n], Dmax)
+        D[-1] = 1
+        for n in range(L - 1, -1, -1):
+            D[n] = min(D[n + 1] * d[n], Dmax, D[n])
+        return D
+
+    @staticmethod
+    def _one_S(D):
+        S = np.zeros(D)
+        S[0] = 1.0
+        return S
+
+    def reset_R(self):
+        """mps.py:281-286."""
+        one = torch.ones((1, 1), dtype=torch.float64, device=_dev())
+        self.R = [one.clone() for _ in range(self.L + 2)]
+        self.R[-1] = None
+
+    def reset_S(self):
+        """mps.py:295-299."""
+        self.S = [self._one_S(self.D[n]) for n in range(self.L + 1)]
+
+    def copy(self):
+        """Deep copy of the tensors (mps.py:159-173); S and ``discarded`` start fresh as in the reference."""
+        o = MPS(d=self.d, L=self.L, Dmax=1, initial='X', canonise=None)
+        o.A = [a.clone() for a in self.A]
+        o.C = self.C.clone()
+        o.pC = self.pC
+        o._nfs = list(self._nfs)
+        o.D = self.D[:]
+        o.R = self.R[:]
+        return o
+
+    # -- absorption ---------------------------------------------------------------------------------------
+    def apply_mpo(self, M, Hconj=False):
+        """psi <- H psi (or H^dag psi), site by site (mps.py:353-359 -> :753-763): K1 tn_absorb."""
+        for n in range(self.L):
+            if M.support[n]:
+                self.A[n] = ops.absorb(self.A[n], M.W[n], Hconj)
+                self.D[n], self.d[n], self.D[n + 1] = self.A[n].shape
+
+    def apply_diagonalO(self, diagO, n):
+        """mps.py:361-366."""
+        ops.scale_phys_(self.A[n], _t(diagO).contiguous())
+
+    # -- gauge moves --------------------------------------------------------------------------------------
+    def attach_AC(self):
+        """A[pC-1] <- A[pC-1] . C (mps.py:368-373)."""
+        n = self.pC - 1
+        Dl, p, Dr = self.A[n].shape
+        self.A[n] = ops.mm(self.A[n].view(Dl * p, Dr), self.C).view(Dl, p, self.C.shape[1])
+
+    def attach_CA(self):
+        """A[pC] <- C . A[pC] (mps.py:375-380)."""
+        n = self.pC
+        Dl, p, Dr = self.A[n].shape
+        self.A[n] = ops.mm(self.C, self.A[n].view(Dl, p * Dr)).view(self.C.shape[0], p, Dr)
+
+    def orth_left(self, n):
+        """A[n] -> Q, C = R / nfactor(R) with QR of the (Dl p, Dr) matrix (mps.py:532-539, 772-785)."""
+        Dl, p, Dr = self.A[n].shape
+        Q, R = ops.qr(self.A[n].view(Dl * p, Dr), overwrite=True)
+        k = R.shape[0]
+        self._nfs.append(ops.normalize_pow2_(R))
+        if R.shape == (1, 1):            # mps.py:778-780 (diag(R) >= 0, so sign(C) = 1): the norm is dropped
+            R = torch.ones_like(R)
+        self.A[n] = Q.view(Dl, p, k)
+        self.C = R
+        self.D[n + 1] = k
+        self.pC = n + 1
+
+    def orth_right(self, n):
+        """A[n] -> C Q with QR of the transposed (p Dr, Dl) view (mps.py:541-548, 787-800)."""
+        Dl, p, Dr = self.A[n].shape
+        k = min(p * Dr, Dl)
+        dev = self.A[n].device
+        Qt = torch.empty((k, p * Dr), dtype=torch.float64, device=dev)      # Q^T, i.e. the new right-canonical site
+        Ct = torch.empty((Dl, k), dtype=torch.float64, device=dev)          # R^T
+        ops.qr_into(self.A[n].view(Dl, p * Dr).t(), Qt.t(), Ct.t(), overwrite=True)
+        self._nfs.append(ops.normalize_pow2_(Ct))
+        if Ct.shape == (1, 1):
+            Ct = torch.ones_like(Ct)
+        self.A[n] = Qt.view(k, p, Dr)
+        self.C = Ct
+        self.D[n] = k
+        self.pC = n
+
+    def truncateC(self, Dmax, tol=None):
+        """SVD-truncate the centre matrix and push the projectors into the neighbours (mps.py:562-585, 802-811)."""
+        if 0 < self.pC < self.L:
+            if tol is None:
+                tol = self.zero
+            Dcap = int(min(Dmax, min(self.C.shape)))
+            U, S, Vt, keep, disc, _ = ops.svd_trunc(self.C, Dcap, tol)
+            nl, nr = self.pC - 1, self.pC
+            Dl, p, _ = self.A[nl].shape
+            self.A[nl] = ops.mm(self.A[nl].view(Dl * p, -1), U).view(Dl, p, keep)
+            _, p2, Dr = self.A[nr].shape
+            self.A[nr] = ops.mm(Vt, self.A[nr].view(-1, p2 * Dr)).view(keep, p2, Dr)
+            self.C = torch.diag(S)
+            self.D[self.pC] = keep
+            self.discarded[self.pC] = max(self.discarded[self.pC], disc)
+            return disc
+        return 0.0
+
+    def canonise_left(self, compress=False, Dmax=np.inf, tol=None):
+        """mps.py:202-218."""
+        self.C = torch.ones((1, 1), dtype=torch.float64, device=self.A[0].device)
+        self.pC = 0
+        for n in range(self.L):
+            self.attach_CA()
+            self.orth_left(n)
+            if compress:
+                self.truncateC(Dmax, tol)
+        self.R[-1] = None
+
+    def canonise_right(self, compress=False, Dmax=np.inf, tol=None):
+        """mps.py:220-236."""
+        self.C = torch.ones((1, 1), dtype=torch.float64, device=self.A[0].device)
+        self.pC = self.L
+        for n in range(self.L - 1, -1, -1):
+            self.attach_AC()
+            self.orth_right(n)
+            if compress:
+                self.truncateC(Dmax, tol)
+        self.R[-1] = None
+
+    # -- environments -------------------------------------------------------------------------------------
+    @staticmethod
+    def _mps_RL(RL, A, Ac):
+        """out[c',a'] = sum_{c,s,a} Ac[c,s,c'] RL[c,a] A[a,s,a'] (mps.py:655-658)."""
+        a, s, a2 = A.shape
+        c, _, c2 = Ac.shape
+        T = ops.mm(RL, A.view(a, s * a2))                       # (c, s a')
+        return ops.mm(Ac.view(c * s, c2).t(), T.view(c * s, a2))
+
+    @staticmethod
+    def _mps_RR(RR, A, Ac):
+        """out[a,c] = sum A[a,s,a'] RR[a',c'] Ac[c,s,c'] (mps.py:660-663)."""
+        a, s, a2 = A.shape
+        c, _, c2 = Ac.shape
+        T = ops.mm(A.view(a * s, a2), RR)                       # (a s, c')
+        return ops.mm(T.view(a, s * c2), Ac.view(c, s * c2).t())
+
+    @staticmethod
+    def _mps_RAR(RL, A, RR):
+        """RL . A . RR (mps.py:748-751)."""
+        a, s, a2 = A.shape
+        T = ops.mm(RL, A.view(a, s * a2))                       # (c, s a')
+        c = RL.shape[0]
+        return ops.mm(T.view(c * s, a2), RR).view(c, s, RR.shape[1])
+
+    def update_RL_mix(self, phi, n):
+        """mps.py:436-444."""
+        new = self._mps_RL(self.R[n], phi.A[n], self.A[n])
+        if n == self.L - 1:
+            self.R[self.L + 1] = float(new.reshape(-1)[0].item())
+        else:
+            self.R[n + 1] = new
+
+    def update_RR_mix(self, phi, n):
+        """mps.py:418-426."""
+        new = self._mps_RR(self.R[n + 1], phi.A[n], self.A[n])
+        if n == 0:
+            self.R[self.L + 1] = float(new.reshape(-1)[0].item())
+        else:
+            self.R[n] = new
+
+    def setup_RL_mix(self, phi):
+        """mps.py:446-452."""
+        for n in range(self.L):
+            self.update_RL_mix(phi, n)
+        return self.R[-1]
+
+    def setup_RR_mix(self, phi):
+        """mps.py:428-434."""
+        for n in range(self.L - 1, -1, -1):
+            self.update_RR_mix(phi, n)
+        return self.R[-1]
+
+    def bond_env_mix(self, phi, n):
+        """p x p environment of the physical leg of site n in <self|phi> (mps.py:454-458, 765-769)."""
+        T2 = self._mps_RAR(self.R[n], phi.A[n], self.R[n + 1])          # (c, s, c')
+        c, s, c2 = T2.shape
+        Ac = self.A[n]
+        # env[s, s'] = sum_{c,c'} T2[c,s,c'] Ac[c,s',c']
+        return ops.mm(T2.permute(1, 0, 2).reshape(s, c * c2), Ac.permute(1, 0, 2).reshape(Ac.shape[1], c * c2).t())
+
+    def expectation_mix(self, phi, n):
+        """<self| ... |phi> at site n given both environments (mps.py:587-591, 694-698).  Syncs."""
+        T2 = self._mps_RAR(self.R[n], phi.A[n], self.R[n + 1])
+        return float(ops.mm(T2.reshape(1, -1), self.A[n].reshape(-1, 1)).item())
+
+    # -- variational compression --------------------------------------------------------------------------
+    def optimise_site(self, phi, n):
+        """mps.py:617-621."""
+        self.A[n] = self._mps_RAR(self.R[n], phi.A[n], self.R[n + 1])
+
+    def update_S(self):
+        """Schmidt values of the centre matrix; returns ||S_old - S_new||_2 (mps.py:550-560)."""
+        S = ops.svdvals(self.C)
+        if self.S[self.pC].size != S.size:
+            self.S[self.pC] = self._one_S(S.size)
+        dS = float(np.sqrt(np.sum((self.S[self.pC] - S) ** 2)))
+        self.S[self.pC] = S
+        return dS
+
+    def variational_compress(self, phi, tol=None, max_sweeps=1, verbose=False):
+        """mps.py:238-279."""
+        if tol is None:
+            tol = self.zero
+        overlap = self.setup_RL_mix(phi)
+        sweeps, diff = 0, 1.0
+        while diff > tol:
+            if sweeps >= max_sweeps:
+                return overlap
+            for n in range(self.L - 1, 0, -1):
+                self.optimise_site(phi, n)
+                self.orth_right(n)
+                self.update_S()
+                self.update_RR_mix(phi, n)
+            diff = 0.0
+            for n in range(self.L):
+                self.optimise_site(phi, n)
+                self.orth_left(n)
+                diff = max(diff, self.update_S())
+                self.update_RL_mix(phi, n)
+            overlap = self.R[-1]
+            sweeps += 1
+        return overlap
+
+    def compress_mps(self, Dmax=np.inf, tolS=None, tolV=None, max_sweeps=4, graduate_truncation=True, verbose=False):
+        """Truncate: SVD initialisation + variational sweeps (mps.py:175-200).  Returns the overlap <psi|phi>."""
+        self.canonise_right()
+        phi = self.copy()
+        self.discarded = [0] * (self.L + 1)
+        if graduate_truncation:
+            self.canonise_left(compress=True, Dmax=Dmax * 4, tol=tolS / 10)
+            self.variational_compress(phi, tol=tolV, max_sweeps=1)
+            self.canonise_right(compress=True, Dmax=Dmax * 2, tol=tolS / 2)
+        self.canonise_left(compress=True, Dmax=Dmax, tol=tolS)
+        return self.variational_compress(phi, tol=tolV, max_sweeps=max_sweeps)

@@ -1,0 +1,195 @@
+"""Thin tensor-level wrappers over the C-ABI (torch tensors in, torch tensors out).  PyTorch is used for device
+memory and streams only; every contraction/factorisation below runs in libtnpeps."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import lib, check
+
+QR_NB = 32
+_ws = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError('tnac4o_amd operates on GPU tensors only (got a %s tensor); there is no CPU path' % t.device)
+    if t.dtype != torch.float64:
+        raise TypeError('float64 required')
+
+
+def workspace(nbytes, slot=0):
+    """A persistent per-device scratch buffer of at least nbytes (grown on demand)."""
+    dev = torch.cuda.current_device()
+    key = (dev, slot)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device='cuda')
+        _ws[key] = buf
+    return buf
+
+
+def mm(A, B, out=None, alpha=1.0, beta=0.0):
+    """out = alpha * A @ B + beta * out for 2-D views with arbitrary strides (tn_gemm)."""
+    _need_gpu(A)
+    _need_gpu(B)
+    M, K = A.shape
+    K2, N = B.shape
+    assert K == K2, (A.shape, B.shape)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float64, device=A.device)
+    L = lib()
+    wsb = L.tn_gemm_ws_bytes(M, N, K, 1)
+    ws = workspace(wsb, 1) if wsb > 0 else None
+    check(L.tn_gemm(M, N, K, alpha, A.data_ptr(), A.stride(0), A.stride(1), B.data_ptr(), B.stride(0), B.stride(1),
+                    beta, out.data_ptr(), out.stride(0), out.stride(1), 1, 0, 0, 0,
+                    ws.data_ptr() if ws is not None else None, wsb, _stream()))
+    return out
+
+
+def bmm(A, B, out=None):
+    """Batched out[b] = A[b] @ B[b]; A (batch|1, M, K), B (batch|1, K, N) with arbitrary strides."""
+    _need_gpu(A)
+    _need_gpu(B)
+    batch = max(A.shape[0], B.shape[0])
+    M, K = A.shape[1:]
+    N = B.shape[2]
+    if out is None:
+        out = torch.empty((batch, M, N), dtype=torch.float64, device=A.device)
+    if batch == 0:
+        return out
+    bsa = A.stride(0) if A.shape[0] > 1 else 0
+    bsb = B.stride(0) if B.shape[0] > 1 else 0
+    check(lib().tn_gemm(M, N, K, 1.0, A.data_ptr(), A.stride(1), A.stride(2), B.data_ptr(), B.stride(1), B.stride(2), 0.0,
+                        out.data_ptr(), out.stride(1), out.stride(2), batch, bsa, bsb, out.stride(0), None, 0, _stream()))
+    return out
+
+
+def absorb(A, W, hconj):
+    """One site of MPO.MPS absorption (tn_absorb).  A (Dl,p,Dr), W (ba,po,bb,pi), both contiguous."""
+    _need_gpu(A)
+    _need_gpu(W)
+    A, W = A.contiguous(), W.contiguous()
+    Dl, p, Dr = A.shape
+    ba, po, bb, pi = W.shape
+    pnew = pi if hconj else po
+    out = torch.empty((Dl * ba, pnew, Dr * bb), dtype=torch.float64, device=A.device)
+    check(lib().tn_absorb(A.data_ptr(), W.data_ptr(), out.data_ptr(), Dl, p, Dr, ba, po, bb, pi, 1 if hconj else 0,
+                          _stream()))
+    return out
+
+
+def qr_into(T, Q, R, overwrite=False, nb=None):
+    """Economic QR of the 2-D view T into the (strided) views Q (m x k) and R (k x n); diag(R) >= 0."""
+    _need_gpu(T)
+    m, n = T.shape
+    if not overwrite:
+        T = T.clone(memory_format=torch.preserve_format)
+    nb = nb or QR_NB
+    L = lib()
+    wsb = L.tn_qr_ws_bytes(m, n, nb)
+    ws = workspace(wsb, 0)
+    check(L.tn_qr(T.data_ptr(), T.stride(0), T.stride(1), m, n, Q.data_ptr(), Q.stride(0), Q.stride(1), R.data_ptr(),
+                  R.stride(0), R.stride(1), nb, ws.data_ptr(), wsb, _stream()))
+    return Q, R
+
+
+def qr(T, overwrite=False, nb=None):
+    m, n = T.shape
+    k = min(m, n)
+    Q = torch.empty((m, k), dtype=torch.float64, device=T.device)
+    R = torch.empty((k, n), dtype=torch.float64, device=T.device)
+    return qr_into(T, Q, R, overwrite, nb)
+
+
+def svd_trunc(Cm, Dmax, tol):
+    """Truncated SVD of the 2-D view Cm.  Returns (U[:, :keep], S[:keep], Vt[:keep], keep, discarded, info)."""
+    _need_gpu(Cm)
+    k, n = Cm.shape
+    cap = int(min(k, n, Dmax))
+    U = torch.empty((k, cap), dtype=torch.float64, device=Cm.device)
+    S = torch.empty((cap,), dtype=torch.float64, device=Cm.device)
+    Vt = torch.empty((cap, n), dtype=torch.float64, device=Cm.device)
+    L = lib()
+    wsb = L.tn_svd_ws_bytes(k, n, 1)
+    ws = workspace(wsb, 0)
+    keep, disc, sweeps, info = C.c_int64(0), C.c_double(0.0), C.c_int(0), C.c_int(0)
+    check(L.tn_svd_trunc(Cm.data_ptr(), Cm.stride(0), Cm.stride(1), k, n, cap if Dmax >= cap else int(Dmax), float(tol),
+                         U.data_ptr(), U.stride(0), U.stride(1), S.data_ptr(), Vt.data_ptr(), Vt.stride(0), Vt.stride(1),
+                         C.byref(keep), C.byref(disc), C.byref(sweeps), C.byref(info), ws.data_ptr(), wsb, _stream()))
+    kp = int(keep.value)
+    return U[:, :kp], S[:kp], Vt[:kp], kp, float(disc.value), dict(sweeps=sweeps.value, info=info.value)
+
+
+def svdvals(Cm):
+    """Singular values (host numpy array, descending) of the 2-D view Cm."""
+    _need_gpu(Cm)
+    k, n = Cm.shape
+    out = np.empty(min(k, n), dtype=np.float64)
+    L = lib()
+    wsb = L.tn_svd_ws_bytes(k, n, 0)
+    ws = workspace(wsb, 0)
+    sweeps, info = C.c_int(0), C.c_int(0)
+    check(L.tn_svdvals(Cm.data_ptr(), Cm.stride(0), Cm.stride(1), k, n, out.ctypes.data_as(C.POINTER(C.c_double)),
+                       C.byref(sweeps), C.byref(info), ws.data_ptr(), wsb, _stream()))
+    return out
+
+
+def nfactor_dev(T):
+    """Device tensor [nf, 1/nf] with nf = 2^floor(log2 max|T|) (tn_nfactor).  T must be contiguous."""
+    _need_gpu(T)
+    assert T.is_contiguous()
+    out = torch.empty(3, dtype=torch.float64, device=T.device)      # [nf, 1/nf, scratch slot]
+    check(lib().tn_nfactor(T.data_ptr(), T.numel(), out.data_ptr(), out.data_ptr() + 16, _stream()))
+    return out
+
+
+def scale_(T, scalar_dev):
+    """T *= scalar_dev[0] in place (T contiguous)."""
+    assert T.is_contiguous()
+    check(lib().tn_scale_by(T.data_ptr(), T.numel(), scalar_dev.data_ptr(), _stream()))
+    return T
+
+
+def normalize_pow2_(T):
+    """T /= nfactor(T) in place; returns the device pair [nf, 1/nf]."""
+    f = nfactor_dev(T)
+    scale_(T, f[1:2])
+    return f
+
+
+def scale_phys_(A, diag, inv=False):
+    assert A.is_contiguous() and diag.is_contiguous()
+    Dl, p, Dr = A.shape
+    assert diag.numel() >= p
+    check(lib().tn_scale_phys(A.data_ptr(), Dl, p, Dr, diag.data_ptr(), 1 if inv else 0, _stream()))
+    return A
+
+
+def nfactor_batched_(X):
+    """Each X[b] (contiguous) divided by its own nfactor."""
+    assert X.is_contiguous()
+    b = X.shape[0]
+    if b:
+        check(lib().tn_nfactor_batched(X.data_ptr(), b, X.numel() // b, _stream()))
+    return X
+
+
+def calc_pn(T1, RR, F, dmap, rmap, pref, suf, lidx, uidx):
+    """Batched conditional probabilities (tn_calc_pn).  Returns (P (nb,q), minP (nb))."""
+    nb = pref.numel()
+    q, nl, nu = F.shape
+    _, p, Dr = T1.shape
+    br = RR.shape[2]
+    for t in (T1, RR, F, dmap, rmap, pref, suf, lidx, uidx):
+        assert t.is_contiguous() and t.is_cuda
+    P = torch.empty((nb, q), dtype=torch.float64, device=T1.device)
+    mP = torch.empty((nb,), dtype=torch.float64, device=T1.device)
+    check(lib().tn_calc_pn(T1.data_ptr(), RR.data_ptr(), F.data_ptr(), dmap.data_ptr(), rmap.data_ptr(), pref.data_ptr(),
+                           suf.data_ptr(), lidx.data_ptr(), uidx.data_ptr(), nb, q, nl, nu, p, Dr, br, P.data_ptr(),
+                           mP.data_ptr(), _stream()))
+    return P, mP

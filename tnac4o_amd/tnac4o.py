@@ -1,0 +1,550 @@
+"""The ``tnac4o`` solver class on MI355X: same constructor, methods and result attributes as the reference's
+``tnac4o.tnac4o`` (tnac4o/tnac4o.py:78-551) for the ground-state path, with the PEPS contraction on the GPU.
+
+Split of work
+  host (numpy, O(nnz) / O(M) integer work): coupling split, rotations, energy tables, the branch bookkeeping of
+      search_ground_state (cut-off, merge of equal boundary indices, top-M) — restated from the reference so that
+      tie-breaking agrees;
+  GPU (libtnpeps): boundary-MPS sweeps (absorb, QR, Jacobi SVD, GEMMs) through ``tnac4o_amd.mps``; right
+      environments for every distinct boundary suffix (batched GEMMs); left environments for every distinct prefix;
+      conditional probabilities of all branches of a site-step in one launch (tn_calc_pn).
+
+The 5-leg PEPS tensor (q,l,d,r,u) of the reference (tnac4o.py:1562-1672; 134 MB and 1/256 dense for chimera) is
+never formed: T[s,l,d,r,u] = F[s,l,u] [d = dmap[s]] [r = rmap[s]].
+"""
+import itertools
+import logging
+
+import numpy as np
+import scipy.linalg
+import torch
+
+from . import mps, ops
+
+
+def _bits(n):
+    s = np.arange(2 ** n)[:, None]
+    return ((s >> np.arange(n)[None, :]) & 1).astype(np.int64)
+
+
+def _spins(n):
+    return 1 - 2 * _bits(n)
+
+
+def _dev_f64(x):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float64).cuda()
+
+
+def _dev_i32(x):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32)).cuda()
+
+
+def _unique_rows(a):
+    """Sorted unique rows and the inverse map; handles zero-width keys."""
+    if a.shape[1] == 0:
+        return np.zeros((1, 0), dtype=a.dtype), np.zeros(a.shape[0], dtype=np.int64)
+    u, inv = np.unique(a, axis=0, return_inverse=True)
+    return u, inv.reshape(-1)
+
+
+class tnac4o:
+    """Ising ('Ising') or Random-Markov-Field ('RMF') problem on an Nx x Ny lattice of cells (tnac4o.py:145-198)."""
+
+    def __init__(self, mode='Ising', Nx=4, Ny=4, Nc=8, beta=1, J=None):
+        self.mode, self.beta = mode, beta
+        self.Nx_model, self.Ny_model = Nx, Ny
+        self.Nx, self.Ny = Nx, Ny
+        if mode == 'Ising':
+            if Nc > 9:
+                raise ValueError('Single cluster is too large.')
+            self.Nc = Nc
+            self.indtype = np.int8 if Nc <= 8 else np.int16
+        elif mode == 'RMF':
+            self.Nc = 1
+            self.indtype = np.int8
+        else:
+            raise ValueError("mode must be 'Ising' or 'RMF'")
+        self.L = Nx * Ny * self.Nc
+        self.order = np.arange(Nx * Ny)
+        self.order_i = np.arange(Nx * Ny)
+        self.logger = logging.getLogger('tnac4o')
+        self.energy = np.zeros(0)
+        self.probability = np.zeros(0)
+        self.rotation = 0
+        self.degeneracy = 0
+        self.states = np.zeros((0, Nx * Ny), dtype=self.indtype)
+        self.discarded_probability = -np.inf
+        self.negative_probability = 0.0
+        if J is not None:
+            if mode == 'Ising':
+                Jd = np.zeros((self.L, self.L))              # upper triangular accumulation (tnac4o.py:176-181)
+                for i, j, v in J:
+                    a, b = (i, j) if i <= j else (j, i)
+                    Jd[a, b] += v
+                self.J = Jd
+                self.ind0 = [[self._active(ny, nx) for nx in range(Nx)] for ny in range(Ny)]
+                self.active = sum(len(self.ind0[ny][nx]) for ny in range(Ny) for nx in range(Nx))
+            else:
+                self.J = {'fun': J['fun'], 'fac': dict(J['fac']), 'N': J['N']}
+                self.N = np.array(J['N']).copy()
+            self._divide_couplings()
+
+    # ------------------------------------------------------------------------------------ problem setup (host)
+    def _active(self, ny, nx):
+        ind = self.Nc * (self.Nx * ny + nx) + np.arange(self.Nc)
+        w = np.abs(self.J[ind, :]).sum(1) + np.abs(self.J[:, ind]).sum(0)
+        return ind[w > 1e-12]
+
+    def _divide_couplings(self):
+        """Per-cell coupling blocks and bond index sets (tnac4o.py:1391-1457)."""
+        Ny, Nx = self.Ny, self.Nx
+        self.lu = np.ones((Ny, Nx), dtype=int)
+        self.lr = np.ones((Ny, Nx), dtype=int)
+        self.ll = np.ones((Ny, Nx), dtype=int)
+        self.ld = np.ones((Ny, Nx), dtype=int)
+        if self.mode == 'Ising':
+            self.ind = [[self._active(ny, nx) for nx in range(Nx)] for ny in range(Ny)]
+            self.sN = np.array([[len(self.ind[ny][nx]) for nx in range(Nx)] for ny in range(Ny)])
+            self.N = 2 ** self.sN
+            self.Jin = [[None] * Nx for _ in range(Ny)]
+            self.Jl = [[np.zeros((self.sN[ny][nx], 0)) for nx in range(Nx)] for ny in range(Ny)]
+            self.Ju = [[np.zeros((self.sN[ny][nx], 0)) for nx in range(Nx)] for ny in range(Ny)]
+            self.id = [[np.zeros(0, dtype=int) for _ in range(Nx)] for _ in range(Ny)]
+            self.ir = [[np.zeros(0, dtype=int) for _ in range(Nx)] for _ in range(Ny)]
+            self.sl, self.sd, self.sr, self.su = (np.zeros((Ny, Nx), dtype=int) for _ in range(4))
+            for ny in range(Ny):
+                for nx in range(Nx):
+                    ind = self.ind[ny][nx]
+                    self.Jin[ny][nx] = self.J[np.ix_(ind, ind)]
+                    for (oy, ox, Jn, idx, s_here, s_there, ldim) in (
+                            (ny, nx - 1, self.Jl, self.ir, self.sl, self.sr, self.lr),
+                            (ny - 1, nx, self.Ju, self.id, self.su, self.sd, self.ld)):
+                        if oy < 0 or ox < 0:
+                            continue
+                        JJ = self.J[np.ix_(self.ind[oy][ox], ind)]
+                        rows = np.nonzero(np.abs(JJ).sum(1))[0]
+                        Jn[ny][nx] = JJ[rows].T
+                        idx[oy][ox] = rows
+                        s_here[ny][nx] = s_there[oy][ox] = len(rows)
+                        ldim[oy][ox] = 2 ** len(rows)
+        else:
+            fac = self.J['fac']
+            for ny in range(Ny):
+                for nx in range(Nx):
+                    if (ny, nx - 1, ny, nx) in fac or (ny, nx, ny, nx - 1) in fac:
+                        self.ll[ny, nx] = self.N[ny][nx - 1]
+                    if (ny, nx, ny, nx + 1) in fac or (ny, nx + 1, ny, nx) in fac:
+                        self.lr[ny, nx] = self.N[ny][nx + 1]
+                    if (ny - 1, nx, ny, nx) in fac or (ny, nx, ny - 1, nx) in fac:
+                        self.lu[ny, nx] = self.N[ny - 1][nx]
+                    if (ny, nx, ny + 1, nx) in fac or (ny + 1, nx, ny, nx) in fac:
+                        self.ld[ny, nx] = self.N[ny + 1][nx]
+        self._reset_X()
+
+    def _reset_X(self):
+        """Gauge diagonals on the PEPS bonds (tnac4o.py:1811-1822)."""
+        Ny, Nx = self.Ny, self.Nx
+        self.Xu = np.ones((Ny, Nx, np.max(self.ld)))
+        self.Xd = np.ones((Ny, Nx, np.max(self.ld)))
+        self.Xl = np.ones((Ny, Nx, np.max(self.lr)))
+        self.Xr = np.ones((Ny, Nx, np.max(self.lr)))
+        self.overlaps_ud = np.empty((0, Ny - 1))
+
+    def rotate_graph(self, rot=1):
+        """Rotate the lattice by 90 degrees `rot` times: cell (ny,nx) -> (Nx-1-nx, ny) (tnac4o.py:290-340)."""
+        for _ in range(rot):
+            Nx, Ny, Nc = self.Nx, self.Ny, self.Nc
+            order_i = np.arange(Nx * Ny)
+            if self.mode == 'Ising':
+                self.rotation += 1
+                cells = np.arange(Nx * Ny).reshape(Ny, Nx)
+                dst = ((Nx - 1 - np.arange(Nx))[None, :] * Ny + np.arange(Ny)[:, None])      # [ny, nx] -> new cell
+                perm = np.empty(self.L, dtype=int)
+                perm[(cells[:, :, None] * Nc + np.arange(Nc)).reshape(-1)] = (dst[:, :, None] * Nc + np.arange(Nc)).reshape(-1)
+                order_i[dst.reshape(-1)] = cells.reshape(-1)
+                Jp = self.J[np.ix_(perm, perm)]
+                self.J = np.triu(Jp) + np.tril(Jp, -1).T
+            else:
+                new = {}
+                for key, val in self.J['fac'].items():
+                    if len(key) == 2:
+                        new[(Nx - key[1] - 1, key[0])] = val
+                    else:
+                        new[(Nx - key[1] - 1, key[0], Nx - key[3] - 1, key[2])] = val
+                Nn = np.zeros((Nx, Ny), dtype=int)
+                for nx in range(Nx):
+                    for ny in range(Ny):
+                        Nn[Nx - nx - 1, ny] = self.N[ny, nx]
+                        order_i[ny * Nx + nx] = (Nx - nx - 1) * Ny + ny
+                self.J['fac'], self.N = new, Nn
+            self.Nx, self.Ny = Ny, Nx
+            self.order = order_i[self.order]
+        self.order_i[self.order] = np.arange(self.Nx * self.Ny)
+        self.rotation = self.rotation % 4
+        self._divide_couplings()
+
+    # ------------------------------------------------------------------------------------ local tables (host)
+    def _ind_bond_down(self, st, ny, nx):
+        """tnac4o.py:1469-1478."""
+        if self.mode == 'Ising':
+            return _bits(self.sN[ny][nx])[st][:, self.id[ny][nx]] @ (2 ** np.arange(self.sd[ny][nx]))
+        return np.mod(st, self.ld[ny, nx])
+
+    def _ind_bond_right(self, st, ny, nx):
+        """tnac4o.py:1480-1489."""
+        if self.mode == 'Ising':
+            return _bits(self.sN[ny][nx])[st][:, self.ir[ny][nx]] @ (2 ** np.arange(self.sr[ny][nx]))
+        return np.mod(st, self.lr[ny, nx])
+
+    def _cell_energies(self, ny, nx):
+        """Es[s], Ese1[s,l], Ese4[s,u] (Ising tnac4o.py:1570-1581, RMF 1613-1635)."""
+        if self.mode == 'Ising':
+            st = _spins(self.sN[ny][nx])
+            Jin = self.Jin[ny][nx]
+            Es = np.sum((st @ np.triu(Jin, 1)) * st, 1) + st @ Jin.diagonal()
+            return Es, (st @ self.Jl[ny][nx]) @ _spins(self.sl[ny][nx]).T, (st @ self.Ju[ny][nx]) @ _spins(self.su[ny][nx]).T
+        fac, fun, N = self.J['fac'], self.J['fun'], self.N[ny][nx]
+        Es = np.reshape(fun[fac[(ny, nx)]], N) if (ny, nx) in fac else np.zeros(N)
+        if (ny, nx - 1, ny, nx) in fac:
+            E1 = fun[fac[(ny, nx - 1, ny, nx)]].T
+        elif (ny, nx, ny, nx - 1) in fac:
+            E1 = fun[fac[(ny, nx, ny, nx - 1)]]
+        else:
+            E1 = np.zeros((N, self.ll[ny, nx]))
+        if (ny - 1, nx, ny, nx) in fac:
+            E4 = fun[fac[(ny - 1, nx, ny, nx)]].T
+        elif (ny, nx, ny - 1, nx) in fac:
+            E4 = fun[fac[(ny, nx, ny - 1, nx)]]
+        else:
+            E4 = np.zeros((N, self.lu[ny, nx]))
+        return Es, E1, E4
+
+    def _update_Eng(self, states, ny, nx):
+        """Energy added by cell (ny,nx) to partial configurations (tnac4o.py:1506-1558)."""
+        Es, E1, E4 = self._cell_energies(ny, nx)
+        pos = ny * self.Nx + nx
+        dE = 1.0 * Es[states[:, pos]]
+        if nx > 0:
+            left = states[:, pos - 1]
+            dE += E1[states[:, pos], self._ind_bond_right(left, ny, nx - 1) if self.mode == 'Ising' else left]
+        if ny > 0:
+            up = states[:, pos - self.Nx]
+            dE += E4[states[:, pos], self._ind_bond_down(up, ny - 1, nx) if self.mode == 'Ising' else up]
+        return dE
+
+    def _peps_factor(self, ny, nx):
+        """F[s,l,u], dmap[s], rmap[s], pd, br with T[s,l,d,r,u] = F[s,l,u][d=dmap[s]][r=rmap[s]]
+        (tnac4o.py:1562-1672; same floating-point evaluation order as the reference)."""
+        b = self.beta
+        Es, E1, E4 = self._cell_energies(ny, nx)
+        Es, E1, E4 = b * (np.min(Es) - Es), b * (np.min(E1) - E1), b * (np.min(E4) - E4)
+        F = np.exp((Es[:, None, None] + E1[:, :, None]) + E4[:, None, :])
+        nl, nu = F.shape[1], F.shape[2]
+        F = F * self.Xu[ny][nx][:nu][None, None, :]
+        F = F * self.Xl[ny][nx][:nl][None, :, None]
+        q = F.shape[0]
+        if self.mode == 'Ising':
+            bt = _bits(self.sN[ny][nx])
+            rmap = bt[:, self.ir[ny][nx]] @ (2 ** np.arange(self.sr[ny][nx]))
+            dmap = bt[:, self.id[ny][nx]] @ (2 ** np.arange(self.sd[ny][nx]))
+            br, pd = 2 ** self.sr[ny][nx], 2 ** self.sd[ny][nx]
+        else:
+            s = np.arange(q)
+            br, pd = int(self.lr[ny, nx]), int(self.ld[ny, nx])
+            rmap = s % br if br > 1 else np.zeros(q, dtype=int)
+            dmap = s % pd if pd > 1 else np.zeros(q, dtype=int)
+        F = F * self.Xr[ny][nx][rmap][:, None, None]
+        F = F * self.Xd[ny][nx][dmap][:, None, None]
+        return F, np.asarray(dmap, dtype=np.int64), np.asarray(rmap, dtype=np.int64), int(pd), int(br)
+
+    def _mpo_site(self, ny, nx):
+        """W[l,d,r,u] = sum_s T[s,l,d,r,u] (tnac4o.py:1686) as a host array."""
+        F, dmap, rmap, pd, br = self._peps_factor(ny, nx)
+        q, nl, nu = F.shape
+        W = np.zeros((pd, br, nl, nu))
+        np.add.at(W, (dmap, rmap), F)                 # unbuffered, increasing s: the reference's summation order
+        return np.ascontiguousarray(W.transpose(2, 0, 1, 3))
+
+    def _row_mpo(self, ny):
+        At = mps.MPO(L=self.Nx)
+        for nx in range(self.Nx):
+            At.set_direct(self._mpo_site(ny, nx), nx)
+        return At
+
+    # ------------------------------------------------------------------------------------ sweeps (GPU)
+    def _setup_rhoT(self, graduate_truncation=True, Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20):
+        """Top boundary MPS of every row, built bottom-up (tnac4o.py:1674-1695)."""
+        Ny = self.Ny
+        self.rhoT = [None] * (Ny + 1)
+        self.rhoT_overlap = [1] * (Ny + 1)
+        self.rhoT_discarded = [0] * (Ny + 1)
+        self.rhoT[Ny] = mps.MPS(d=1, L=self.Nx, Dmax=1, initial='X')
+        for ny in range(Ny - 1, -1, -1):
+            psi = self.rhoT[ny + 1].copy()
+            psi.apply_mpo(self._row_mpo(ny), Hconj=True)
+            self.rhoT_overlap[ny] = psi.compress_mps(Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps,
+                                                     graduate_truncation=graduate_truncation)
+            self.rhoT_discarded[ny] = max(psi.discarded)
+            self.rhoT[ny] = psi
+
+    def _setup_rhoB(self, graduate_truncation=True, Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20):
+        """Bottom boundary MPS, built top-down (tnac4o.py:1697-1718)."""
+        Ny = self.Ny
+        self.rhoB = [None] * (Ny + 1)
+        self.rhoB_overlap = [1] * (Ny + 1)
+        self.rhoB_discarded = [0] * (Ny + 1)
+        self.rhoB[0] = mps.MPS(d=1, L=self.Nx, Dmax=1, initial='X')
+        for ny in range(Ny):
+            psi = self.rhoB[ny].copy()
+            psi.apply_mpo(self._row_mpo(ny), Hconj=False)
+            self.rhoB_overlap[ny + 1] = psi.compress_mps(Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps,
+                                                         graduate_truncation=graduate_truncation)
+            self.rhoB_discarded[ny + 1] = max(psi.discarded)
+            self.rhoB[ny + 1] = psi
+
+    # ------------------------------------------------------------------------------------ preconditioning
+    def precondition(self, mode='balancing', steps=2, beta_cond=(), Dmax_cond=(), max_scale=1024,
+                     graduate_truncation=False, tolS=1e-16, tolV=1e-10, max_sweeps=20):
+        """'balancing' gauge fix of the vertical bonds at reduced beta (tnac4o.py:342-379)."""
+        if mode != 'balancing':
+            return
+        beta_cond = list(beta_cond) or [self.beta * 2.0 ** (n - steps) for n in range(steps)]
+        Dmax_cond = list(Dmax_cond) or [8] * len(beta_cond)
+        main_beta = self.beta
+        for b, D in zip(beta_cond, Dmax_cond):
+            self.beta = b
+            self.logger.info('Preconditioning with beta = %.2f', b)
+            self._update_conditioning(Dmax=D, graduate_truncation=graduate_truncation, tolS=tolS, tolV=tolV,
+                                      max_sweeps=max_sweeps, max_scale=max_scale)
+        self.beta = main_beta
+
+    def _balance_site(self, B, T, ny, nx, max_scale, overlaps):
+        """One balancing step for the vertical bond above cell (ny,nx) (tnac4o.py:1844-1867).  The p x p bond
+        environment comes from the GPU; its dgebal scaling (<= 16 x 16) is computed on the host like the reference."""
+        env = B.bond_env_mix(T, nx).cpu().numpy()
+        _, sc = scipy.linalg.matrix_balance(env, permute=False, separate=True)
+        sc = np.minimum(np.maximum(sc[0], 1 / max_scale), max_scale)
+        nrm = lambda t: float(torch.linalg.vector_norm(t).item())                       # noqa: E731
+        o1 = B.expectation_mix(T, nx) * (1 / (nrm(B.A[nx]) * nrm(T.A[nx])))
+        B.apply_diagonalO(sc, nx)
+        T.apply_diagonalO(1 / sc, nx)
+        o2 = B.expectation_mix(T, nx) * (1 / (nrm(B.A[nx]) * nrm(T.A[nx])))
+        if o1 < overlaps[0, ny - 1]:
+            overlaps[0, ny - 1] = o1
+            overlaps[1, ny - 1] = max(o1, o2)
+        k = self.ld[ny - 1, nx]
+        self.Xd[ny - 1, nx, :k] *= sc
+        self.Xu[ny, nx, :k] *= 1 / sc
+
+    def _update_conditioning(self, graduate_truncation=False, Dmax=8, tolS=1e-16, tolV=1e-10, max_sweeps=4,
+                             max_scale=1024):
+        """tnac4o.py:1824-1918 ('ud' direction; the 'lr' branch is dead code in the reference)."""
+        max_scale = 2.0 ** np.floor(np.log2(np.sqrt(max_scale)))
+        kw = dict(graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps)
+        self._setup_rhoT(**kw)
+        self._setup_rhoB(**kw)
+        overlaps = np.ones((2, self.Ny - 1))
+        Nx = self.Nx
+
+        def renorm(B, k):
+            B.R[k] = B.R[k] * (1.0 / float(torch.linalg.vector_norm(B.R[k]).item()))
+        for ny in range(1, self.Ny):
+            B, T = self.rhoB[ny], self.rhoT[ny]
+            for nx in range(Nx):
+                B.update_RL_mix(T, nx)
+                renorm(B, nx + 1)            # for nx = Nx-1 this touches the unused 1x1 slot R[Nx], as in the reference
+            for nx in range(Nx - 1, -1, -1):
+                self._balance_site(B, T, ny, nx, max_scale, overlaps)
+                if nx > 0:
+                    B.orth_right(nx)
+                    B.attach_AC()
+                    T.orth_right(nx)
+                    T.attach_AC()
+                    B.update_RR_mix(T, nx)
+                    renorm(B, nx)
+            for nx in range(Nx):
+                self._balance_site(B, T, ny, nx, max_scale, overlaps)
+                if nx < Nx - 1:
+                    B.orth_left(nx)
+                    B.attach_CA()
+                    T.orth_left(nx)
+                    T.attach_CA()
+                    B.update_RL_mix(T, nx)
+                    renorm(B, nx + 1)
+        self.overlaps_ud = np.vstack([self.overlaps_ud, overlaps])
+        self.rhoB = []
+
+    # ------------------------------------------------------------------------------------ search (GPU + host)
+    def _setup_RR(self, vind, ny):
+        """Right environments for every distinct boundary-index suffix of the beam (tnac4o.py:1768-1784).
+
+        Returns a list over levels j = 0 .. Nx-1 (level j belongs to site nx = Nx - j): (keys, RR) with keys the
+        sorted unique suffixes vind[:, nx+1:] and RR a device tensor (nkeys, Dl(nx), bl(nx))."""
+        top = self.rhoT[ny + 1]
+        dev = top.A[0].device
+        levels = [(np.zeros((1, 0), dtype=vind.dtype), torch.ones((1, 1, 1), dtype=torch.float64, device=dev))]
+        for nx in range(self.Nx - 1, 0, -1):
+            keys, _ = _unique_rows(vind[:, nx + 1:])
+            pkeys, prr = levels[-1]
+            _, pinv = _unique_rows(np.vstack([pkeys, keys[:, 1:]]))          # parent rows: match suffix[1:] to pkeys
+            parent = pinv[len(pkeys):]
+            # pkeys are sorted-unique, so their own inverse is the identity: parent indexes rows of prr directly
+            W = mps._t(self._mpo_site(ny, nx))                               # (bl, p, br, pu)
+            bl, p, br, pu = W.shape
+            A = top.A[nx]
+            Dl, _, Dr = A.shape
+            RRg = prr[torch.as_tensor(parent, device=dev)]                   # (nk, Dr, br)
+            T = ops.bmm(A.view(1, Dl * p, Dr), RRg)                          # (nk, Dl p, br)
+            Wt = W.permute(3, 1, 2, 0).reshape(pu, p * br, bl).contiguous()
+            Wsel = Wt[torch.as_tensor(keys[:, 0].astype(np.int64), device=dev)]
+            RR = ops.bmm(T.view(-1, Dl, p * br), Wsel)                       # (nk, Dl, bl)
+            ops.nfactor_batched_(RR)
+            levels.append((keys, RR))
+        return levels
+
+    def search_ground_state(self, M=2 ** 10, relative_P_cutoff=1e-6, min_dEng=1e-12, graduate_truncation=True,
+                            Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20, trace=None):
+        """Row-major branch-and-bound for the most probable configuration (tnac4o.py:381-551).  Results are stored in
+        energy, degeneracy, states, probability (log2), discarded_probability, negative_probability.
+        ``trace`` (a list) receives (ny, nx, Pn table, minPn, vind) of every site-step when given (parity tests)."""
+        self.logger.info('Searching ground state with beta = %.2f', self.beta)
+        self._setup_rhoT(graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps)
+        Nx, Ny = self.Nx, self.Ny
+        vind = np.zeros((1, Nx + 1), dtype=self.indtype)
+        states = np.zeros((1, Nx * Ny), dtype=self.indtype)
+        Eng, prob, deg = np.zeros(1), np.zeros(1), np.ones(1, dtype=int)
+        pd_max, globalmin = -np.inf, 0.0
+        dev = self.rhoT[0].A[0].device
+
+        for ny in range(Ny):
+            self.logger.info('Row %d / %d', ny + 1, Ny)
+            levels = self._setup_RR(vind, ny)
+            top = self.rhoT[ny + 1]
+            pkeys = np.zeros((1, 0), dtype=vind.dtype)                       # distinct prefixes, sorted
+            RL = torch.ones((1, 1), dtype=torch.float64, device=dev)         # (nprefix, Dl)
+            for nx in range(Nx):
+                q, nb = int(self.N[ny][nx]), prob.size
+                F, dmap, rmap, _, _ = self._peps_factor(ny, nx)
+                AT = top.A[nx]
+                Dl, p, Dr = AT.shape
+                # every prefix's left environment through the top site in one GEMM: T1[prefix, d, chi']
+                T1 = ops.mm(RL, AT.view(Dl, p * Dr)).view(-1, p, Dr)
+                _, pref = _unique_rows(np.vstack([pkeys, vind[:, :nx]]))
+                pref = pref[len(pkeys):]
+                skeys, RR = levels[Nx - nx - 1]
+                _, suf = _unique_rows(np.vstack([skeys, vind[:, nx + 2:]]))
+                suf = suf[len(skeys):]
+                P, mP = ops.calc_pn(T1, RR, _dev_f64(F), _dev_i32(dmap), _dev_i32(rmap), _dev_i32(pref), _dev_i32(suf),
+                                    _dev_i32(vind[:, nx]), _dev_i32(vind[:, nx + 1]))
+                newprob = P.cpu().numpy()
+                minprob = float(mP.min().item())
+                if trace is not None:
+                    trace.append((ny, nx, newprob.copy(), mP.cpu().numpy(), vind.copy()))
+
+                with np.errstate(divide='ignore'):
+                    newprob = np.log2(newprob)
+                newprob += prob[:, None]
+                prob = newprob.reshape(nb * q)
+
+                order = np.arange(prob.size)
+                if relative_P_cutoff > 0:                                    # tnac4o.py:458-465
+                    cutoff = np.max(prob) + np.log2(relative_P_cutoff)
+                    keep = max(int((prob > cutoff).sum()), 1)
+                    if keep < prob.size:
+                        order = prob.argpartition(-keep - 1)
+                        pd_max = max(pd_max, prob[order[-keep - 1]])
+                        order = order[-keep:]
+                        prob = prob[order]
+
+                inds, indc = order // q, np.mod(order, q)                    # tnac4o.py:469-478
+                states = states[inds]
+                states[:, ny * Nx + nx] = indc
+                vind = vind[inds]
+                deg = deg[inds]
+                vind[:, nx] = self._ind_bond_down(indc, ny, nx)
+                vind[:, nx + 1] = self._ind_bond_right(indc, ny, nx)
+                Eng = Eng[inds]
+                Eng += self._update_Eng(states, ny, nx)
+
+                vindn, inv = np.unique(vind, return_inverse=True, axis=0)    # merge equal boundaries (:481-515)
+                inv = inv.reshape(-1)
+                order = inv.argsort()
+                inv = inv[order]
+                sizes = [len(list(g)) for _, g in itertools.groupby(inv)]
+                n_grp = len(sizes)
+                indn = np.zeros(n_grp, dtype=int)
+                degn = np.zeros(n_grp, dtype=int)
+                probn = np.zeros(n_grp)
+                lo = 0
+                for k, sz in enumerate(sizes):
+                    ind = order[lo:lo + sz]
+                    Ek = Eng[ind]
+                    imin = np.argmin(Ek)
+                    indn[k] = ind[imin]
+                    same = ind[(Ek - Ek[imin]) <= min_dEng]
+                    if len(same) > 1:
+                        degn[k] = sum(deg[same])
+                        probn[k] = np.mean(prob[same])
+                    else:
+                        degn[k] = deg[same][0]
+                        probn[k] = prob[same][0]
+                    lo += sz
+                vind, prob, deg = vindn, probn, degn
+                states, Eng = states[indn], Eng[indn]
+
+                if prob.size > M:                                            # keep the M most probable (:518-526)
+                    order = prob.argpartition(-M - 1)
+                    pd_max = max(pd_max, prob[order[-M - 1]])
+                    order = order[-M:]
+                    vind, states, prob, Eng, deg = vind[order], states[order], prob[order], Eng[order], deg[order]
+
+                # left environments of the new distinct prefixes: rows of T1 (tnac4o.py:528-535)
+                nkeys, _ = _unique_rows(vind[:, :nx + 1])
+                _, par = _unique_rows(np.vstack([pkeys, nkeys[:, :nx]]))
+                par = par[len(pkeys):]
+                RL = T1[torch.as_tensor(par, device=dev), torch.as_tensor(nkeys[:, nx].astype(np.int64), device=dev)].contiguous()
+                ops.nfactor_batched_(RL)
+                pkeys = nkeys
+                globalmin = min(globalmin, minprob)
+
+            vind[:, 1:] = vind[:, :-1]                                       # tnac4o.py:540-542
+            vind[:, 0] = 0
+
+        self.energy = Eng
+        self.degeneracy = deg[0]
+        self.states = states[:, self.order]
+        self.probability = prob
+        self.discarded_probability = pd_max
+        self.negative_probability = min(globalmin, 0)
+        return Eng
+
+    # ------------------------------------------------------------------------------------ output
+    def binary_states(self, number=-1):
+        """Bit strings: 1 spin up, 0 spin down, 2 inactive (tnac4o.py:261-288)."""
+        ns = self.states.shape[0]
+        ns = ns + number + 1 if number < 0 else min(number, ns)
+        if self.mode != 'Ising':
+            return self.states[:ns]
+        out = np.zeros((ns, self.L), dtype=np.int8) + 2
+        k = -1
+        for ny in range(self.Ny_model):
+            for nx in range(self.Nx_model):
+                k += 1
+                act = self.ind0[ny][nx]
+                out[:, act] = (1 - _bits(len(act)))[self.states[:ns, k]]
+        return out
+
+    def show_solution(self, state=False):
+        """tnac4o.py:244-259."""
+        if len(self.energy) > 0:
+            print("Energy            : %4.6f" % self.energy[0])
+            print("Degeneracy        : %2d" % self.degeneracy)
+            print("log2(Probability) : %0.2e" % self.probability[0])
+            print("Discarder log2(P) : %0.2e" % self.discarded_probability)
+            print("Min P (err)       : %0.2e" % self.negative_probability)
+            print("# of states       : %1d" % len(self.energy))
+            print("Rotation/direction: %1d" % self.rotation)
+            if state:
+                print(self.states[0])
+        else:
+            print('No solution to show.')
