@@ -29,7 +29,7 @@ import torch         # noqa: E402
 
 FAMILIES = ['gemm_kernel<128,128>', 'gemm_kernel<128,32>', 'gemm_kernel<32,128>', 'gemm_kernel<64,64>',
             'splitk_reduce_kernel', 'absorb_kernel', 'gram_partial_kernel', 'eig_small_kernel',
-            'rows_times_small_kernel', 'small_t_times_vecs_kernel']
+            'rows_times_small_kernel', 'small_t_times_vecs_kernel', 'tsqr_factor/apply_kernel']
 MFMA_FAM = {0, 1, 2, 3}
 PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X fp64 matrix peak (vendor figure quoted in SURVEY.md §7; not in the microarch guide)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec

@@ -86,7 +86,7 @@ int tn_nfactor_batched(double* x, int64_t batch, int64_t len, void* stream);
 
 /* ---- measurement: bracket every launch of the selected kernel families with HIP events on the launch stream.
  * family ids: 0-3 gemm_kernel<128,128> / <128,32> / <32,128> / <64,64> (all operand layouts), 4 splitk_reduce,
- * 5 absorb, 6 gram_partial, 7 eig_small, 8 rows_times_small, 9 small_t_times_vecs.
+ * 5 absorb, 6 gram_partial, 7 eig_small, 8 rows_times_small, 9 small_t_times_vecs, 10 tsqr_factor/apply.
  * mask bit f enables family f.  tn_profile_get synchronises the recorded events and returns totals since the last
  * reset: launches, summed duration (ms), algorithmic flops and bytes (SURVEY.md §8d counts). */
 void tn_profile_enable(unsigned mask);

@@ -233,7 +233,8 @@ def test_svd_golden(ops, shape, kind):
         pinned = kind != 'rankdef' or tol > 1e-10 or Dmax == 8         # eps-level rank decisions are noise
         # graded spectrum: sigma_k = 10^(-k/2) crosses eps*S0 between k=31 and k=32, where LAPACK's absolute error
         # (~eps*S0) decides; the Jacobi kernel resolves sigma_31 = 3.2e-16 > eps, so allow one vector of slack there
-        edge = kind == 'graded' and tol < 1e-10 and Dmax > 8
+        # (the same knife edge exists at tol = 1e-3: sigma_6 = 1e-3 * S0 exactly, decided by the last bit)
+        edge = kind == 'graded' and Dmax > 8
         check_svd(ops, T, min(Dmax, min(shape)), tol, int(want[0]) if pinned else None,
                   want[1] if pinned and not edge else None, Sref=g[tag + '_S'], keep_slack=1 if edge else 0)
     S = ops.svdvals(dev(T))

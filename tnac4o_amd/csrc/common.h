@@ -35,7 +35,7 @@ static inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
 
 // ---- optional event timing per kernel family (prof.hip) ---------------------------------------------
 enum { PROF_GEMM_128x128 = 0, PROF_GEMM_128x32, PROF_GEMM_32x128, PROF_GEMM_64x64, PROF_SPLITK_REDUCE, PROF_ABSORB,
-       PROF_GRAM, PROF_EIG, PROF_ROWS_SMALL, PROF_VECS_SMALL, PROF_NFAM };
+       PROF_GRAM, PROF_EIG, PROF_ROWS_SMALL, PROF_VECS_SMALL, PROF_TSQR, PROF_NFAM };
 bool prof_on(int fam);
 void prof_begin(hipStream_t st, int fam);
 void prof_end(hipStream_t st, int fam, double flops, double bytes);
@@ -93,5 +93,10 @@ int rows_times_small(hipStream_t st, double* X, int64_t rs, int64_t cs, int64_t 
 // c < L; in place when Out == In.  If nrot != nullptr groups with nrot[g]==0 are skipped.
 int small_t_times_vecs(hipStream_t st, const double* S, double* X, int64_t vs, int64_t es, int64_t L, int nvec, int w,
                        const int* pairs, int ngroups, const int* nrot);
+
+
+// ---- TSQR panel orthonormalisation (tsqr.hip) -------------------------------------------------------------------
+int64_t tsqr_ws_bytes(int64_t nrows, int b);
+int tsqr_orthonormalize(hipStream_t st, double* X, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws, int64_t ws_bytes);
 
 }  // namespace tn

@@ -247,6 +247,8 @@ struct QrWs {
     double *Y, *T, *X, *X2, *part, *Js, *Uinv, *Z, *Tri, *gemm_ws;
     int* dead;
     int64_t gemm_ws_bytes;
+    void* tsqr_ws;
+    int64_t tsqr_bytes;
 };
 
 static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
@@ -264,9 +266,11 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     double* Tri = (double*)take(P * nb * nb * 8);
     int* dead = (int*)take(nb * 4);
     // split-K scratch for the tall TN products (b x n, K = m)
-    int64_t gw = gemm_ws_bytes(nb, n > k ? n : k, m, 1);
-    if (gw < 0) gw = 0;
+    int64_t gw = (int64_t)64 * nb * (n > k ? n : k) * 8;      // upper bound of pick_splitk's partial buffers
     double* gws = (double*)take(gw + 256);
+    const int64_t tsb = tsqr_ws_bytes(m, nb < 32 ? nb : 32);
+    void* tsw = (void*)take(tsb);
+    if (w) { w->tsqr_ws = tsw; w->tsqr_bytes = tsb; }
     if (w) { w->Y = Y; w->T = T; w->X = X; w->X2 = X2; w->part = part; w->Js = Js; w->Uinv = Uinv; w->Z = Z; w->Tri = Tri;
              w->dead = dead; w->gemm_ws = gws; w->gemm_ws_bytes = gw; }
     return off;
@@ -294,23 +298,27 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         const int64_t mp = m - j0, ntr = n - j0;
         Mat Ap = sub(Am, j0, j0), Yp = sub(Ym, j0, j0);
         if ((rc = copy_mat(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b))) return rc;
-        // --- panel orthonormalisation: columns of Yp are the vectors (vs = ycs, es = yrs)
-        const int nchunk = gram_nchunk(mp);
-        for (int it = 0; it < 5; ++it) {
-            if ((rc = gram_partial(st, Yp.p, ycs, yrs, mp, b, b, nullptr, 1, nchunk, w.part))) return rc;
-            const int mode = (it < 4) ? 0 : 1;
-            // after the first round the columns are images of unit columns under an orthogonal J: a squared norm below
-            // 1e-26 there is rounding noise (possibly structured, e.g. all parallel), so the column is refilled
-            if ((rc = eig_small(st, w.part, nchunk, b, 1, mode, 12, it == 0 ? 0.0 : 1e-26, w.Js, mode == 0 ? w.dead : nullptr,
-                                nullptr, nullptr)))
-                return rc;
-            dbg_check(st, w.Js, b, 1, b, b, "Js", p, it);
-            if ((rc = rows_times_small(st, Yp.p, yrs, ycs, mp, b, w.Js))) return rc;
-            dbg_check(st, Yp.p, yrs, ycs, mp < 64 ? mp : 64, b, "W", p, it);
-            if (mode == 0) {
-                hipLaunchKernelGGL(refill_dead_kernel, dim3((unsigned)cdiv(mp, 256)), dim3(256), 0, st, Yp.p, yrs, ycs, mp,
-                                   b, w.dead, (uint64_t)(0x9E3779B97F4A7C15ULL * (uint64_t)(p * 4 + it + 1)));
-                TN_CHECK_LAUNCH("refill_dead_kernel");
+        // --- panel orthonormalisation
+        if (nb == 32) {
+            if ((rc = tsqr_orthonormalize(st, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes))) return rc;
+        } else {
+            const int nchunk = gram_nchunk(mp);
+            for (int it = 0; it < 5; ++it) {
+                if ((rc = gram_partial(st, Yp.p, ycs, yrs, mp, b, b, nullptr, 1, nchunk, w.part))) return rc;
+                const int mode = (it < 4) ? 0 : 1;
+                // after the first round the columns are images of unit columns under an orthogonal J: a squared norm below
+                // 1e-26 there is rounding noise (possibly structured, e.g. all parallel), so the column is refilled
+                if ((rc = eig_small(st, w.part, nchunk, b, 1, mode, 12, it == 0 ? 0.0 : 1e-26, w.Js, mode == 0 ? w.dead : nullptr,
+                                    nullptr, nullptr)))
+                    return rc;
+                dbg_check(st, w.Js, b, 1, b, b, "Js", p, it);
+                if ((rc = rows_times_small(st, Yp.p, yrs, ycs, mp, b, w.Js))) return rc;
+                dbg_check(st, Yp.p, yrs, ycs, mp < 64 ? mp : 64, b, "W", p, it);
+                if (mode == 0) {
+                    hipLaunchKernelGGL(refill_dead_kernel, dim3((unsigned)cdiv(mp, 256)), dim3(256), 0, st, Yp.p, yrs, ycs, mp,
+                                       b, w.dead, (uint64_t)(0x9E3779B97F4A7C15ULL * (uint64_t)(p * 4 + it + 1)));
+                    TN_CHECK_LAUNCH("refill_dead_kernel");
+                }
             }
         }
         // --- Householder reconstruction

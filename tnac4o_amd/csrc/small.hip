@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const double* __restr
 }
 
 int gram_nchunk(int64_t L) {
-    int64_t n = L / 256;
+    int64_t n = L / 128;
     if (n < 1) n = 1;
     if (n > 64) n = 64;
     return (int)n;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
     __shared__ double dsc[NB];
     __shared__ double rc[NB / 2], rsn[NB / 2];
     __shared__ int rp[NB / 2], rq[NB / 2];
-    __shared__ int cnt, total;
+    __shared__ int cnt, total, stepflag;
     __shared__ double red[256];
     const int tid = threadIdx.x, grp = blockIdx.x;
     const int n = (nvec + 1) & ~1;          // even working size (a padding index never rotates)
@@ -164,15 +164,21 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
         if (tid == 0 && maxoff_out) maxoff_out[grp] = red[0];
     }
 
-    if (mode != 1 && n >= 2) {
+    // Parallel-order Jacobi on the full NB x NB arrays (indices >= nvec are isolated: unit diagonal, zero coupling,
+    // so they never rotate).  Trip counts are compile-time so that each phase issues all of its LDS loads at once.
+    const bool need = (mode != 1) && (nvec >= 2) && (red[0] > 8.881784197001252e-16);
+    if (need) {
+        constexpr int HP = NB / 2, IT = HP * NB / 256;
         const double tol = 8.881784197001252e-16;      // 2^-50
         for (int sweep = 0; sweep < max_sweeps; ++sweep) {
             if (tid == 0) cnt = 0;
             __syncthreads();
-            for (int s = 0; s < n - 1; ++s) {
-                if (tid < n / 2) {
+            for (int s = 0; s < NB - 1; ++s) {
+                if (tid == 0) stepflag = 0;
+                __syncthreads();
+                if (tid < HP) {
                     int p, q;
-                    rr_pair(n, s, tid, p, q);
+                    rr_pair(NB, s, tid, p, q);
                     const double gpq = G[p * P + q], gpp = G[p * P + p], gqq = G[q * P + q];
                     double c = 1.0, sn = 0.0;
                     if (gpq != 0.0 && fabs(gpq) > tol * sqrt(fabs(gpp * gqq))) {
@@ -183,32 +189,47 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                         c = 1.0 / sqrt(1.0 + t * t);
                         sn = t * c;
                         atomicAdd(&cnt, 1);
+                        stepflag = 1;
                     }
                     rc[tid] = c; rsn[tid] = sn; rp[tid] = p; rq[tid] = q;
                 }
                 __syncthreads();
-                for (int e = tid; e < (n / 2) * n; e += 256) {          // rows: G <- R^T G
-                    const int a = e / n, j = e % n;
-                    const double c = rc[a], sn = rsn[a];
-                    if (sn != 0.0) {
-                        const int p = rp[a], q = rq[a];
-                        const double gp = G[p * P + j], gq = G[q * P + j];
-                        G[p * P + j] = c * gp - sn * gq;
-                        G[q * P + j] = sn * gp + c * gq;
+                if (stepflag == 0) continue;                       // uniform: nothing to rotate in this step
+                {   // rows: G <- R^T G
+                    double gp[IT], gq[IT];
+#pragma unroll
+                    for (int k = 0; k < IT; ++k) {
+                        const int e = tid + 256 * k, a = e / NB, j = e % NB;
+                        gp[k] = G[rp[a] * P + j];
+                        gq[k] = G[rq[a] * P + j];
+                    }
+#pragma unroll
+                    for (int k = 0; k < IT; ++k) {
+                        const int e = tid + 256 * k, a = e / NB, j = e % NB;
+                        const double c = rc[a], sn = rsn[a];
+                        G[rp[a] * P + j] = c * gp[k] - sn * gq[k];
+                        G[rq[a] * P + j] = sn * gp[k] + c * gq[k];
                     }
                 }
                 __syncthreads();
-                for (int e = tid; e < (n / 2) * n; e += 256) {          // columns: G <- G R, J <- J R
-                    const int a = e / n, i = e % n;
-                    const double c = rc[a], sn = rsn[a];
-                    if (sn != 0.0) {
-                        const int p = rp[a], q = rq[a];
-                        const double gp = G[i * P + p], gq = G[i * P + q];
-                        G[i * P + p] = c * gp - sn * gq;
-                        G[i * P + q] = sn * gp + c * gq;
-                        const double jp = J[i * P + p], jq = J[i * P + q];
-                        J[i * P + p] = c * jp - sn * jq;
-                        J[i * P + q] = sn * jp + c * jq;
+                {   // columns: G <- G R, J <- J R
+                    double gp[IT], gq[IT], jp[IT], jq[IT];
+#pragma unroll
+                    for (int k = 0; k < IT; ++k) {
+                        const int e = tid + 256 * k, a = e / NB, i = e % NB;
+                        gp[k] = G[i * P + rp[a]];
+                        gq[k] = G[i * P + rq[a]];
+                        jp[k] = J[i * P + rp[a]];
+                        jq[k] = J[i * P + rq[a]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < IT; ++k) {
+                        const int e = tid + 256 * k, a = e / NB, i = e % NB;
+                        const double c = rc[a], sn = rsn[a];
+                        G[i * P + rp[a]] = c * gp[k] - sn * gq[k];
+                        G[i * P + rq[a]] = sn * gp[k] + c * gq[k];
+                        J[i * P + rp[a]] = c * jp[k] - sn * jq[k];
+                        J[i * P + rq[a]] = sn * jp[k] + c * jq[k];
                     }
                 }
                 __syncthreads();
