@@ -193,6 +193,21 @@ def test_search_L512_golden():
     assert s.energy[0] == pytest.approx(E, abs=1e-5) and np.array_equal(s.binary_states()[0], bits)
 
 
+def test_search_L2048_droplet_golden_energy():
+    """The reference's largest bundled instance (chimera2048 droplet #1): full search at chi=32 on the GPU.  The golden
+    file gives the energy to 6 digits and one ground state; this instance is two-fold degenerate in the search
+    (deg = 2), so the energy, its independent recomputation and the degeneracy are pinned, not the bit string."""
+    from tnac4o_amd import energy_Jij
+    s = gpu_solver(L=2048)
+    s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=32)
+    E, bits = gi.golden_groundstate(2048, 1)
+    assert s.energy[0] == pytest.approx(E, abs=1e-5)
+    J = gi.droplet_J(2048, 1)
+    assert energy_Jij(J, s.binary_states()[:1])[0] == pytest.approx(s.energy[0], abs=1e-8)
+    assert energy_Jij(J, bits[None, :])[0] == pytest.approx(s.energy[0], abs=1e-8)      # the golden state has the same energy
+    assert int(s.degeneracy) >= 1 and min(s.rhoT_overlap) > 1 - 1e-10
+
+
 def test_search_rmf():
     import tnac4o_amd
     J = gi.minimal_rmf()

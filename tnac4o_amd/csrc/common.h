@@ -33,6 +33,24 @@ inline int hip_fail(hipError_t e, const char* what) {
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
 
+// Fast reciprocal square root / reciprocal with three Newton steps (full double accuracy to ~1 ulp; the hardware
+// seeds are single-precision accurate).  They sit on the per-column critical path of the panel factorisation.
+static __device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
+}
+static __device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+
+
 // ---- optional event timing per kernel family (prof.hip) ---------------------------------------------
 enum { PROF_GEMM_128x128 = 0, PROF_GEMM_128x32, PROF_GEMM_32x128, PROF_GEMM_64x64, PROF_SPLITK_REDUCE, PROF_ABSORB,
        PROF_GRAM, PROF_EIG, PROF_ROWS_SMALL, PROF_VECS_SMALL, PROF_TSQR, PROF_NFAM };

@@ -182,11 +182,15 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                     const double gpq = G[p * P + q], gpp = G[p * P + p], gqq = G[q * P + q];
                     double c = 1.0, sn = 0.0;
                     if (gpq != 0.0 && fabs(gpq) > tol * sqrt(fabs(gpp * gqq))) {
-                        const double tau = (gqq - gpp) / (2.0 * gpq);
+                        const double tau = (gqq - gpp) * 0.5 * fast_rcp(gpq);
                         double t;
-                        if (fabs(tau) > 1e150) t = 0.5 / tau;
-                        else t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                        c = 1.0 / sqrt(1.0 + t * t);
+                        if (!(fabs(tau) < 1e150)) t = 0.5 * fast_rcp(tau);
+                        else {
+                            const double h = 1.0 + tau * tau;
+                            t = copysign(fast_rcp(fabs(tau) + h * fast_rsqrt(h)), tau);
+                        }
+                        if (!(fabs(t) <= 1.0)) t = 0.0;            // non-finite intermediates (subnormal g_pq): no rotation
+                        c = fast_rsqrt(1.0 + t * t);
                         sn = t * c;
                         atomicAdd(&cnt, 1);
                         stepflag = 1;
@@ -195,41 +199,38 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                 }
                 __syncthreads();
                 if (stepflag == 0) continue;                       // uniform: nothing to rotate in this step
-                {   // rows: G <- R^T G
-                    double gp[IT], gq[IT];
+                {   // G <- R^T G R as independent 2x2 blocks (pair a x pair b);  J <- J R as (row i, pair b)
+                    constexpr int GB = HP * HP / 256, JB = NB * HP / 256;
+                    double g00[GB], g01[GB], g10[GB], g11[GB], jp[JB], jq[JB];
 #pragma unroll
-                    for (int k = 0; k < IT; ++k) {
-                        const int e = tid + 256 * k, a = e / NB, j = e % NB;
-                        gp[k] = G[rp[a] * P + j];
-                        gq[k] = G[rq[a] * P + j];
+                    for (int k = 0; k < GB; ++k) {
+                        const int e = tid + 256 * k, a = e / HP, b = e % HP;
+                        const int pa = rp[a], qa = rq[a], pb2 = rp[b], qb = rq[b];
+                        g00[k] = G[pa * P + pb2]; g01[k] = G[pa * P + qb];
+                        g10[k] = G[qa * P + pb2]; g11[k] = G[qa * P + qb];
                     }
 #pragma unroll
-                    for (int k = 0; k < IT; ++k) {
-                        const int e = tid + 256 * k, a = e / NB, j = e % NB;
-                        const double c = rc[a], sn = rsn[a];
-                        G[rp[a] * P + j] = c * gp[k] - sn * gq[k];
-                        G[rq[a] * P + j] = sn * gp[k] + c * gq[k];
-                    }
-                }
-                __syncthreads();
-                {   // columns: G <- G R, J <- J R
-                    double gp[IT], gq[IT], jp[IT], jq[IT];
-#pragma unroll
-                    for (int k = 0; k < IT; ++k) {
-                        const int e = tid + 256 * k, a = e / NB, i = e % NB;
-                        gp[k] = G[i * P + rp[a]];
-                        gq[k] = G[i * P + rq[a]];
-                        jp[k] = J[i * P + rp[a]];
-                        jq[k] = J[i * P + rq[a]];
+                    for (int k = 0; k < JB; ++k) {
+                        const int e = tid + 256 * k, i = e / HP, b = e % HP;
+                        jp[k] = J[i * P + rp[b]];
+                        jq[k] = J[i * P + rq[b]];
                     }
 #pragma unroll
-                    for (int k = 0; k < IT; ++k) {
-                        const int e = tid + 256 * k, a = e / NB, i = e % NB;
-                        const double c = rc[a], sn = rsn[a];
-                        G[i * P + rp[a]] = c * gp[k] - sn * gq[k];
-                        G[i * P + rq[a]] = sn * gp[k] + c * gq[k];
-                        J[i * P + rp[a]] = c * jp[k] - sn * jq[k];
-                        J[i * P + rq[a]] = sn * jp[k] + c * jq[k];
+                    for (int k = 0; k < GB; ++k) {
+                        const int e = tid + 256 * k, a = e / HP, b = e % HP;
+                        const int pa = rp[a], qa = rq[a], pb2 = rp[b], qb = rq[b];
+                        const double ca = rc[a], sa = rsn[a], cb = rc[b], sb = rsn[b];
+                        const double t00 = ca * g00[k] - sa * g10[k], t01 = ca * g01[k] - sa * g11[k];
+                        const double t10 = sa * g00[k] + ca * g10[k], t11 = sa * g01[k] + ca * g11[k];
+                        G[pa * P + pb2] = cb * t00 - sb * t01; G[pa * P + qb] = sb * t00 + cb * t01;
+                        G[qa * P + pb2] = cb * t10 - sb * t11; G[qa * P + qb] = sb * t10 + cb * t11;
+                    }
+#pragma unroll
+                    for (int k = 0; k < JB; ++k) {
+                        const int e = tid + 256 * k, i = e / HP, b = e % HP;
+                        const double cb = rc[b], sb = rsn[b];
+                        J[i * P + rp[b]] = cb * jp[k] - sb * jq[k];
+                        J[i * P + rq[b]] = sb * jp[k] + cb * jq[k];
                     }
                 }
                 __syncthreads();

@@ -178,13 +178,16 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     const int nchunk = gram_nchunk(L);
     const int nvec = 2 * SVD_W;
     std::vector<double> hoff((size_t)nr * ng);
+    // a single block pair is diagonalised completely inside eig_small (one round + one verification round);
+    // with several pairs two inner sweeps per visit give the fewest total Jacobi steps
+    const int inner_sweeps = (ng == 1) ? 12 : 2;
     int sweeps = 0;
     bool converged = false;
     for (int outer = 0; outer < 40 && !converged; ++outer) {
         for (int r = 0; r < nr; ++r) {
             const int* pr = w.pairs + (int64_t)r * ng * 2;
             if ((rc = gram_partial(st, w.X, L, 1, L, nvec, SVD_W, pr, ng, nchunk, w.part))) return rc;
-            if ((rc = eig_small(st, w.part, nchunk, nvec, ng, 2, 4, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng))) return rc;
+            if ((rc = eig_small(st, w.part, nchunk, nvec, ng, 2, inner_sweeps, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng))) return rc;
             if ((rc = small_t_times_vecs(st, w.Js, w.X, L, 1, L, nvec, SVD_W, pr, ng, w.nrot))) return rc;
             if (vectors)
                 if ((rc = small_t_times_vecs(st, w.Js, w.P, nv, 1, nv, nvec, SVD_W, pr, ng, w.nrot))) return rc;

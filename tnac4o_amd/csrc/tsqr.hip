@@ -46,23 +46,6 @@ __device__ __forceinline__ void block_rows(int64_t nrows, int nblk, int blk, int
     nr = (int)(base + (blk < rem ? 1 : 0));
 }
 
-// Fast reciprocal square root / reciprocal with three Newton steps (full double accuracy to ~1 ulp; the hardware
-// seeds are single-precision accurate).  They sit on the per-column critical path of the panel factorisation.
-__device__ __forceinline__ double fast_rsqrt(double x) {
-    double r = __builtin_amdgcn_rsq(x);
-    r = r * (1.5 - 0.5 * x * r * r);
-    r = r * (1.5 - 0.5 * x * r * r);
-    r = r * (1.5 - 0.5 * x * r * r);
-    return r;
-}
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = r * (2.0 - x * r);
-    r = r * (2.0 - x * r);
-    r = r * (2.0 - x * r);
-    return r;
-}
-
 // Thread (c, g) = (tid & 31, tid >> 5) keeps rows [32g, 32g+32) of column c of the block in REGISTERS for the whole
 // kernel; LDS only carries what must cross threads: the current column (vbuf), the current row (rowbuf) and the 8
 // partial sums per column (part).

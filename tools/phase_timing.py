@@ -1,0 +1,41 @@
+"""Wall time per phase of the sweep (synchronised), for finding where a sweep spends its time."""
+import os, sys, time, collections
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import torch
+import tnac4o_amd
+from tnac4o_amd import mps, ops
+from tnac4o_amd.auxx import synthetic_chimera
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+chi = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+n = {128: 4, 512: 8, 2048: 16}[L]
+acc = collections.defaultdict(float); cnt = collections.defaultdict(int)
+def timed(obj, name, label=None):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        r = f(*a, **k)
+        torch.cuda.synchronize(); acc[label or name] += time.perf_counter() - t; cnt[label or name] += 1
+        return r
+    setattr(obj, name, g)
+for nm in ['qr_into', 'svd_trunc', 'svdvals', 'mm', 'absorb']:
+    timed(ops, nm, 'ops.' + nm)
+s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=synthetic_chimera(n, n, 20260004), beta=3.0)
+orig = mps.MPS.compress_mps
+def compress(self, Dmax, tolS, tolV, max_sweeps, graduate_truncation=True, verbose=False):
+    def ph(label, fn):
+        torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); acc[label] += time.perf_counter() - t; return r
+    ph('p1 canonise_right', self.canonise_right)
+    phi = ph('copy', self.copy)
+    self.discarded = [0] * (self.L + 1)
+    ph('p2 canonise_left 4chi', lambda: self.canonise_left(compress=True, Dmax=Dmax * 4, tol=tolS / 10))
+    ph('v1 variational', lambda: self.variational_compress(phi, tol=tolV, max_sweeps=1))
+    ph('p3 canonise_right 2chi', lambda: self.canonise_right(compress=True, Dmax=Dmax * 2, tol=tolS / 2))
+    ph('p4 canonise_left chi', lambda: self.canonise_left(compress=True, Dmax=Dmax, tol=tolS))
+    return ph('v2 variational', lambda: self.variational_compress(phi, tol=tolV, max_sweeps=max_sweeps))
+mps.MPS.compress_mps = compress
+t0 = time.perf_counter()
+s._setup_rhoT(graduate_truncation=True, Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
+torch.cuda.synchronize(); tot = time.perf_counter() - t0
+print('total %.2f s (with per-call syncs)' % tot)
+for k in sorted(acc, key=lambda k: -acc[k]):
+    print('%-26s %8.3f s  %6d calls' % (k, acc[k], cnt[k]))
