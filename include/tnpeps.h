@@ -70,6 +70,17 @@ int tn_scale_by(double* x, int64_t n, const double* scalar_dev, void* stream);
 /* A[dl, s, dr] *= diag[s] (inv=0) or /= diag[s] (inv=1).  Replaces MPS.apply_diagonalO (mps.py:361-366). */
 int tn_scale_phys(double* A, int64_t Dl, int64_t p, int64_t Dr, const double* diag, int inv, void* stream);
 
+/* ---- K7: structured PEPS-factor and MPO-site builder.  Replaces tnac4o._peps_tensor (tnac4o.py:1562-1672) and the sum
+ * over the physical index at tnac4o.py:1686 without ever forming the dense (q,l,d,r,u) tensor:
+ *   F[s,l,u] = exp((Es[s] + E1[s,l]) + E4[s,u]) * Xu[u] * Xl[l] * Xr[rmap[s]] * Xd[dmap[s]]     (q, nl, nu)
+ *   W[l,d,r,u] = sum_{s: dmap[s]=d, rmap[s]=r} F[s,l,u]                                          (nl, pd, br, nu)
+ * Es/E1/E4 are the beta-scaled min-shifted energy tables beta*(min E - E); dmap/rmap are int32. */
+int tn_peps_factor(const double* Es, const double* E1, const double* E4, const double* Xu, const double* Xl, const double* Xr,
+                   const double* Xd, const int32_t* dmap, const int32_t* rmap, int64_t q, int64_t nl, int64_t nu, double* F,
+                   void* stream);
+int tn_mpo_from_factor(const double* F, const int32_t* dmap, const int32_t* rmap, int64_t q, int64_t nl, int64_t nu, int64_t pd,
+                       int64_t br, double* W, void* stream);
+
 /* ---- K8: conditional probabilities of one cell for a batch of branches.  Replaces the per-branch loop
  * tnac4o.py:444-448 around _calculate_Pn (:1786-1807), including the negative-probability rule.
  *   T1: (npref, p, Dr)  left environment times the top MPS site, one row block per distinct prefix

@@ -258,3 +258,28 @@ def test_svd_triangular_lowrank(ops):
     Sref = np.linalg.svd(R, compute_uv=False)
     assert keep == min(int((Sref > Sref[0] * 2.220446049250313e-16).sum()), 64)
     check_svd(ops, R.T.copy(), 64, 1e-16)
+
+
+# ------------------------------------------------------------------------------------------------ K7 builder
+@pytest.mark.parametrize('rot', [0, 1])
+def test_peps_factor_and_mpo_builder(ops, rot):
+    import tnac4o_amd
+    s = tnac4o_amd.tnac4o(mode='Ising', Nx=4, Ny=4, Nc=8, J=gi.droplet_J(128, 3), beta=3.0)
+    if rot:
+        s.rotate_graph(rot)
+    rng = np.random.default_rng(rot)
+    s.Xu, s.Xd = rng.uniform(0.5, 2, s.Xu.shape), rng.uniform(0.5, 2, s.Xd.shape)
+    s.Xl, s.Xr = rng.uniform(0.5, 2, s.Xl.shape), rng.uniform(0.5, 2, s.Xr.shape)
+    for ny in range(4):
+        for nx in range(4):
+            F, dmap, rmap, pd, br = s._peps_factor(ny, nx)                 # host twin
+            Fd, dm, rm, pd2, br2 = s._peps_factor_dev(ny, nx)
+            assert (pd, br) == (pd2, br2)
+            assert np.array_equal(host(dm.double()), dmap) and np.array_equal(host(rm.double()), rmap)
+            np.testing.assert_allclose(host(Fd), F, rtol=4e-16 * 8, atol=0)
+            np.testing.assert_allclose(host(s._mpo_site_dev(ny, nx)), s._mpo_site(ny, nx), rtol=1e-14, atol=0)
+    J = gi.minimal_rmf()
+    r = tnac4o_amd.tnac4o(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=2.0)
+    for ny in range(r.Ny):
+        for nx in range(r.Nx):
+            np.testing.assert_allclose(host(r._mpo_site_dev(ny, nx)), r._mpo_site(ny, nx), rtol=1e-14, atol=0)

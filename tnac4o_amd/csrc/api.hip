@@ -32,6 +32,9 @@ int calc_pn(hipStream_t, const double*, const double*, const double*, const int3
             const int32_t*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, double*,
             double*);
 int nfactor_batched(hipStream_t, double*, int64_t, int64_t);
+int peps_factor(hipStream_t, const double*, const double*, const double*, const double*, const double*, const double*, const double*,
+                const int32_t*, const int32_t*, int64_t, int64_t, int64_t, double*);
+int mpo_from_factor(hipStream_t, const double*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t, double*);
 
 }  // namespace tn
 
@@ -116,6 +119,17 @@ int tn_calc_pn(const double* T1, const double* RR, const double* F, const int32_
                int64_t nl, int64_t nu, int64_t p, int64_t Dr, int64_t br, double* P, double* minP, void* stream) {
     TN_CHECK_ARG(T1 && RR && F && dmap && rmap && pref && suf && lidx && uidx && P && minP, "null operand");
     return calc_pn(ST, T1, RR, F, dmap, rmap, pref, suf, lidx, uidx, nb, q, nl, nu, p, Dr, br, P, minP);
+}
+int tn_peps_factor(const double* Es, const double* E1, const double* E4, const double* Xu, const double* Xl, const double* Xr,
+                   const double* Xd, const int32_t* dmap, const int32_t* rmap, int64_t q, int64_t nl, int64_t nu, double* F,
+                   void* stream) {
+    TN_CHECK_ARG(Es && E1 && E4 && Xu && Xl && Xr && Xd && dmap && rmap && F, "null operand");
+    return peps_factor(ST, Es, E1, E4, Xu, Xl, Xr, Xd, dmap, rmap, q, nl, nu, F);
+}
+int tn_mpo_from_factor(const double* F, const int32_t* dmap, const int32_t* rmap, int64_t q, int64_t nl, int64_t nu, int64_t pd,
+                       int64_t br, double* W, void* stream) {
+    TN_CHECK_ARG(F && dmap && rmap && W, "null operand");
+    return mpo_from_factor(ST, F, dmap, rmap, q, nl, nu, pd, br, W);
 }
 int tn_nfactor_batched(double* x, int64_t batch, int64_t len, void* stream) {
     TN_CHECK_ARG(x, "null operand");

@@ -90,24 +90,33 @@ __global__ __launch_bounds__(256) void lu_reconstruct_kernel(double* __restrict_
         }
         __syncthreads();
     }
-    if (tid < b) {                               // column tid of U^-1 (back substitution)
-        const int j = tid;
-        Ui[j * P + j] = 1.0 / B[j * P + j];
-        for (int i = j - 1; i >= 0; --i) {
-            double s = 0.0;
-            for (int k = i + 1; k <= j; ++k) s += B[i * P + k] * Ui[k * P + j];
-            Ui[i * P + j] = -s / B[i * P + i];
-        }
-    } else if (tid >= 64 && tid < 64 + b) {      // column of L1^-1 (forward substitution), second wave
-        const int j = tid - 64;
-        Li[j * P + j] = 1.0;
-        for (int i = j + 1; i < b; ++i) {
-            double s = 0.0;
-            for (int k = j; k < i; ++k) s += B[i * P + k] * Li[k * P + j];
-            Li[i * P + j] = -s;
+    // U^-1 (rows from the bottom up) and L1^-1 (rows from the top down) by substitution, one row of each per iteration;
+    // column j is shared by 8 threads (k = h mod 8), whose partial sums meet in LDS: 2 barriers per row instead of a
+    // ~500-term dependent chain per column.
+    {
+        __shared__ double redU[8 * NB], redL[8 * NB];
+        const int j = tid & (NB - 1), h = tid / NB;            // NB = 32: 8 parts;  NB = 64: 4 parts
+        constexpr int NH = 256 / NB;
+        for (int it = 0; it < b; ++it) {
+            const int iu = b - 1 - it, il = it;
+            double su = 0.0, sl = 0.0;
+            if (j < b) {
+                for (int k = iu + 1 + h; k <= j; k += NH) su += B[iu * P + k] * Ui[k * P + j];      // needs j >= k > iu
+                for (int k = j + h; k < il; k += NH) sl += B[il * P + k] * Li[k * P + j];            // needs il > k >= j
+            }
+            redU[h * NB + j] = su;
+            redL[h * NB + j] = sl;
+            __syncthreads();
+            if (h == 0 && j < b) {
+                double tu = 0.0, tl = 0.0;
+#pragma unroll
+                for (int q = 0; q < NH; ++q) { tu += redU[q * NB + j]; tl += redL[q * NB + j]; }
+                if (j >= iu) Ui[iu * P + j] = ((j == iu ? 1.0 : 0.0) - tu) / B[iu * P + iu];
+                if (j <= il) Li[il * P + j] = (j == il) ? 1.0 : -tl;
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
     for (int e = tid; e < b * b; e += 256) {
         const int i = e / b, j = e % b;
         double t = 0.0;
@@ -139,51 +148,78 @@ __global__ __launch_bounds__(256) void diag_qr_kernel(const double* __restrict__
         Z[i * P + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
-    for (int j = 0; j < b; ++j) {
+    // Householder QR with all 256 threads: thread (c, g) = (tid % NB, tid / NB) owns rows g, g + NG, ... of column c.
+    // Per column one pass gives sum_{r>j} a_rj a_rc for every c (partials meet in LDS), from which the reflector and
+    // its action follow (same scheme as tsqr_factor_kernel); entries are first scaled to [0.5,1) by a power of two.
+    constexpr int NG = 256 / NB;
+    __shared__ double part[256];
+    __shared__ double dscale;
+    {
+        double m = 0.0;
+        for (int e = tid; e < b * b; e += 256) m = fmax(m, fabs(D[(e / b) * P + e % b]));
+        part[tid] = m;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) {
+            if (tid < k) part[tid] = fmax(part[tid], part[tid + k]);
+            __syncthreads();
+        }
         if (tid == 0) {
-            double sigma = 0.0, amax = 0.0;
-            for (int r = j + 1; r < b; ++r) amax = fmax(amax, fabs(D[r * P + j]));
-            const double alpha = D[j * P + j];
-            double t = 0.0;
-            if (amax > 0.0) {
-                // everything in units of sc, so that repeated cancellation (entries down to the subnormal range for
-                // exactly dependent columns) can neither overflow 1/(alpha - beta) nor underflow the norm
-                const double sc = fmax(amax, fabs(alpha));
-                for (int r = j + 1; r < b; ++r) { const double x = D[r * P + j] / sc; sigma += x * x; }
-                const double as = alpha / sc;
-                const double bs = -copysign(sqrt(as * as + sigma), as);
-                t = (bs - as) / bs;
-                const double invs = 1.0 / (as - bs);
-                for (int r = j + 1; r < b; ++r) D[r * P + j] = (D[r * P + j] / sc) * invs;
-                D[j * P + j] = bs * sc;
-            }
-            tau[j] = t;
+            int ex = 0;
+            if (part[0] > 0.0 && part[0] < 1.7e308) frexp(part[0], &ex);
+            dscale = ldexp(1.0, ex);
         }
         __syncthreads();
-        const double t = tau[j];
-        if (t != 0.0) {
-            for (int c = j + 1 + tid; c < b; c += 256) {
-                double w = D[j * P + c];
-                for (int r = j + 1; r < b; ++r) w += D[r * P + j] * D[r * P + c];
-                w *= t;
-                D[j * P + c] -= w;
-                for (int r = j + 1; r < b; ++r) D[r * P + c] -= D[r * P + j] * w;
+        const double scl = 1.0 / dscale;
+        for (int e = tid; e < b * b; e += 256) D[(e / b) * P + e % b] *= scl;
+        __syncthreads();
+    }
+    const int c = tid % NB, g = tid / NB;
+    for (int j = 0; j < b; ++j) {
+        double s = 0.0;
+        if (c < b)
+            for (int r = j + 1 + g; r < b; r += NG) s += D[r * P + j] * D[r * P + c];
+        part[tid] = s;
+        const double alpha = D[j * P + j], ajc = (c < b) ? D[j * P + c] : 0.0;
+        __syncthreads();
+        double sc = 0.0, sj = 0.0;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) { sc += part[k * NB + c]; sj += part[k * NB + j]; }
+        const double wj = alpha * alpha + sj;
+        double t = 0.0;
+        if (sj > 0.0 && wj > 1e-290) {                    // nothing below the diagonal -> H = I (like dlarfg)
+            const double rn = fast_rsqrt(wj), nrm = wj * rn;
+            const double beta = -copysign(nrm, alpha), d = alpha - beta, invd = fast_rcp(d);
+            t = 1.0 + fabs(alpha) * rn;
+            if (c > j && c < b) {
+                const double f = t * (ajc + sc * invd);
+                for (int r = j + 1 + g; r < b; r += NG) D[r * P + c] -= D[r * P + j] * invd * f;
+                if (g == 0) D[j * P + c] = ajc - f;
+            }
+            __syncthreads();                               // column j is still needed unscaled by the updates above
+            if (c == j) {
+                for (int r = j + 1 + g; r < b; r += NG) D[r * P + j] *= invd;
+                if (g == 0) D[j * P + j] = beta;
             }
         }
+        if (tid == 0) tau[j] = t;
         __syncthreads();
     }
     for (int j = b - 1; j >= 0; --j) {            // Z = H_0 ... H_{b-1}
         const double t = tau[j];
-        if (t != 0.0) {
-            for (int c = tid; c < b; c += 256) {
-                double w = Z[j * P + c];
-                for (int r = j + 1; r < b; ++r) w += D[r * P + j] * Z[r * P + c];
-                w *= t;
-                Z[j * P + c] -= w;
-                for (int r = j + 1; r < b; ++r) Z[r * P + c] -= D[r * P + j] * w;
-            }
+        if (t != 0.0) {                            // uniform
+            double s = 0.0;
+            if (c < b)
+                for (int r = j + g; r < b; r += NG) s += ((r == j) ? 1.0 : D[r * P + j]) * Z[r * P + c];
+            part[tid] = s;
+            __syncthreads();
+            double w = 0.0;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) w += part[k * NB + c];
+            w *= t;
+            if (c < b)
+                for (int r = j + g; r < b; r += NG) Z[r * P + c] -= ((r == j) ? 1.0 : D[r * P + j]) * w;
+            __syncthreads();
         }
-        __syncthreads();
     }
     double* zo = Zbuf + (int64_t)p * nb * nb;
     double* to = Tri + (int64_t)p * nb * nb;
@@ -191,7 +227,7 @@ __global__ __launch_bounds__(256) void diag_qr_kernel(const double* __restrict__
         const int i = e / b, j = e % b;
         const double sj = (D[j * P + j] < 0.0) ? -1.0 : 1.0, si = (D[i * P + i] < 0.0) ? -1.0 : 1.0;
         zo[i * nb + j] = Z[i * P + j] * sj;                  // column j of Z scaled
-        to[i * nb + j] = (i <= j) ? D[i * P + j] * si : 0.0; // row i of Tri scaled
+        to[i * nb + j] = (i <= j) ? D[i * P + j] * si * dscale : 0.0; // row i of Tri scaled (and un-normalised)
     }
 }
 

@@ -193,3 +193,23 @@ def calc_pn(T1, RR, F, dmap, rmap, pref, suf, lidx, uidx):
                            suf.data_ptr(), lidx.data_ptr(), uidx.data_ptr(), nb, q, nl, nu, p, Dr, br, P.data_ptr(),
                            mP.data_ptr(), _stream()))
     return P, mP
+
+
+def peps_factor(Es, E1, E4, Xu, Xl, Xr, Xd, dmap, rmap):
+    """F[s,l,u] on the device from the (beta-scaled, min-shifted) energy tables and gauge diagonals (tn_peps_factor)."""
+    q, nl = E1.shape
+    nu = E4.shape[1]
+    for t in (Es, E1, E4, Xu, Xl, Xr, Xd, dmap, rmap):
+        assert t.is_contiguous() and t.is_cuda
+    F = torch.empty((q, nl, nu), dtype=torch.float64, device=Es.device)
+    check(lib().tn_peps_factor(Es.data_ptr(), E1.data_ptr(), E4.data_ptr(), Xu.data_ptr(), Xl.data_ptr(), Xr.data_ptr(),
+                               Xd.data_ptr(), dmap.data_ptr(), rmap.data_ptr(), q, nl, nu, F.data_ptr(), _stream()))
+    return F
+
+
+def mpo_from_factor(F, dmap, rmap, pd, br):
+    """W[l,d,r,u] = sum over cell states of the PEPS factor (tn_mpo_from_factor)."""
+    q, nl, nu = F.shape
+    W = torch.empty((nl, pd, br, nu), dtype=torch.float64, device=F.device)
+    check(lib().tn_mpo_from_factor(F.data_ptr(), dmap.data_ptr(), rmap.data_ptr(), q, nl, nu, pd, br, W.data_ptr(), _stream()))
+    return W

@@ -257,8 +257,41 @@ class tnac4o:
         F = F * self.Xd[ny][nx][dmap][:, None, None]
         return F, np.asarray(dmap, dtype=np.int64), np.asarray(rmap, dtype=np.int64), int(pd), int(br)
 
+    def _site_tables(self, ny, nx):
+        """Host side of K7: the three beta-scaled, min-shifted energy tables and the index maps of a cell (O(q) work;
+        tnac4o.py:1570-1583, 1598-1607).  The exponentials, gauge products and the sum over s run on the GPU."""
+        b = self.beta
+        Es, E1, E4 = self._cell_energies(ny, nx)
+        Es, E1, E4 = b * (np.min(Es) - Es), b * (np.min(E1) - E1), b * (np.min(E4) - E4)
+        q = Es.shape[0]
+        if self.mode == 'Ising':
+            bt = _bits(self.sN[ny][nx])
+            rmap = bt[:, self.ir[ny][nx]] @ (2 ** np.arange(self.sr[ny][nx]))
+            dmap = bt[:, self.id[ny][nx]] @ (2 ** np.arange(self.sd[ny][nx]))
+            br, pd = 2 ** self.sr[ny][nx], 2 ** self.sd[ny][nx]
+        else:
+            s = np.arange(q)
+            br, pd = int(self.lr[ny, nx]), int(self.ld[ny, nx])
+            rmap = s % br if br > 1 else np.zeros(q, dtype=int)
+            dmap = s % pd if pd > 1 else np.zeros(q, dtype=int)
+        return Es, np.ascontiguousarray(E1), np.ascontiguousarray(E4), dmap, rmap, int(pd), int(br)
+
+    def _peps_factor_dev(self, ny, nx):
+        """(F, dmap, rmap, pd, br) as device tensors (K7, tn_peps_factor)."""
+        Es, E1, E4, dmap, rmap, pd, br = self._site_tables(ny, nx)
+        nl, nu = E1.shape[1], E4.shape[1]
+        dm, rm = _dev_i32(dmap), _dev_i32(rmap)
+        F = ops.peps_factor(_dev_f64(Es), _dev_f64(E1), _dev_f64(E4), _dev_f64(self.Xu[ny][nx][:nu]), _dev_f64(self.Xl[ny][nx][:nl]),
+                            _dev_f64(self.Xr[ny][nx]), _dev_f64(self.Xd[ny][nx]), dm, rm)
+        return F, dm, rm, pd, br
+
+    def _mpo_site_dev(self, ny, nx):
+        """Row-MPO site W[l,d,r,u] built on the device (K7, tn_mpo_from_factor)."""
+        F, dm, rm, pd, br = self._peps_factor_dev(ny, nx)
+        return ops.mpo_from_factor(F, dm, rm, pd, br)
+
     def _mpo_site(self, ny, nx):
-        """W[l,d,r,u] = sum_s T[s,l,d,r,u] (tnac4o.py:1686) as a host array."""
+        """W[l,d,r,u] = sum_s T[s,l,d,r,u] (tnac4o.py:1686) as a host array (host twin of _mpo_site_dev, used by tests)."""
         F, dmap, rmap, pd, br = self._peps_factor(ny, nx)
         q, nl, nu = F.shape
         W = np.zeros((pd, br, nl, nu))
@@ -268,7 +301,7 @@ class tnac4o:
     def _row_mpo(self, ny):
         At = mps.MPO(L=self.Nx)
         for nx in range(self.Nx):
-            At.set_direct(self._mpo_site(ny, nx), nx)
+            At.set_direct(self._mpo_site_dev(ny, nx), nx)
         return At
 
     # ------------------------------------------------------------------------------------ sweeps (GPU)
@@ -389,7 +422,7 @@ class tnac4o:
             _, pinv = _unique_rows(np.vstack([pkeys, keys[:, 1:]]))          # parent rows: match suffix[1:] to pkeys
             parent = pinv[len(pkeys):]
             # pkeys are sorted-unique, so their own inverse is the identity: parent indexes rows of prr directly
-            W = mps._t(self._mpo_site(ny, nx))                               # (bl, p, br, pu)
+            W = self._mpo_site_dev(ny, nx)                                   # (bl, p, br, pu)
             bl, p, br, pu = W.shape
             A = top.A[nx]
             Dl, _, Dr = A.shape
@@ -424,7 +457,7 @@ class tnac4o:
             RL = torch.ones((1, 1), dtype=torch.float64, device=dev)         # (nprefix, Dl)
             for nx in range(Nx):
                 q, nb = int(self.N[ny][nx]), prob.size
-                F, dmap, rmap, _, _ = self._peps_factor(ny, nx)
+                F, dmap, rmap, _, _ = self._peps_factor_dev(ny, nx)
                 AT = top.A[nx]
                 Dl, p, Dr = AT.shape
                 # every prefix's left environment through the top site in one GEMM: T1[prefix, d, chi']
@@ -434,8 +467,8 @@ class tnac4o:
                 skeys, RR = levels[Nx - nx - 1]
                 _, suf = _unique_rows(np.vstack([skeys, vind[:, nx + 2:]]))
                 suf = suf[len(skeys):]
-                P, mP = ops.calc_pn(T1, RR, _dev_f64(F), _dev_i32(dmap), _dev_i32(rmap), _dev_i32(pref), _dev_i32(suf),
-                                    _dev_i32(vind[:, nx]), _dev_i32(vind[:, nx + 1]))
+                P, mP = ops.calc_pn(T1, RR, F, dmap, rmap, _dev_i32(pref), _dev_i32(suf), _dev_i32(vind[:, nx]),
+                                    _dev_i32(vind[:, nx + 1]))
                 newprob = P.cpu().numpy()
                 minprob = float(mP.min().item())
                 if trace is not None:
