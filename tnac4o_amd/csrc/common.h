@@ -115,6 +115,7 @@ int small_t_times_vecs(hipStream_t st, const double* S, double* X, int64_t vs, i
 
 // ---- TSQR panel orthonormalisation (tsqr.hip) -------------------------------------------------------------------
 int64_t tsqr_ws_bytes(int64_t nrows, int b);
-int tsqr_orthonormalize(hipStream_t st, double* X, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws, int64_t ws_bytes);
+int tsqr_orthonormalize(hipStream_t st, const double* Xin, int64_t irs, int64_t ics, double* X, int64_t rs, int64_t cs,
+                        int64_t nrows, int b, void* ws, int64_t ws_bytes);
 
 }  // namespace tn

@@ -333,11 +333,11 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         const int b = (int)((k - j0 < nb) ? k - j0 : nb);
         const int64_t mp = m - j0, ntr = n - j0;
         Mat Ap = sub(Am, j0, j0), Yp = sub(Ym, j0, j0);
-        if ((rc = copy_mat(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b))) return rc;
         // --- panel orthonormalisation
         if (nb == 32) {
-            if ((rc = tsqr_orthonormalize(st, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes))) return rc;
+            if ((rc = tsqr_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes))) return rc;
         } else {
+            if ((rc = copy_mat(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b))) return rc;
             const int nchunk = gram_nchunk(mp);
             for (int it = 0; it < 5; ++it) {
                 if ((rc = gram_partial(st, Yp.p, ycs, yrs, mp, b, b, nullptr, 1, nchunk, w.part))) return rc;

@@ -46,29 +46,34 @@ __device__ __forceinline__ void block_rows(int64_t nrows, int nblk, int blk, int
     nr = (int)(base + (blk < rem ? 1 : 0));
 }
 
-// Thread (c, g) = (tid & 31, tid >> 5) keeps rows [32g, 32g+32) of column c of the block in REGISTERS for the whole
-// kernel; LDS only carries what must cross threads: the current column (vbuf), the current row (rowbuf) and the 8
-// partial sums per column (part).
+// Block layout of tsqr_factor_kernel: the first 32 rows of a block (the "head", where the triangle R and the pivots
+// live) stay in an LDS tile H; the remaining <= 224 rows (the "body") live in REGISTERS: thread (c, g) =
+// (tid & 31, tid >> 5) owns body rows 32 + 28 g ... 32 + 28 g + 27 of column c.  LDS carries only what crosses threads:
+// the head, the body of the current column (vbuf) and 8 partial sums per column (part).
 
-// Householder QR of one row block.  Per column j a single pass forms the Gram row w_c = sum_{r>=j} a_rj a_rc for all
-// c >= j; the reflector then follows without any further reduction:  beta = -sign(alpha) sqrt(w_j),
-// v = [1; a_j / (alpha - beta)],  tau = (beta - alpha)/beta = 1 + |alpha|/sqrt(w_j),
-// v^T a_c = a_jc + (w_c - alpha a_jc)/(alpha - beta)  (absolute error eps |a_jc|: column-wise backward stable).
-// Two barriers per column, no cross-lane shuffles.  The block is pre-scaled by a power of two so that squares neither
-// overflow nor lose entries above 1e-145 of the block maximum.
-__global__ __launch_bounds__(256) void tsqr_factor_kernel(double* __restrict__ X, int64_t rs, int64_t cs, int64_t nrows, int b,
-                                                          int nblk, double* __restrict__ taus, double* __restrict__ Rout) {
+// Householder QR of one row block.  Per column j a single pass forms  s_c = sum_{r>j} a_rj a_rc  for every c; the
+// reflector then follows without any further reduction:  beta = -sign(alpha) sqrt(alpha^2 + s_j),
+// v = [1; a_j / (alpha - beta)],  tau = 1 + |alpha| / sqrt(alpha^2 + s_j),  v^T a_c = a_jc + s_c / (alpha - beta)
+// (no cancellation: column-wise backward stable).  Two barriers per column, no cross-lane shuffles, no dynamic register
+// indexing.  The block is pre-scaled by a power of two so that squares neither overflow nor lose entries above 1e-145 of
+// the block maximum.  X (input) and Vout (reflectors + triangle, LAPACK layout) may be the same array.
+constexpr int TS_BODY = 28;
+
+__global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64_t rs, int64_t cs, double* Vout, int64_t ors,
+                                                          int64_t ocs, int64_t nrows, int b, int nblk,
+                                                          double* __restrict__ taus, double* __restrict__ Rout) {
     constexpr int P = 33;
-    __shared__ double T[TS_RB * P];          // staging for coalesced global loads / stores
+    __shared__ double T[TS_RB * P];          // staging for coalesced global loads / stores; rows 0..31 double as the head H
     __shared__ double part[256];
     __shared__ double vbuf[TS_RB];
-    __shared__ double rowbuf[32];
+    __shared__ double dinv[32];
     const int tid = threadIdx.x, blk = blockIdx.x;
     int64_t r0;
     int nr;
     block_rows(nrows, nblk, blk, r0, nr);
     const bool colfast = (cs == 1);
     for (int e = tid; e < TS_RB * P; e += 256) T[e] = 0.0;
+    if (tid < 32) dinv[tid] = 0.0;
     __syncthreads();
     double amax = 0.0;
     for (int e = tid; e < nr * b; e += 256) {
@@ -87,31 +92,40 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(double* __restrict__ X
     int ex = 0;
     if (amax > 0.0 && amax < 1.7e308) frexp(amax, &ex);
     const double scl = ldexp(1.0, -ex), iscl = ldexp(1.0, ex);
-    const int c = tid & 31, g = tid >> 5, rb = g * 32;
-    double y[32];
+    const int c = tid & 31, g = tid >> 5, rb = 32 + g * TS_BODY;
+    double y[TS_BODY];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) y[k] = T[(rb + k) * P + c] * scl;
+    for (int k = 0; k < TS_BODY; ++k) y[k] = T[(rb + k) * P + c] * scl;
+    __syncthreads();
+    for (int e = tid; e < 32 * P; e += 256) T[e] *= scl;          // the head stays in T (rows 0..31)
     const int kmax = b < nr ? b : nr;
-    // publish column 0 masked to the rows BELOW the diagonal, and row 0
     if (c == 0) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) vbuf[rb + k] = (rb + k > 0) ? y[k] : 0.0;
+        for (int k = 0; k < TS_BODY; ++k) vbuf[rb + k] = y[k];
     }
-    if (g == 0) rowbuf[c] = y[0];
     for (int j = 0; j < kmax; ++j) {
-        __syncthreads();                                    // column j / row j published, part[] free
-        double v[32];
+        __syncthreads();                                    // head updated, body of column j published, part[] free
+        double v[TS_BODY];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) v[k] = vbuf[rb + k];   // a_rj for r > j, 0 otherwise
-        const double alpha = rowbuf[j], ajc = rowbuf[c];
+        for (int k = 0; k < TS_BODY; ++k) v[k] = vbuf[rb + k];
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-        for (int k = 0; k < 32; k += 4) {
+        for (int k = 0; k < TS_BODY; k += 4) {
             s0 += v[k] * y[k]; s1 += v[k + 1] * y[k + 1]; s2 += v[k + 2] * y[k + 2]; s3 += v[k + 3] * y[k + 3];
         }
+        // head rows 4g .. 4g+3 (only those below the diagonal)
+        double hv[4], hy[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 4 * g + k;
+            hv[k] = (r > j) ? T[r * P + j] : 0.0;
+            hy[k] = T[r * P + c];
+            s0 += hv[k] * hy[k];
+        }
+        const double alpha = T[j * P + j], ajc = T[j * P + c];
         part[tid] = (s0 + s1) + (s2 + s3);
         __syncthreads();
-        double sc = 0.0, sj = 0.0;                          // sums over rows below the diagonal
+        double sc = 0.0, sj = 0.0;                          // sums over the rows below the diagonal
 #pragma unroll
         for (int k = 0; k < 8; ++k) { sc += part[k * 32 + c]; sj += part[k * 32 + j]; }
         const double wj = alpha * alpha + sj;
@@ -123,46 +137,45 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(double* __restrict__ X
             const double rn = fast_rsqrt(wj), nrm = wj * rn;
             const double beta = -copysign(nrm, alpha), d = alpha - beta, invd = fast_rcp(d);
             tau = 1.0 + fabs(alpha) * rn;
-            // v = [1; a_j/d]:  v^T a_c = a_jc + (sum_{r>j} a_rj a_rc)/d ;  column j itself: a_jj -> beta, i.e. f = d
-            const double f = (c > j) ? tau * (ajc + sc * invd) : (c == j ? d : 0.0);
-            const double gf = (c > j) ? invd * f : 0.0;
+            // column j itself: a_jj -> beta, everything below is kept unscaled (scaled by 1/d when written out)
+            const double f = (c > j) ? tau * (ajc + sc * invd) : 0.0;
+            const double gf = invd * f;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) y[k] = fma(-v[k], gf, y[k]);
-            if (g == (j >> 5)) {                            // the row-j element of every column c >= j
+            for (int k = 0; k < TS_BODY; ++k) y[k] = fma(-v[k], gf, y[k]);
+            if (c > j) {
 #pragma unroll
-                for (int k = 0; k < 32; ++k) y[k] = ((j & 31) == k) ? y[k] - f : y[k];
+                for (int k = 0; k < 4; ++k)
+                    if (4 * g + k > j) T[(4 * g + k) * P + c] = fma(-hv[k], gf, hy[k]);
+                if (g == 0) T[j * P + c] = ajc - f;
             }
-            if (c == j) {                                   // keep the reflector (below the diagonal) in the tile
-#pragma unroll
-                for (int k = 0; k < 32; ++k) T[(rb + k) * P + j] = v[k] * invd;
-            }
-        } else if (c == j) {
-#pragma unroll
-            for (int k = 0; k < 32; ++k) T[(rb + k) * P + j] = 0.0;
+            if (g == 0 && c == j) { T[j * P + j] = beta; dinv[j] = invd; }
         }
         if (tid == 0) taus[blk * 32 + j] = tau;
-        if (c == j + 1) {                                   // publish the next column and row (read after the barrier)
+        // every read of vbuf for this column happened before the barrier above, so the next column may be published now
+        if (c == j + 1) {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) vbuf[rb + k] = (rb + k > j + 1) ? y[k] : 0.0;
-        }
-        if (g == ((j + 1) >> 5)) {
-            double yr = y[0];
-#pragma unroll
-            for (int k = 1; k < 32; ++k) yr = (((j + 1) & 31) == k) ? y[k] : yr;
-            rowbuf[c] = yr;
+            for (int k = 0; k < TS_BODY; ++k) vbuf[rb + k] = y[k];
         }
     }
     for (int j = kmax + tid; j < 32; j += 256) taus[blk * 32 + j] = 0.0;
     __syncthreads();
-    // the tile now holds the reflectors below the diagonal (scale free); add the triangle with its power-of-two scale
-    // (columns >= kmax were never factored: their entries below the diagonal stay as they are)
+    // assemble the LAPACK-style tile: triangle (with its power-of-two scale) on and above the diagonal, reflectors
+    // a_rj / d_j below it (scale free); columns that were skipped (dinv = 0) get zero reflectors
+    {
+        const double dj = dinv[c];
 #pragma unroll
-    for (int k = 0; k < 32; ++k)
-        if (rb + k <= c || c >= kmax) T[(rb + k) * P + c] = y[k] * iscl;
+        for (int k = 0; k < TS_BODY; ++k) T[(rb + k) * P + c] = (c < kmax) ? y[k] * dj : y[k] * iscl;
+    }
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int i = e >> 5, j = e & 31;
+        const double x = T[i * P + j];
+        T[i * P + j] = (i <= j || j >= kmax) ? x * iscl : x * dinv[j];
+    }
     __syncthreads();
+    const bool ofast = (ocs == 1);
     for (int e = tid; e < nr * b; e += 256) {
-        const int i = colfast ? e / b : e % nr, j = colfast ? e % b : e / nr;
-        X[(r0 + i) * rs + j * cs] = T[i * P + j];
+        const int i = ofast ? e / b : e % nr, j = ofast ? e % b : e / nr;
+        Vout[(r0 + i) * ors + j * ocs] = T[i * P + j];
     }
     for (int e = tid; e < b * b; e += 256) {
         const int i = e / b, j = e % b;
@@ -248,9 +261,10 @@ int64_t tsqr_ws_bytes(int64_t nrows, int b) {
     return tot + 256;
 }
 
-// In place: the nrows x b panel X (strides rs, cs) is replaced by an orthonormal basis Q1 of its column space
+// The nrows x b panel Xin is read once; X (may be Xin) receives an orthonormal basis Q1 of its column space
 // (completed arbitrarily where the panel is rank deficient).
-int tsqr_orthonormalize(hipStream_t st, double* X, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws, int64_t ws_bytes) {
+int tsqr_orthonormalize(hipStream_t st, const double* Xin, int64_t irs, int64_t ics, double* X, int64_t rs, int64_t cs,
+                        int64_t nrows, int b, void* ws, int64_t ws_bytes) {
     TN_CHECK_ARG(b >= 1 && b <= 32, "panel width must be <= 32");
     TN_CHECK_ARG(nrows >= b, "panel must have at least b rows");
     TN_CHECK_ARG(ws_bytes >= tsqr_ws_bytes(nrows, b), "workspace too small");
@@ -267,7 +281,12 @@ int tsqr_orthonormalize(hipStream_t st, double* X, int64_t rs, int64_t cs, int64
         L.R = (double*)p; p += align_up((int64_t)L.nblk * b * b * 8, 256);
         L.Q = (double*)p; p += align_up(n * b * 8, 256);       // explicit Q of this level (level 0 writes into X)
         prof_begin(st, PROF_TSQR);
-        hipLaunchKernelGGL(tsqr_factor_kernel, dim3(L.nblk), dim3(256), 0, st, L.V, L.rs, L.cs, L.nrows, b, L.nblk, L.taus, L.R);
+        if (nl == 0)     // level 0 reads the caller's panel and writes its reflectors into X (fuses the panel copy)
+            hipLaunchKernelGGL(tsqr_factor_kernel, dim3(L.nblk), dim3(256), 0, st, Xin, irs, ics, L.V, L.rs, L.cs, L.nrows, b,
+                               L.nblk, L.taus, L.R);
+        else
+            hipLaunchKernelGGL(tsqr_factor_kernel, dim3(L.nblk), dim3(256), 0, st, (const double*)L.V, L.rs, L.cs, L.V, L.rs,
+                               L.cs, L.nrows, b, L.nblk, L.taus, L.R);
         TN_CHECK_LAUNCH("tsqr_factor_kernel");
         prof_end(st, PROF_TSQR, 2.0 * L.nrows * b * b, 16.0 * L.nrows * b);
         ++nl;
