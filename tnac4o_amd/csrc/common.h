@@ -78,6 +78,19 @@ int gemm(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const do
          int64_t batch = 1, int64_t bsa = 0, int64_t bsb = 0, int64_t bsc = 0, double* ws = nullptr,
          int64_t ws_bytes = 0);
 int64_t gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch);
+// Extended form: block-pair row indirection (see GemmP in gemm_f64.hip), forced split-K with the partial sums left in
+// ws as [(batch*splitk + s)][M][N] (raw_partials), per-batch skip flags.
+struct GemmExtra {
+    const int* pairs = nullptr;
+    const int* skip = nullptr;
+    int pw = 0, mapA = 0, mapB = 0, mapC = 0;
+    int force_splitk = 0;
+    bool raw_partials = false;
+    int* splitk_used = nullptr;
+};
+int gemm_ex(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
+            const double* B, int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc, int64_t batch,
+            int64_t bsa, int64_t bsb, int64_t bsc, double* ws, int64_t ws_bytes, const GemmExtra* x);
 
 static inline int gemm(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, Mat A, Mat B, double beta, Mat C,
                        double* ws = nullptr, int64_t ws_bytes = 0) {

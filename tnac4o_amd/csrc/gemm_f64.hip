@@ -28,6 +28,12 @@ struct GemmP {
     int64_t kchunk;     // K range per split (multiple of 16)
     double* ws;         // split-K partials [(batch*splitk+s)][M][N]
     int tiles_m, tiles_n;
+    // optional block-pair indirection (Jacobi SVD): a "vector index" v of batch z lives in physical row
+    //   pairs[2z + (v >= pw)] * pw + (v mod pw).  mapA: on A's row index; mapB: 1 on B's k index, 2 on B's column index;
+    //   mapC: on C's row index.  skip[z] == 0 -> the whole batch item is a no-op.
+    const int* pairs;
+    const int* skip;
+    int pw, mapA, mapB, mapC;
 };
 
 constexpr int BK = 16;
@@ -49,7 +55,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int tm0 = (bid / g.tiles_n) * BM, tn0 = (bid % g.tiles_n) * BN;
-    const int zb = blockIdx.z / g.splitk, zs = blockIdx.z % g.splitk;
+    const int nsk = g.splitk < 0 ? 1 : g.splitk;
+    const int zb = blockIdx.z / nsk, zs = blockIdx.z % nsk;
+    if (g.skip && g.skip[zb] == 0) return;
+    int blk0 = 0, blk1 = 0;
+    if (g.pairs) { blk0 = g.pairs[2 * zb]; blk1 = g.pairs[2 * zb + 1]; }
+    auto remap = [&](int64_t v) -> int64_t { return v < g.pw ? (int64_t)blk0 * g.pw + v : (int64_t)blk1 * g.pw + (v - g.pw); };
     const double* A = g.A + zb * g.bsa;
     const double* B = g.B + zb * g.bsb;
     const int64_t k_lo = zs * g.kchunk;
@@ -63,7 +74,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
             const int m = AKFAST ? idx / BK : idx % BM;
             const int k = AKFAST ? idx % BK : idx / BM;
             const int64_t gm = tm0 + m, gk = k0 + k;
-            ra[e] = (gm < g.M && gk < k_hi) ? A[gm * g.rsa + gk * g.csa] : 0.0;
+            ra[e] = (gm < g.M && gk < k_hi) ? A[(g.mapA ? remap(gm) : gm) * g.rsa + gk * g.csa] : 0.0;
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
@@ -71,7 +82,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
             const int n = BKFAST ? idx / BK : idx % BN;
             const int k = BKFAST ? idx % BK : idx / BN;
             const int64_t gn = tn0 + n, gk = k0 + k;
-            rb[e] = (gn < g.N && gk < k_hi) ? B[gk * g.rsb + gn * g.csb] : 0.0;
+            rb[e] = (gn < g.N && gk < k_hi) ? B[(g.mapB == 1 ? remap(gk) : gk) * g.rsb + (g.mapB == 2 ? remap(gn) : gn) * g.csb] : 0.0;
         }
     };
     auto store_tiles = [&]() {
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
         __syncthreads();
     }
 
-    if (g.splitk > 1) {
+    if (g.splitk > 1 || g.splitk < 0) {
         double* W = g.ws + (int64_t)blockIdx.z * g.M * g.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
                 for (int r = 0; r < 4; ++r) {
                     const int64_t row = tm0 + wm * WM + i * 16 + lk + 4 * r, col = tn0 + wn * WN + j * 16 + lr;
                     if (row < g.M && col < g.N) {
-                        double* c = C + row * g.rsc + col * g.csc;
+                        double* c = C + (g.mapC ? remap(row) : row) * g.rsc + col * g.csc;
                         double v = g.alpha * acc[i][j][r];
                         if (g.beta != 0.0) v += g.beta * *c;
                         *c = v;
@@ -200,20 +211,32 @@ int64_t gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch) {
 int gemm(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
          const double* B, int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc, int64_t batch,
          int64_t bsa, int64_t bsb, int64_t bsc, double* ws, int64_t ws_bytes) {
+    return gemm_ex(st, M, N, K, alpha, A, rsa, csa, B, rsb, csb, beta, C, rsc, csc, batch, bsa, bsb, bsc, ws, ws_bytes, nullptr);
+}
+
+int gemm_ex(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
+            const double* B, int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc, int64_t batch,
+            int64_t bsa, int64_t bsb, int64_t bsc, double* ws, int64_t ws_bytes, const GemmExtra* x) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     TN_CHECK_ARG(K >= 0, "negative K");
     GemmP g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
     g.rsa = rsa; g.csa = csa; g.rsb = rsb; g.csb = csb; g.rsc = rsc; g.csc = csc;
     g.bsa = bsa; g.bsb = bsb; g.bsc = bsc; g.alpha = alpha; g.beta = beta; g.ws = ws;
+    g.pairs = x ? x->pairs : nullptr; g.skip = x ? x->skip : nullptr;
+    g.pw = x ? x->pw : 0; g.mapA = x ? x->mapA : 0; g.mapB = x ? x->mapB : 0; g.mapC = x ? x->mapC : 0;
     int bm, bn;
     pick_tile(M, N, bm, bn);
     g.tiles_m = (int)cdiv(M, bm); g.tiles_n = (int)cdiv(N, bn);
-    int s = pick_splitk(M, N, K, batch);
+    int s = (x && x->force_splitk > 0) ? x->force_splitk : pick_splitk(M, N, K, batch);
     if (s > 1 && (ws == nullptr || ws_bytes < (int64_t)s * batch * M * N * 8)) s = 1;
+    const bool raw = x && x->raw_partials;
+    TN_CHECK_ARG(!raw || ws != nullptr, "raw partials need a workspace");
     g.splitk = s;
     g.kchunk = s > 1 ? align_up(cdiv(K, s), BK) : (K > 0 ? align_up(K, BK) : BK);
     if (s > 1) g.splitk = s = (int)cdiv(K, g.kchunk);
+    if (raw && s == 1) g.splitk = -1;          // single "partial": still written to ws (handled below)
+    if (x && x->splitk_used) *x->splitk_used = s;
     TN_CHECK_ARG(batch * s <= 65535, "batch*splitk exceeds grid.z");
     const bool ak = (csa == 1 && rsa != 1), bk = (rsb == 1 && csb != 1);
     dim3 grid(g.tiles_m * g.tiles_n, 1, (unsigned)(batch * s));
@@ -227,7 +250,7 @@ int gemm(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const do
     TN_CHECK_LAUNCH("gemm_kernel");
     // algorithmic work of SURVEY.md §8d: 2MNK flops, 8(MK + KN + MN) bytes
     prof_end(st, fam, 2.0 * M * N * K * batch, 8.0 * batch * ((double)M * K + (double)K * N + (double)M * N));
-    if (s > 1) {
+    if (s > 1 && !raw) {
         dim3 rg((unsigned)cdiv(M * N, 256), (unsigned)batch);
         prof_begin(st, PROF_SPLITK_REDUCE);
         hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, st, g);

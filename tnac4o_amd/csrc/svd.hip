@@ -186,11 +186,25 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     for (int outer = 0; outer < 40 && !converged; ++outer) {
         for (int r = 0; r < nr; ++r) {
             const int* pr = w.pairs + (int64_t)r * ng * 2;
-            if ((rc = gram_partial(st, w.X, L, 1, L, nvec, SVD_W, pr, ng, nchunk, w.part))) return rc;
-            if ((rc = eig_small(st, w.part, nchunk, nvec, ng, 2, inner_sweeps, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng))) return rc;
-            if ((rc = small_t_times_vecs(st, w.Js, w.X, L, 1, L, nvec, SVD_W, pr, ng, w.nrot))) return rc;
+            // Gram matrices of all block pairs on the matrix cores: G = Xp Xp^T, split over L with the partial sums left
+            // in w.part (eig_small adds them up); then X_pair <- J^T X_pair (and the same on P) as in-place GEMMs
+            GemmExtra xg;
+            int used = 1;
+            xg.pairs = pr; xg.pw = SVD_W; xg.mapA = 1; xg.mapB = 2; xg.force_splitk = nchunk; xg.raw_partials = true;
+            xg.splitk_used = &used;
+            if ((rc = gemm_ex(st, nvec, nvec, L, 1.0, w.X, L, 1, w.X, 1, L, 0.0, nullptr, 0, 0, ng, 0, 0, 0, w.part,
+                              (int64_t)ng * nchunk * nvec * nvec * 8, &xg)))
+                return rc;
+            if ((rc = eig_small(st, w.part, used, nvec, ng, 2, inner_sweeps, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng))) return rc;
+            GemmExtra xa;
+            xa.pairs = pr; xa.pw = SVD_W; xa.mapB = 1; xa.mapC = 1; xa.skip = w.nrot;
+            if ((rc = gemm_ex(st, nvec, L, nvec, 1.0, w.Js, 1, nvec, w.X, L, 1, 0.0, w.X, L, 1, ng, (int64_t)nvec * nvec, 0, 0,
+                              nullptr, 0, &xa)))
+                return rc;
             if (vectors)
-                if ((rc = small_t_times_vecs(st, w.Js, w.P, nv, 1, nv, nvec, SVD_W, pr, ng, w.nrot))) return rc;
+                if ((rc = gemm_ex(st, nvec, nv, nvec, 1.0, w.Js, 1, nvec, w.P, nv, 1, 0.0, w.P, nv, 1, ng, (int64_t)nvec * nvec, 0,
+                                  0, nullptr, 0, &xa)))
+                    return rc;
         }
         ++sweeps;
         if ((e = hipMemcpyAsync(hoff.data(), w.maxoff, hoff.size() * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy maxoff");
