@@ -6,7 +6,9 @@ MPO, absorb it into the boundary MPS and compress back to chi=64 with the defaul
 (graduate_truncation, tolS=1e-16, tolV=1e-10, max_sweeps=20).  Synthetic chimera couplings (seed 20260004,
 SURVEY.md §8d).  With N GPUs each rank sweeps its own lattice rotation (rank mod 4) of the same couplings — the
 reference's 4-rotation loop (examples/e06:97-109) sharded with no data-path collective ("weak" scaling);
-`value` = wall ms divided by the number of sweeps all ranks completed.
+`value` = wall ms divided by the number of sweeps all ranks completed.  On each GPU the G = 4 lattice rotations of one
+instance run interleaved on 4 HIP streams (the chains are latency-bound), so one step = G sweeps
+per rank; the latency of a single chain is reported as config.single_chain_sweep_latency_ms.
 
 Prints ONE JSON line on rank 0.  `roofline` describes the kernel family with the largest summed duration, timed
 with HIP events on its launch stream inside the timed region; `cpu_baseline` times the CPU oracle on a bounded
@@ -52,6 +54,8 @@ def main():
     ap.add_argument('--L', type=int, default=2048, choices=[128, 512, 2048])
     ap.add_argument('--chi', type=int, default=64)
     ap.add_argument('--cpu-rows', type=int, default=2, help='bottom rows timed on the CPU oracle (0 disables)')
+    ap.add_argument('--concurrent', type=int, default=4,
+                    help='independent sweeps (lattice rotations of one instance) interleaved per GPU, one stream each')
     ap.add_argument('--no-profile', action='store_true')
     args = ap.parse_args()
 
@@ -71,14 +75,15 @@ def main():
     lib = _lib.lib()
     n = {128: 4, 512: 8, 2048: 16}[args.L]
     seed = {128: 20260002, 512: 20260003, 2048: 20260004}[args.L]
-    J = synthetic_chimera(n, n, seed)
-    rot = rank % 4
+    from tnac4o_amd.parallel import run_concurrent
+    G = max(1, args.concurrent)
+    J = synthetic_chimera(n, n, seed + rank)                 # every rank sweeps its own instance (weak scaling)
     kw = dict(graduate_truncation=True, Dmax=args.chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
 
-    def make():
+    def make(rot):
         s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=J, beta=3.0)
-        if rot:
-            s.rotate_graph(rot)
+        if rot % 4:
+            s.rotate_graph(rot % 4)
         return s
 
     def barrier():
@@ -87,29 +92,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    solver = make()
-    # Warm-up sweeps run with events on EVERY kernel family (that costs ~10 % wall): they give the per-family table
-    # and identify the dominant family.  The timed sweeps then bracket only that family's launches with events, so the
-    # roofline duration is measured inside the timed region at negligible overhead (< 0.5 % of the wall time).
-    warm_prof = None
+    solvers = [make(g) for g in range(G)]
+    solver = solvers[0]
+
+    def step():                  # one step = G sweeps (the rotations of this rank's instance), interleaved on G streams
+        run_concurrent([(lambda s=s: s._setup_rhoT(**kw)) for s in solvers])
+
+    # Untimed phase.  (1) one single-chain sweep with events on every kernel family: sweep latency and the per-family
+    # table; (2) the W warm-up steps.  The timed steps then bracket only the dominant family's launches with events, so
+    # the roofline duration is measured inside the timed region at small overhead.
+    warm_prof, single_ms = None, None
     mask_all = (1 << len(FAMILIES)) - 1
-    if not args.no_profile:
+    if not args.no_profile and args.warmup > 0:
         lib.tn_profile_reset()
         lib.tn_profile_enable(mask_all)
-    for _ in range(args.warmup):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         solver._setup_rhoT(**kw)
-    dom_mask = mask_all
+        torch.cuda.synchronize()
+        single_ms = 1e3 * (time.perf_counter() - t0)
+        warm_prof = profile_totals(lib)
+        lib.tn_profile_enable(0)
+    for _ in range(args.warmup):
+        step()
     if not args.no_profile:
-        if args.warmup > 0:
-            torch.cuda.synchronize()
-            warm_prof = profile_totals(lib)
-            dom_mask = 1 << max(range(len(warm_prof)), key=lambda i: warm_prof[i]['ms'])
+        dom_mask = mask_all if warm_prof is None else 1 << max(range(len(warm_prof)), key=lambda i: warm_prof[i]['ms'])
         lib.tn_profile_reset()
         lib.tn_profile_enable(dom_mask)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        solver._setup_rhoT(**kw)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     prof = None
@@ -125,12 +138,15 @@ def main():
     if rank == 0:
         out = {
             'metric': 'PEPS-contraction ms/sweep, chimera L=%d chi=%d (boundary-MPS sweep _setup_rhoT)' % (args.L, args.chi),
-            'value': ms_per_step / world, 'unit': 'ms/sweep', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': ms_per_step / (world * G), 'unit': 'ms/sweep', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'chimera L=%d (Nx=Ny=%d, Nc=8) synthetic couplings seed %d, beta=3, chi=%d, one sweep = %d '
                                    'rows of MPO absorb + compress_mps' % (args.L, n, seed, args.chi, n),
-                       'sweeps_per_step_all_ranks': world, 'parallelism': 'rotation-per-rank x%d, no data-path collective' % world,
+                       'sweeps_per_step_all_ranks': world * G,
+                       'parallelism': '%d rank(s) x %d lattice rotations interleaved per GPU (one HIP stream each), one instance per '
+                                      'rank, no data-path collective' % (world, G),
+                       'single_chain_sweep_latency_ms': single_ms,
                        'rhoT_discarded_max': float(max(solver.rhoT_discarded)),
                        'rhoT_overlap_min': float(min(solver.rhoT_overlap)),
                        'bond_dims_mid_row': [int(d) for d in solver.rhoT[n // 2].D]},
@@ -147,15 +163,16 @@ def main():
                 ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9 if d['ms'] > 0 else 0.0
                 roof = {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS}
             roof.update({'traffic': None, 'kernel': d['kernel'], 'launches': d['calls'], 'avg_launch_ms': avg_ms,
-                         'share_of_wall': d['ms'] / (1e3 * dt) if dt > 0 else 0.0,
+                         'summed_duration_over_wall': d['ms'] / (1e3 * dt) if dt > 0 else 0.0,
                          'algorithmic_flops_per_launch': d['flops'] / max(1, d['calls']),
                          'algorithmic_bytes_per_launch': d['bytes'] / max(1, d['calls']),
                          'note': 'single-workgroup LDS-resident Jacobi step: latency-bound, far from either roofline'
                                  if d['kernel'].startswith('eig_small') or d['kernel'].startswith('tsqr') else ''})
             out['roofline'] = roof
             table = warm_prof if warm_prof is not None else prof
-            nsw = args.warmup if warm_prof is not None else args.steps
-            out['kernel_table_source'] = 'warm-up sweeps (events on all families)' if warm_prof is not None else 'timed sweeps'
+            nsw = 1 if warm_prof is not None else args.steps * G
+            out['kernel_table_source'] = ('one single-chain sweep before the timed region (events on all families)'
+                                          if warm_prof is not None else 'timed sweeps')
             out['kernel_time_ms_per_sweep'] = {p['kernel']: round(p['ms'] / nsw, 3) for p in table}
             out['kernel_launches_per_sweep'] = {p['kernel']: p['calls'] // nsw for p in table}
             gm = [p for i, p in enumerate(table) if i in MFMA_FAM and p['ms'] > 0]

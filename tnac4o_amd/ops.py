@@ -23,9 +23,10 @@ def _need_gpu(t):
 
 
 def workspace(nbytes, slot=0):
-    """A persistent per-device scratch buffer of at least nbytes (grown on demand)."""
+    """A persistent scratch buffer of at least nbytes (grown on demand), private to the (device, stream) pair so that
+    independent chains running on different streams never share scratch memory."""
     dev = torch.cuda.current_device()
-    key = (dev, slot)
+    key = (dev, torch.cuda.current_stream().cuda_stream, slot)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device='cuda')

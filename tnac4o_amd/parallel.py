@@ -9,6 +9,37 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+def run_concurrent(fns):
+    """Run independent chains concurrently on one GPU: each callable gets its own host thread and its own HIP stream
+    (one stream per rotation so that the latency-bound chains interleave on the device).  Returns the
+    list of results; the first exception raised by a chain is re-raised here."""
+    import threading
+    n = len(fns)
+    if n == 1:
+        return [fns[0]()]
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    out, err = [None] * n, [None] * n
+    cur = torch.cuda.current_stream()
+
+    def work(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                streams[i].wait_stream(cur)
+                out[i] = fns[i]()
+                streams[i].synchronize()
+        except BaseException as e:      # noqa: BLE001 - re-raised in the caller's thread
+            err[i] = e
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
 _HEAD = 6       # energy, degeneracy, log2 P, discarded log2 P, negative probability, rotation
 
 
@@ -25,9 +56,10 @@ def _pack(s, rot, ncell):
 
 
 def solve_rotations(make_solver, rotations=(0, 1, 2, 3), precondition=False, min_dEng=1e-12, group=None,
-                    **search_kwargs):
+                    concurrent=False, **search_kwargs):
     """Solve the same instance from several lattice rotations, sharded round-robin over the ranks of `group`.
 
+    concurrent=True runs the rotations assigned to this rank at the same time (threads + streams, GPU only).
     make_solver() -> a fresh solver exposing rotate_graph / precondition / search_ground_state and the result
     attributes of tnac4o.tnac4o.  Returns a dict (identical on every rank):
       energy (min over rotations), degeneracy (max over the rotations reaching that energy, e06:107-109),
@@ -40,15 +72,21 @@ def solve_rotations(make_solver, rotations=(0, 1, 2, 3), precondition=False, min
     slots = (len(rotations) + world - 1) // world
     mine = [r for i, r in enumerate(rotations) if i % world == rank]
     local, ncell = [], None
-    for rot in mine:
+
+    def one(rot):
         s = make_solver()
         if rot:
             s.rotate_graph(rot)
         if precondition:
             s.precondition(mode='balancing')
         s.search_ground_state(**search_kwargs)
-        ncell = s.states.shape[1]
-        local.append(_pack(s, rot, ncell))
+        return _pack(s, rot, s.states.shape[1])
+    if concurrent and len(mine) > 1:        # this rank's rotations interleave on the GPU, one stream each
+        local = run_concurrent([(lambda r=rot: one(r)) for rot in mine])
+    else:
+        local = [one(rot) for rot in mine]
+    if local:
+        ncell = len(local[0]) - _HEAD
     if ncell is None:                       # a rank without work still takes part in the gather
         probe = make_solver()
         ncell = probe.Nx * probe.Ny
