@@ -39,19 +39,19 @@ __global__ __launch_bounds__(256) void vec_norm2_kernel(const double* __restrict
 // X[i] <- M[live[i]] (zero rows beyond nvl); P[i] <- one-hot(live[i]) when P != nullptr
 __global__ __launch_bounds__(256) void svd_init_kernel(const double* __restrict__ M, int64_t vs, int64_t es, int64_t L,
                                                        int64_t nv, const int* __restrict__ live, int nvl,
-                                                       double* __restrict__ X, double* __restrict__ P) {
+                                                       double* __restrict__ X, double* __restrict__ P, int64_t pitch) {
     const int i = blockIdx.x, tid = threadIdx.x;
     const bool on = i < nvl;
     const int src = on ? live[i] : 0;
-    for (int64_t c = tid; c < L; c += 256) X[(int64_t)i * L + c] = on ? M[(int64_t)src * vs + c * es] : 0.0;
+    for (int64_t c = tid; c < L; c += 256) X[(int64_t)i * pitch + c] = on ? M[(int64_t)src * vs + c * es] : 0.0;
     if (P)
-        for (int64_t c = tid; c < nv; c += 256) P[(int64_t)i * nv + c] = (on && c == src) ? 1.0 : 0.0;
+        for (int64_t c = tid; c < nv; c += 256) P[(int64_t)i * pitch + c] = (on && c == src) ? 1.0 : 0.0;
 }
 
 // One block per kept vector j (source row order[j]):  left[:, j] = sgn * P[row, :],  right[j, :] = sgn * X[row, :] / S_j
 // with the reference's sign gauge: flip when in both vectors the most negative entry outweighs the most positive.
 __global__ __launch_bounds__(256) void svd_gather_kernel(const double* __restrict__ X, int64_t L, const double* __restrict__ P,
-                                                         int64_t nv, const int* __restrict__ order,
+                                                         int64_t nv, int64_t pitch, const int* __restrict__ order,
                                                          const double* __restrict__ Ssorted, double* __restrict__ left,
                                                          int64_t lrs, int64_t lcs, double* __restrict__ right, int64_t rrs,
                                                          int64_t rcs) {
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void svd_gather_kernel(const double* __restric
     __shared__ double sgn;
     const int j = blockIdx.x, tid = threadIdx.x;
     const int row = order[j];
-    const double* x = X + (int64_t)row * L;
-    const double* p = P + (int64_t)row * nv;
+    const double* x = X + (int64_t)row * pitch;
+    const double* p = P + (int64_t)row * pitch;
     double xmin = 0.0, xmax = 0.0, pmin = 0.0, pmax = 0.0;
     bool first = true;
     for (int64_t c = tid; c < L; c += 256) { const double t = x[c]; xmin = first ? t : fmin(xmin, t); xmax = first ? t : fmax(xmax, t); first = false; }
@@ -120,8 +120,10 @@ static int64_t svd_layout(int64_t nv, int64_t L, bool vectors, char* base, SvdWs
     const int nchunk = gram_nchunk(L);
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off += align_up(bytes, 256); return base ? base + o : nullptr; };
-    double* X = (double*)take(nvp * L * 8);
-    double* P = (double*)take(vectors ? nvp * nv * 8 : 8);
+    // X (nvp x L) and the accumulator P (nvp x nv) share rows of one (nvp x (L + nv)) array, so that one GEMM applies a
+    // round's rotations to both
+    double* X = (double*)take(nvp * (L + (vectors ? nv : 0)) * 8);
+    double* P = X + L;
     double* part = (double*)take(ng * nchunk * 4 * SVD_W * SVD_W * 8);
     double* Js = (double*)take(ng * 4 * SVD_W * SVD_W * 8);
     double* maxoff = (double*)take(nr * ng * 8);
@@ -166,8 +168,9 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     const int64_t nvp = align_up(nvl, 2 * SVD_W);
     const int nblk = (int)(nvp / SVD_W), ng = nblk / 2, nr = nblk - 1;
     if ((e = hipMemcpyAsync(w.live, live.data(), nvl * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy live");
+    const int64_t pitch = L + (vectors ? nv : 0);
     hipLaunchKernelGGL(svd_init_kernel, dim3((unsigned)nvp), dim3(256), 0, st, M, vs, es, L, nv, w.live, nvl, w.X,
-                       vectors ? w.P : nullptr);
+                       vectors ? w.P : nullptr, pitch);
     TN_CHECK_LAUNCH("svd_init_kernel");
     std::vector<int> pairs;
     round_robin(nblk, pairs);
@@ -192,19 +195,15 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
             int used = 1;
             xg.pairs = pr; xg.pw = SVD_W; xg.mapA = 1; xg.mapB = 2; xg.force_splitk = nchunk; xg.raw_partials = true;
             xg.splitk_used = &used;
-            if ((rc = gemm_ex(st, nvec, nvec, L, 1.0, w.X, L, 1, w.X, 1, L, 0.0, nullptr, 0, 0, ng, 0, 0, 0, w.part,
+            if ((rc = gemm_ex(st, nvec, nvec, L, 1.0, w.X, pitch, 1, w.X, 1, pitch, 0.0, nullptr, 0, 0, ng, 0, 0, 0, w.part,
                               (int64_t)ng * nchunk * nvec * nvec * 8, &xg)))
                 return rc;
             if ((rc = eig_small(st, w.part, used, nvec, ng, 2, inner_sweeps, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng))) return rc;
             GemmExtra xa;
             xa.pairs = pr; xa.pw = SVD_W; xa.mapB = 1; xa.mapC = 1; xa.skip = w.nrot;
-            if ((rc = gemm_ex(st, nvec, L, nvec, 1.0, w.Js, 1, nvec, w.X, L, 1, 0.0, w.X, L, 1, ng, (int64_t)nvec * nvec, 0, 0,
-                              nullptr, 0, &xa)))
+            if ((rc = gemm_ex(st, nvec, pitch, nvec, 1.0, w.Js, 1, nvec, w.X, pitch, 1, 0.0, w.X, pitch, 1, ng, (int64_t)nvec * nvec,
+                              0, 0, nullptr, 0, &xa)))                 // [X | P] <- J^T [X | P] in one launch
                 return rc;
-            if (vectors)
-                if ((rc = gemm_ex(st, nvec, nv, nvec, 1.0, w.Js, 1, nvec, w.P, nv, 1, 0.0, w.P, nv, 1, ng, (int64_t)nvec * nvec, 0,
-                                  0, nullptr, 0, &xa)))
-                    return rc;
         }
         ++sweeps;
         if ((e = hipMemcpyAsync(hoff.data(), w.maxoff, hoff.size() * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy maxoff");
@@ -215,7 +214,7 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     }
     if (sweeps_out) *sweeps_out = sweeps;
     if (info) *info = converged ? 0 : 1;
-    hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nvp), dim3(256), 0, st, w.X, L, 1, L, w.norms);
+    hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nvp), dim3(256), 0, st, w.X, pitch, 1, L, w.norms);
     TN_CHECK_LAUNCH("vec_norm2_kernel");
     std::vector<double> hs(nvp);
     if ((e = hipMemcpyAsync(hs.data(), w.norms, nvp * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy S");
@@ -262,11 +261,11 @@ int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t
     if ((e = hipMemcpyAsync(S, w.Ssorted, keep * 8, hipMemcpyDeviceToDevice, st)) != hipSuccess) return hip_fail(e, "copy S");
     // rows: left = U (k x keep), right = Vt.  columns (C^T was factored): left = Vt^T, right = U^T.
     if (rows)
-        hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, w.order, w.Ssorted, U,
-                           urs, ucs, Vt, vrs, vcs);
+        hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, w.order, w.Ssorted,
+                           U, urs, ucs, Vt, vrs, vcs);
     else
-        hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, w.order, w.Ssorted, Vt,
-                           vcs, vrs, U, ucs, urs);
+        hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, w.order, w.Ssorted,
+                           Vt, vcs, vrs, U, ucs, urs);
     TN_CHECK_LAUNCH("svd_gather_kernel");
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync gather");   // hS/hO go out of scope
     return 0;

@@ -15,7 +15,7 @@ def make(rot):
     return s
 make(0)._setup_rhoT(**dict(kw, Dmax=8))      # warm the library
 torch.cuda.synchronize()
-for G in (4, 8, 12):
+for G in (4, 8):
     solvers = [make(r % 4) for r in range(G)]
     streams = [torch.cuda.Stream() for _ in range(G)]
     res = [None] * G
