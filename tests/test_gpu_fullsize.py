@@ -1,0 +1,97 @@
+"""GPU property tests at the BASELINE.json sizes (chi = 64, b = p = 16, D' = 1024), where the CPU oracle would take
+minutes to hours: size-independent properties of each kernel and of the full sweep."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from tnac4o_amd import ops as o
+    return o
+
+
+def rnd(shape, seed, span=0.0):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    x = torch.randn(shape, dtype=torch.float64, device='cuda', generator=g)
+    if span:
+        x = x * torch.exp(-span * torch.rand(shape, dtype=torch.float64, device='cuda', generator=g))
+    return x
+
+
+def test_absorb_bulk_site_linearity_and_slices(ops):
+    """absorb is bilinear; checked at the bulk shape (64,16,64) x (16,16,16,16) -> (1024,16,1024), plus exact slices."""
+    A1, A2 = rnd((64, 16, 64), 1), rnd((64, 16, 64), 2)
+    W = rnd((16, 16, 16, 16), 3)
+    for hconj in (True, False):
+        T1, T2, T12 = ops.absorb(A1, W, hconj), ops.absorb(A2, W, hconj), ops.absorb(A1 + 2.0 * A2, W, hconj)
+        assert T12.shape == (1024, 16, 1024)
+        assert float((T12 - (T1 + 2.0 * T2)).abs().max()) < 1e-12
+        # one (left, right) bond slice against a dense contraction of that slice
+        dl, a, dr, b = 37, 5, 11, 9
+        if hconj:
+            ref = torch.einsum('o,oi->i', A1[dl, :, dr], W[a, :, b, :])
+            got = T1[dl * 16 + a, :, dr * 16 + b]
+        else:
+            ref = torch.einsum('oi,i->o', W[a, :, b, :], A1[dl, :, dr])
+            got = T1[a * 64 + dl, :, b * 64 + dr]
+        assert float((got - ref).abs().max()) < 1e-13
+
+
+@pytest.mark.parametrize('colmajor', [False, True])
+def test_qr_16384x1024_graded_lowrank(ops, colmajor):
+    """The pass-1 shape: 16384 x 1024, numerically rank ~200, entries spanning 60 orders of magnitude."""
+    m, n, r = 16384, 1024, 200
+    T = (rnd((m, r), 5, span=40.0) @ rnd((r, n), 6)) * torch.exp(-60.0 * torch.rand((1, n), dtype=torch.float64, device='cuda'))
+    view = T.t().contiguous().t() if colmajor else T
+    Q, R = ops.qr(view)
+    cn = torch.linalg.vector_norm(T, dim=0)
+    res = ops.mm(Q, R) - T
+    assert float((res.abs().max(dim=0).values / cn).max()) < 1e-13               # column-relative residual
+    G = ops.mm(Q.t(), Q)
+    assert float((G - torch.eye(n, dtype=torch.float64, device='cuda')).abs().max()) < 1e-13
+    assert float(torch.tril(R, -1).abs().max()) == 0.0 and bool((torch.diagonal(R) >= 0).all())
+
+
+def test_svd_1024_triangular_lowrank_truncation(ops):
+    """The pass-2 shape: SVD of a 1024 x 1024 triangular factor of a rank ~150 matrix, truncated to 4 chi = 256."""
+    A = rnd((4096, 150), 7) * (10.0 ** (-torch.arange(150, dtype=torch.float64, device='cuda') / 10.0))
+    A = A @ rnd((150, 1024), 8)
+    _, R = ops.qr(A)
+    U, S, Vt, keep, disc, info = ops.svd_trunc(R, 256, 1e-17)
+    assert info['info'] == 0 and 100 <= keep <= 160
+    Sref = torch.linalg.svdvals(R.cpu()).cuda()
+    assert float((S - Sref[:keep]).abs().max()) < 1e-13 * float(Sref[0])
+    I = torch.eye(keep, dtype=torch.float64, device='cuda')
+    assert float((ops.mm(U.t(), U) - I).abs().max()) < 1e-12 and float((ops.mm(Vt, Vt.t()) - I).abs().max()) < 1e-12
+    rec = ops.mm(U * S, Vt) - R
+    assert float(rec.abs().max()) < 1e-12 * float(Sref[0])
+    assert disc < 1e-14
+
+
+def test_sweep_L2048_chi64_properties():
+    """One full boundary sweep of the headline workload: every boundary MPS is left-canonical, the compression
+    overlaps are 1 to 1e-10, compressing again is idempotent, and bond dimensions respect chi."""
+    import tnac4o_amd
+    from tnac4o_amd import mps
+    from tnac4o_amd.auxx import synthetic_chimera
+    s = tnac4o_amd.tnac4o(mode='Ising', Nx=16, Ny=16, Nc=8, J=synthetic_chimera(16, 16, 20260004), beta=3.0)
+    s._setup_rhoT(graduate_truncation=True, Dmax=64, tolS=1e-16, tolV=1e-10, max_sweeps=20)
+    assert min(s.rhoT_overlap) > 1 - 1e-10 and max(s.rhoT_overlap) < 1 + 1e-10
+    assert max(s.rhoT_discarded) < 1e-8
+    for ny in (0, 5, 11):
+        psi = s.rhoT[ny]
+        assert max(psi.D) <= 64 and psi.D[0] == psi.D[-1] == 1
+        for A in psi.A:
+            M = A.reshape(-1, A.shape[2])
+            G = tnac4o_amd.ops.mm(M.t(), M)
+            assert float((G - torch.eye(M.shape[1], dtype=torch.float64, device='cuda')).abs().max()) < 1e-11
+    psi = s.rhoT[7].copy()
+    before = [a.clone() for a in psi.A]
+    ov = psi.compress_mps(Dmax=64, tolS=1e-16, tolV=1e-10, max_sweeps=20, graduate_truncation=True)
+    assert ov == pytest.approx(1.0, abs=1e-11)                       # idempotent: nothing left to truncate
+    phi = mps.MPS(d=psi.d, L=psi.L, Dmax=1, canonise=None)
+    phi.A = before
+    assert abs(mps.dot(phi, psi)) == pytest.approx(1.0, abs=1e-10)   # same state (both are normalised)

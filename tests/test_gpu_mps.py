@@ -208,6 +208,42 @@ def test_search_L2048_droplet_golden_energy():
     assert int(s.degeneracy) >= 1 and min(s.rhoT_overlap) > 1 - 1e-10
 
 
+def test_search_J124_degeneracy_golden():
+    """J124 C8 #1 (reference test_e06, examples/test_examples.py:139-147): energy -2309 and ground-state degeneracy
+    1152 from the reference's results file, with preconditioning, chi=8, M=4096, beta=0.75 — the degeneracy-counting
+    merge path of search_ground_state."""
+    import tnac4o_amd
+    want = g7()['J124_C8_i1_r0_chi8_pre1']
+    s = tnac4o_amd.tnac4o(mode='Ising', Nx=8, Ny=8, Nc=8, J=gi.j124_J(1), beta=0.75)
+    s.precondition(mode='balancing')
+    s.search_ground_state(M=2 ** 12, relative_P_cutoff=1e-8, Dmax=8)
+    assert s.energy[0] == pytest.approx(-2309.0, abs=1e-9) and s.energy[0] == pytest.approx(want['energy'], abs=1e-9)
+    assert int(s.degeneracy) == 1152 == want['degeneracy']
+    with open(os.path.join(gi.INST_DIR, 'C8_J124_results_1-5.txt')) as f:
+        line = f.readlines()[1].split()
+    assert float(line[1]) == -2309 and int(line[2]) == 1152
+    from tnac4o_amd import energy_Jij
+    assert energy_Jij(gi.j124_J(1), s.binary_states()[:1])[0] == pytest.approx(s.energy[0], abs=1e-9)
+
+
+def test_search_rmf_dense_path_vs_oracle():
+    """A larger Random Markov Field (8 x 8, d = 4, chi = 16): the dense non-chimera PEPS path of BASELINE config 5 at a
+    size the oracle finishes in seconds; GPU search vs the CPU oracle."""
+    import tnac4o_amd
+    from tnac4o_amd.auxx import synthetic_rmf, energy_RMF
+    J = synthetic_rmf(8, 8, 4, 20260005)
+    a = tnac4o_amd.tnac4o(mode='RMF', Nx=8, Ny=8, J=J, beta=1.0)
+    b = sr.RefSolver(mode='RMF', Nx=8, Ny=8, J=J, beta=1.0)
+    kw = dict(M=256, relative_P_cutoff=1e-8, Dmax=16)
+    a.search_ground_state(**kw)
+    b.search_ground_state(**kw)
+    assert a.energy[0] == pytest.approx(b.energy[0], abs=1e-10)
+    assert np.array_equal(a.states[0], b.states[0]) and int(a.degeneracy) == int(b.degeneracy)
+    assert a.probability[0] == pytest.approx(b.probability[0], abs=1e-8)
+    assert energy_RMF(J, a.states[:1])[0] == pytest.approx(a.energy[0], abs=1e-10)
+    np.testing.assert_allclose(np.array(a.rhoT_overlap, dtype=float), np.array(b.rhoT_overlap, dtype=float), atol=1e-10)
+
+
 def test_search_rmf():
     import tnac4o_amd
     J = gi.minimal_rmf()
