@@ -60,11 +60,15 @@ __global__ __launch_bounds__(256) void refill_dead_kernel(double* __restrict__ W
 // back in place with explicit zeros/ones), Uinv (b x b), T (b x b upper).
 template <int NB>
 __global__ __launch_bounds__(256) void lu_reconstruct_kernel(double* __restrict__ Ytop, int64_t rs, int64_t cs, int b,
-                                                             double* __restrict__ Uinv, double* __restrict__ T) {
+                                                             double* __restrict__ Uinv, double* __restrict__ T,
+                                                             double* __restrict__ UT, double* __restrict__ UTq,
+                                                             double* __restrict__ Wtop, int64_t wrs, int64_t wcs,
+                                                             double* __restrict__ Wqtop) {
     constexpr int P = NB + 1;
     __shared__ double B[NB * P];
     __shared__ double Li[NB * P];
     __shared__ double Ui[NB * P];
+    __shared__ double Tm[NB * P];
     __shared__ double sg[NB];
     const int tid = threadIdx.x;
     for (int e = tid; e < b * b; e += 256) {
@@ -125,8 +129,67 @@ __global__ __launch_bounds__(256) void lu_reconstruct_kernel(double* __restrict_
             t = -t;
         }
         T[e] = t;
+        Tm[i * P + j] = t;
+    }
+    __syncthreads();
+    // Products that fold T into the tall factors, so that the block reflector is applied with two GEMMs instead of three:
+    //   W  = Y T^T  (trailing update  A -= W (Y^T A)),   Wq = Y T  (Q accumulation  Q -= Wq (Y^T Q)),
+    // where Y = [Y1; Q1_below Uinv]:  rows below the top block use UT = Uinv T^T and UTq = Uinv T, the top block is done here.
+    for (int e = tid; e < b * b; e += 256) {
+        const int i = e / b, j = e % b;
+        double ut = 0.0, utq = 0.0;
+        for (int k = i; k < b; ++k) {                       // Uinv is upper triangular
+            const double u = Ui[i * P + k];
+            ut += u * Tm[j * P + k];
+            utq += u * Tm[k * P + j];
+        }
+        double wh = Tm[j * P + i], wqh = Tm[i * P + j];     // Y1 is unit lower triangular
+        for (int k = 0; k < i; ++k) {
+            const double l = B[i * P + k];
+            wh += l * Tm[j * P + k];
+            wqh += l * Tm[k * P + j];
+        }
         Uinv[e] = Ui[i * P + j];
+        UT[e] = ut;
+        UTq[e] = utq;
         Ytop[i * rs + j * cs] = (i > j) ? B[i * P + j] : (i == j ? 1.0 : 0.0);
+        Wtop[i * wrs + j * wcs] = wh;
+        Wqtop[i * rs + j * cs] = wqh;
+    }
+}
+
+// rows r < nrows:  x = X(r, :b);  X(r,:) <- x S0 (in place),  W1(r,:) <- x S1,  W2(r,:) <- x S2   (all b x b, row-major)
+template <int NB>
+__global__ __launch_bounds__(256) void rows_times_small3_kernel(double* __restrict__ X, int64_t rs, int64_t cs, int64_t nrows,
+                                                                int b, const double* __restrict__ S0, const double* __restrict__ S1,
+                                                                const double* __restrict__ S2, double* __restrict__ W1, int64_t w1rs,
+                                                                int64_t w1cs, double* __restrict__ W2) {
+    __shared__ double Ss[3][NB * NB];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        const bool in = (i < b && j < b);
+        Ss[0][e] = in ? S0[i * b + j] : 0.0;
+        Ss[1][e] = in ? S1[i * b + j] : 0.0;
+        Ss[2][e] = in ? S2[i * b + j] : 0.0;
+    }
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+    if (r >= nrows) return;
+    double x[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) x[i] = (i < b) ? X[r * rs + i * cs] : 0.0;
+    for (int j = 0; j < b; ++j) {
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            y0 += x[i] * Ss[0][i * NB + j];
+            y1 += x[i] * Ss[1][i * NB + j];
+            y2 += x[i] * Ss[2][i * NB + j];
+        }
+        X[r * rs + j * cs] = y0;
+        W1[r * w1rs + j * w1cs] = y1;
+        W2[r * rs + j * cs] = y2;
     }
 }
 
@@ -280,7 +343,8 @@ static void dbg_check(hipStream_t st, const double* p, int64_t rs, int64_t cs, i
 }
 
 struct QrWs {
-    double *Y, *T, *X, *X2, *part, *Js, *Uinv, *Z, *Tri, *gemm_ws;
+    double *Y, *Wq, *W, *UT, *UTq;
+    double *T, *X, *X2, *part, *Js, *Uinv, *Z, *Tri, *gemm_ws;
     int* dead;
     int64_t gemm_ws_bytes;
     void* tsqr_ws;
@@ -292,6 +356,10 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off += align_up(bytes, 256); return base ? base + o : nullptr; };
     double* Y = (double*)take(m * k * 8);
+    double* Wq = (double*)take(m * k * 8);            // Y T of every panel (Q accumulation)
+    double* Wp = (double*)take(m * nb * 8);           // Y T^T of the current panel (trailing update)
+    double* UT = (double*)take((int64_t)nb * nb * 8);
+    double* UTq = (double*)take((int64_t)nb * nb * 8);
     double* T = (double*)take(P * nb * nb * 8);
     double* X = (double*)take((int64_t)nb * (n > k ? n : k) * 8);
     double* X2 = (double*)take((int64_t)nb * (n > k ? n : k) * 8);
@@ -307,6 +375,7 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     const int64_t tsb = tsqr_ws_bytes(m, nb < 32 ? nb : 32);
     void* tsw = (void*)take(tsb);
     if (w) { w->tsqr_ws = tsw; w->tsqr_bytes = tsb; }
+    if (w) { w->Wq = Wq; w->W = Wp; w->UT = UT; w->UTq = UTq; }
     if (w) { w->Y = Y; w->T = T; w->X = X; w->X2 = X2; w->part = part; w->Js = Js; w->Uinv = Uinv; w->Z = Z; w->Tri = Tri;
              w->dead = dead; w->gemm_ws = gws; w->gemm_ws_bytes = gw; }
     return off;
@@ -326,7 +395,8 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
     // Y shares A's fast direction so panel kernels coalesce the same way
     const bool rowmajor = (cs == 1 && rs != 1);
     const int64_t yrs = rowmajor ? k : 1, ycs = rowmajor ? 1 : m;
-    Mat Am = mat(A, rs, cs), Ym = mat(w.Y, yrs, ycs);
+    const int64_t wrs = rowmajor ? nb : 1, wcs = rowmajor ? 1 : m;
+    Mat Am = mat(A, rs, cs), Ym = mat(w.Y, yrs, ycs), Wqm = mat(w.Wq, yrs, ycs);
     int rc;
     for (int p = 0; p < P; ++p) {
         const int64_t j0 = (int64_t)p * nb;
@@ -359,18 +429,32 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         }
         // --- Householder reconstruction
         double* Tp = w.T + (int64_t)p * nb * nb;
-        if (nb == 32) hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp);
-        else hipLaunchKernelGGL((lu_reconstruct_kernel<64>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp);
+        Mat Wqp = sub(Wqm, j0, j0), Wp = mat(w.W, wrs, wcs);
+        if (nb == 32)
+            hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT, w.UTq,
+                               Wp.p, wrs, wcs, Wqp.p);
+        else
+            hipLaunchKernelGGL((lu_reconstruct_kernel<64>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT, w.UTq,
+                               Wp.p, wrs, wcs, Wqp.p);
         TN_CHECK_LAUNCH("lu_reconstruct_kernel");
         dbg_check(st, Tp, b, 1, b, b, "T", p, 9);
         dbg_check(st, w.Uinv, b, 1, b, b, "Uinv", p, 9);
-        if (mp > b)
-            if ((rc = rows_times_small(st, sub(Yp, b, 0).p, yrs, ycs, mp - b, b, w.Uinv))) return rc;
-        // --- trailing update  A[j0:, j0:] -= Y (T^T (Y^T A[j0:, j0:]))
-        Mat Xm = mat(w.X, ntr, 1), X2m = mat(w.X2, ntr, 1), Tm = mat(Tp, b, 1);
+        if (mp > b) {            // rows below the top block: Y <- Q1 Uinv,  W <- Q1 (Uinv T^T),  Wq <- Q1 (Uinv T)
+            dim3 grid((unsigned)cdiv(mp - b, 256));
+            prof_begin(st, PROF_ROWS_SMALL);
+            if (nb == 32)
+                hipLaunchKernelGGL((rows_times_small3_kernel<32>), grid, dim3(256), 0, st, sub(Yp, b, 0).p, yrs, ycs, mp - b, b,
+                                   w.Uinv, w.UT, w.UTq, sub(Wp, b, 0).p, wrs, wcs, sub(Wqp, b, 0).p);
+            else
+                hipLaunchKernelGGL((rows_times_small3_kernel<64>), grid, dim3(256), 0, st, sub(Yp, b, 0).p, yrs, ycs, mp - b, b,
+                                   w.Uinv, w.UT, w.UTq, sub(Wp, b, 0).p, wrs, wcs, sub(Wqp, b, 0).p);
+            TN_CHECK_LAUNCH("rows_times_small3_kernel");
+            prof_end(st, PROF_ROWS_SMALL, 6.0 * (mp - b) * b * b, 32.0 * (mp - b) * b);
+        }
+        // --- trailing update  A[j0:, j0:] -= (Y T^T) (Y^T A[j0:, j0:])
+        Mat Xm = mat(w.X, ntr, 1);
         if ((rc = gemm(st, b, ntr, mp, 1.0, tr(Yp), Ap, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
-        if ((rc = gemm(st, b, ntr, b, 1.0, tr(Tm), Xm, 0.0, X2m))) return rc;
-        if ((rc = gemm(st, mp, ntr, b, -1.0, Yp, X2m, 1.0, Ap))) return rc;
+        if ((rc = gemm(st, mp, ntr, b, -1.0, Wp, Xm, 1.0, Ap))) return rc;
     }
     // --- triangularise the diagonal blocks, assemble R
     if (nb == 32) hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri);
@@ -391,11 +475,10 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         const int64_t j0 = (int64_t)p * nb;
         const int b = (int)((k - j0 < nb) ? k - j0 : nb);
         const int64_t mp = m - j0, nq = k - j0;
-        Mat Qp = sub(Qm, j0, j0), Yp = sub(Ym, j0, j0);
-        Mat Xm = mat(w.X, nq, 1), X2m = mat(w.X2, nq, 1), Tm = mat(w.T + (int64_t)p * nb * nb, b, 1);
-        if ((rc = gemm(st, b, nq, mp, 1.0, tr(Yp), Qp, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
-        if ((rc = gemm(st, b, nq, b, 1.0, Tm, Xm, 0.0, X2m))) return rc;
-        if ((rc = gemm(st, mp, nq, b, -1.0, Yp, X2m, 1.0, Qp))) return rc;
+        Mat Qp = sub(Qm, j0, j0), Yp = sub(Ym, j0, j0), Wqp = sub(Wqm, j0, j0);
+        Mat Xm = mat(w.X, nq, 1);
+        if ((rc = gemm(st, b, nq, mp, 1.0, tr(Yp), Qp, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;     // Y^T Q
+        if ((rc = gemm(st, mp, nq, b, -1.0, Wqp, Xm, 1.0, Qp))) return rc;                                  // Q -= (Y T) (Y^T Q)
     }
     return 0;
 }
