@@ -57,6 +57,7 @@ def main():
     ap.add_argument('--concurrent', type=int, default=4,
                     help='independent sweeps (lattice rotations of one instance) interleaved per GPU, one stream each')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-search', action='store_true', help='skip the (untimed) full search_ground_state figure')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -129,6 +130,18 @@ def main():
     if not args.no_profile:
         prof = profile_totals(lib)
         lib.tn_profile_enable(0)
+    # second headline, outside the timed region: one full search_ground_state (sweep + 256-site beam,
+    # M = 1024) of rotation 0 on a single chain
+    search_ms = None
+    if rank == 0 and not args.no_search:
+        sv = make(0)
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        sv.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=args.chi)
+        torch.cuda.synchronize()
+        search_ms = 1e3 * (time.perf_counter() - t0s)
+        search_info = {'ms': search_ms, 'energy': float(sv.energy[0]), 'degeneracy': int(sv.degeneracy),
+                       'log2_probability': float(sv.probability[0]), 'negative_probability': float(sv.negative_probability)}
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,6 +197,8 @@ def main():
             if ab['ms'] > 0:
                 out['absorb_hbm'] = {'achieved': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                      'frac': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        if search_ms is not None:
+            out['full_search_single_chain'] = search_info
         if args.cpu_rows > 0:
             out['cpu_baseline'] = cpu_baseline(J, n, args, solver, kw)
         print(json.dumps(out), flush=True)

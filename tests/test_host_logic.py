@@ -83,3 +83,39 @@ def test_synthetic_chimera_topology():
     assert sorted((i, j) for i, j, _ in J) == sorted((int(r[0]) - 1, int(r[1]) - 1) for r in ref)
     assert all(v != 0 and abs(round(v * 75) - v * 75) < 1e-9 for _, _, v in J)
     assert synthetic_chimera(4, 4, 20260003) == J
+
+
+def test_fast_unique_and_merge_match_reference_semantics():
+    """The packed-key unique and the vectorised merge reproduce np.unique(axis=0) and the reference's group loop
+    (tnac4o.py:481-509) exactly, including tie-breaking."""
+    import itertools
+    from tnac4o_amd.tnac4o import _unique_rows, _merge_groups
+    rng = np.random.default_rng(0)
+    for (n, w, hi) in [(5000, 17, 16), (3000, 5, 16), (2000, 9, 3), (1000, 1, 2), (4000, 17, 2), (1500, 20, 128)]:
+        vind = rng.integers(0, hi, (n, w)).astype(np.int8 if hi <= 127 else np.int16)
+        vind[rng.integers(0, n, n // 2)] = vind[rng.integers(0, n, n // 2)]          # plenty of duplicates
+        u0, i0 = np.unique(vind, return_inverse=True, axis=0)
+        u1, i1 = _unique_rows(vind)
+        assert np.array_equal(u0, u1) and np.array_equal(i0.reshape(-1), i1)
+        Eng = np.round(rng.standard_normal(n), 1)                                      # many exact ties
+        prob = rng.standard_normal(n)
+        deg = rng.integers(1, 5, n)
+        min_dEng = 1e-12
+        order = i1.argsort()
+        inv = i1[order]
+        sizes = [len(list(g)) for _, g in itertools.groupby(inv)]
+        indn, degn, probn = np.zeros(len(sizes), dtype=int), np.zeros(len(sizes), dtype=int), np.zeros(len(sizes))
+        lo = 0
+        for k, sz in enumerate(sizes):
+            ind = order[lo:lo + sz]
+            Ek = Eng[ind]
+            imin = np.argmin(Ek)
+            indn[k] = ind[imin]
+            same = ind[(Ek - Ek[imin]) <= min_dEng]
+            if len(same) > 1:
+                degn[k], probn[k] = sum(deg[same]), np.mean(prob[same])
+            else:
+                degn[k], probn[k] = deg[same][0], prob[same][0]
+            lo += sz
+        a, b, c = _merge_groups(i1, Eng, prob, deg, min_dEng)
+        assert np.array_equal(a, indn) and np.array_equal(b, degn) and np.array_equal(c, probn)

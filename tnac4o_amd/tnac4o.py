@@ -40,11 +40,57 @@ def _dev_i32(x):
 
 
 def _unique_rows(a):
-    """Sorted unique rows and the inverse map; handles zero-width keys."""
-    if a.shape[1] == 0:
-        return np.zeros((1, 0), dtype=a.dtype), np.zeros(a.shape[0], dtype=np.int64)
-    u, inv = np.unique(a, axis=0, return_inverse=True)
-    return u, inv.reshape(-1)
+    """Sorted unique rows and the inverse map — the same result as np.unique(a, axis=0, return_inverse=True)
+    (lexicographic row order) for non-negative integer rows, computed on packed 64-bit keys instead of a sort of
+    multi-byte records (30x faster for the 262144 x 17 candidate tables of a site-step).  Handles zero-width keys."""
+    n, w = a.shape
+    if w == 0:
+        return np.zeros((1, 0), dtype=a.dtype), np.zeros(n, dtype=np.int64)
+    if n == 0 or a.min() < 0:
+        u, inv = np.unique(a, axis=0, return_inverse=True)
+        return u, inv.reshape(-1)
+    bits = max(1, int(a.max()).bit_length())
+    inv, c0 = None, 0
+    while c0 < w:
+        # the rank of the prefix processed so far (order preserving) goes in the high bits, as many new columns as fit below
+        used = 0 if inv is None else max(1, int(inv.max()).bit_length())
+        ncol = max(1, min(w - c0, (63 - used) // bits))
+        key = np.zeros(n, dtype=np.uint64) if inv is None else inv.astype(np.uint64)
+        for j in range(c0, c0 + ncol):
+            key = (key << np.uint64(bits)) | a[:, j].astype(np.uint64)
+        _, inv = np.unique(key, return_inverse=True)
+        inv = inv.reshape(-1)
+        c0 += ncol
+    first = np.zeros(int(inv.max()) + 1, dtype=np.int64)
+    first[inv[::-1]] = np.arange(n - 1, -1, -1)      # any representative row of each group
+    return a[first], inv
+
+
+def _merge_groups(inv, Eng, prob, deg, min_dEng):
+    """The merge of branches with identical boundary indices (tnac4o.py:481-509), vectorised: per group the
+    representative is the first minimal-energy member in the order `inv.argsort()` (the reference's order), the
+    degeneracy is summed over members within min_dEng of the minimum and their log-probabilities are averaged."""
+    order = inv.argsort()
+    ginv = inv[order]
+    n_grp = int(ginv[-1]) + 1
+    starts = np.flatnonzero(np.r_[True, ginv[1:] != ginv[:-1]])
+    E = Eng[order]
+    Emin = np.minimum.reduceat(E, starts)
+    pos = np.arange(E.size)
+    is_min = E == Emin[ginv]
+    first_min = np.minimum.reduceat(np.where(is_min, pos, E.size), starts)
+    indn = order[first_min]
+    near = (E - Emin[ginv]) <= min_dEng
+    cnt = np.add.reduceat(near.astype(np.int64), starts)
+    degn = np.add.reduceat(np.where(near, deg[order], 0), starts)
+    probn = prob[indn].copy()
+    # single-member case: deg/prob of that member (== the representative); several: mean in the reference's summation order
+    for k in np.flatnonzero(cnt > 1):
+        lo = starts[k]
+        hi = starts[k + 1] if k + 1 < n_grp else E.size
+        same = order[lo:hi][near[lo:hi]]
+        probn[k] = np.mean(prob[same])
+    return indn, degn, probn
 
 
 class tnac4o:
@@ -499,29 +545,8 @@ class tnac4o:
                 Eng = Eng[inds]
                 Eng += self._update_Eng(states, ny, nx)
 
-                vindn, inv = np.unique(vind, return_inverse=True, axis=0)    # merge equal boundaries (:481-515)
-                inv = inv.reshape(-1)
-                order = inv.argsort()
-                inv = inv[order]
-                sizes = [len(list(g)) for _, g in itertools.groupby(inv)]
-                n_grp = len(sizes)
-                indn = np.zeros(n_grp, dtype=int)
-                degn = np.zeros(n_grp, dtype=int)
-                probn = np.zeros(n_grp)
-                lo = 0
-                for k, sz in enumerate(sizes):
-                    ind = order[lo:lo + sz]
-                    Ek = Eng[ind]
-                    imin = np.argmin(Ek)
-                    indn[k] = ind[imin]
-                    same = ind[(Ek - Ek[imin]) <= min_dEng]
-                    if len(same) > 1:
-                        degn[k] = sum(deg[same])
-                        probn[k] = np.mean(prob[same])
-                    else:
-                        degn[k] = deg[same][0]
-                        probn[k] = prob[same][0]
-                    lo += sz
+                vindn, inv = _unique_rows(vind)                              # merge equal boundaries (:481-515)
+                indn, degn, probn = _merge_groups(inv, Eng, prob, deg, min_dEng)
                 vind, prob, deg = vindn, probn, degn
                 states, Eng = states[indn], Eng[indn]
 
