@@ -43,9 +43,15 @@ int tn_absorb(const double* A, const double* W, double* out, int64_t Dl, int64_t
               int64_t po, int64_t bb, int64_t pi, int hconj, void* stream);
 
 /* ---- K3: economic QR, diag(R) >= 0.  Replaces mps.qr (mps.py:43-59) as used by _mps_decompose_AC/CA (:772-800).
- * A (m x n) is DESTROYED.  Q: m x min(m,n), R: min(m,n) x n.  nb in {32, 64} is the panel width. */
+ * A (m x n) is DESTROYED.  Q: m x min(m,n), R: min(m,n) x n.  nb in {32, 64} is the panel width.
+ * rank_tol = 0: the plain factorisation (asynchronous).  rank_tol > 0 (nb = 32, keff_host != NULL): early exit for the
+ * truncating canonisation passes — every second panel the largest column norm of the unfactored trailing block is read
+ * back; once it is <= rank_tol x the largest column norm of A the factorisation stops and *keff_host (HOST) receives
+ * the number of columns of Q / rows of R produced (A = Q[:, :keff] R[:keff, :] to rank_tol * max column norm).  With
+ * rank_tol = 2^-56 this drops exactly the rows the Jacobi SVD (tn_svd_trunc) would deflate.  Synchronises the stream
+ * at each check.  *keff_host = min(m, n) otherwise. */
 int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs, int64_t qcs, double* R,
-          int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, void* stream);
+          int64_t rrs, int64_t rcs, int nb, double rank_tol, int64_t* keff_host, void* ws, int64_t ws_bytes, void* stream);
 int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb);
 
 /* ---- K4: truncated SVD of a centre matrix.  Replaces mps.svd (mps.py:24-40, sign gauge included) +

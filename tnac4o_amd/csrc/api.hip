@@ -19,7 +19,7 @@ const char* get_error() { return g_err; }
 // implemented in the other translation units
 int absorb(hipStream_t, const double*, const double*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
 int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
-              void*, int64_t);
+              void*, int64_t, double, int64_t*);
 int64_t qr_ws_bytes(int64_t, int64_t, int);
 int svd_trunc(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double, double*, int64_t, int64_t, double*,
               double*, int64_t, int64_t, int64_t*, double*, int*, int*, void*, int64_t);
@@ -81,9 +81,10 @@ int tn_absorb(const double* A, const double* W, double* out, int64_t Dl, int64_t
 }
 
 int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs, int64_t qcs, double* R, int64_t rrs,
-          int64_t rcs, int nb, void* ws, int64_t ws_bytes, void* stream) {
+          int64_t rcs, int nb, double rank_tol, int64_t* keff_host, void* ws, int64_t ws_bytes, void* stream) {
     TN_CHECK_ARG(A && Q && R && ws, "null operand");
-    return qr_factor(ST, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes);
+    TN_CHECK_ARG(rank_tol >= 0.0 && rank_tol < 1.0, "rank_tol out of range");
+    return qr_factor(ST, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host);
 }
 int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_ws_bytes(m, n, nb); }
 

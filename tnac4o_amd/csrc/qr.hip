@@ -328,6 +328,23 @@ __global__ __launch_bounds__(256) void init_Q_kernel(double* __restrict__ Q, int
     Q[i * rs + j * cs] = v;
 }
 
+// max over columns of sum_i A(i,j)^2 for an (m x n) block -> atomicMax on the bit pattern in slot (pre-zeroed)
+__global__ __launch_bounds__(256) void colnorm2_max_kernel(const double* __restrict__ A, int64_t rs, int64_t cs, int64_t m,
+                                                           int64_t n, unsigned long long* __restrict__ slot) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int64_t j = blockIdx.x;
+    double s = 0.0;
+    for (int64_t i = tid; i < m; i += 256) { const double x = A[i * rs + j * cs]; s += x * x; }
+    red[tid] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) red[tid] += red[tid + k];
+        __syncthreads();
+    }
+    if (tid == 0) atomicMax(slot, (unsigned long long)__double_as_longlong(red[0]));
+}
+
 // ------------------------------------------------------------------------------------------ driver
 // TN_DEBUG=1: synchronise after each stage and report the first non-finite intermediate (diagnostics only)
 static bool dbg_on() { static int v = -1; if (v < 0) { const char* e = getenv("TN_DEBUG"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
@@ -383,18 +400,35 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
 
 int64_t qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_layout(m, n, nb, nullptr, nullptr); }
 
+// rank_tol > 0 enables the early exit: every second panel the largest column norm of the not-yet-factored trailing block
+// is compared with the largest column norm of the input; once it is below rank_tol times that, the remaining rows of R
+// would be negligible on the scale of the leading singular value and the factorisation stops with k_eff columns
+// (A = Q[:, :k_eff] R[:k_eff, :] to rank_tol * max column norm).  Used by the truncating canonisation passes, whose centre
+// matrix is SVD-truncated at eps * S0 right afterwards (the Jacobi SVD deflates rows below 2^-56 anyway); it needs one
+// 16-byte read-back per check.  *keff_host receives the number of columns/rows produced.
 int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
-              int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes) {
+              int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
+              int64_t* keff_host) {
     TN_CHECK_ARG(m >= 1 && n >= 1, "empty matrix");
     TN_CHECK_ARG(nb == 32 || nb == 64, "nb must be 32 or 64");
     TN_CHECK_ARG(ws_bytes >= qr_ws_bytes(m, n, nb), "workspace too small");
     QrWs w;
     qr_layout(m, n, nb, (char*)ws, &w);
-    const int64_t k = m < n ? m : n;
-    const int P = (int)cdiv(k, nb);
+    int64_t k = m < n ? m : n;
+    int P = (int)cdiv(k, nb);
+    const int64_t kfull = k;
+    unsigned long long* slots = (unsigned long long*)w.dead;         // 2 x 8 bytes of scratch (the nb=64 path's flags)
+    double scale2 = 0.0;
+    const bool reveal = rank_tol > 0.0 && keff_host != nullptr && P > 2 && nb == 32;
+    if (reveal) {
+        hipError_t e = hipMemsetAsync(slots, 0, 16, st);
+        if (e != hipSuccess) return hip_fail(e, "memset slots");
+        hipLaunchKernelGGL(colnorm2_max_kernel, dim3((unsigned)n), dim3(256), 0, st, A, rs, cs, m, n, slots);
+        TN_CHECK_LAUNCH("colnorm2_max_kernel");
+    }
     // Y shares A's fast direction so panel kernels coalesce the same way
     const bool rowmajor = (cs == 1 && rs != 1);
-    const int64_t yrs = rowmajor ? k : 1, ycs = rowmajor ? 1 : m;
+    const int64_t yrs = rowmajor ? kfull : 1, ycs = rowmajor ? 1 : m;
     const int64_t wrs = rowmajor ? nb : 1, wcs = rowmajor ? 1 : m;
     Mat Am = mat(A, rs, cs), Ym = mat(w.Y, yrs, ycs), Wqm = mat(w.Wq, yrs, ycs);
     int rc;
@@ -455,7 +489,25 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         Mat Xm = mat(w.X, ntr, 1);
         if ((rc = gemm(st, b, ntr, mp, 1.0, tr(Yp), Ap, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
         if ((rc = gemm(st, mp, ntr, b, -1.0, Wp, Xm, 1.0, Ap))) return rc;
+        if (reveal && (p & 1) == 1 && p + 1 < P) {
+            const int64_t j1 = j0 + b;
+            hipError_t e = hipMemsetAsync(slots + 1, 0, 8, st);
+            if (e != hipSuccess) return hip_fail(e, "memset slot");
+            hipLaunchKernelGGL(colnorm2_max_kernel, dim3((unsigned)(n - j1)), dim3(256), 0, st, sub(Am, j1, j1).p, rs, cs, m - j1,
+                               n - j1, slots + 1);
+            TN_CHECK_LAUNCH("colnorm2_max_kernel");
+            double h[2];
+            if ((e = hipMemcpyAsync(h, slots, 16, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy norms");
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync norms");
+            scale2 = h[0];
+            if (h[1] <= rank_tol * rank_tol * scale2) {       // nothing left above the threshold: stop here
+                k = j1;
+                P = p + 1;
+                break;
+            }
+        }
     }
+    if (keff_host) *keff_host = k;
     // --- triangularise the diagonal blocks, assemble R
     if (nb == 32) hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri);
     else hipLaunchKernelGGL((diag_qr_kernel<64>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri);

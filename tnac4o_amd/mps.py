@@ -180,11 +180,17 @@ class MPS:
         Dl, p, Dr = self.A[n].shape
         self.A[n] = ops.mm(self.C, self.A[n].view(Dl, p * Dr)).view(self.C.shape[0], p, Dr)
 
-    def orth_left(self, n):
-        """A[n] -> Q, C = R / nfactor(R) with QR of the (Dl p, Dr) matrix (mps.py:532-539, 772-785)."""
+    def orth_left(self, n, rank_tol=0.0):
+        """A[n] -> Q, C = R / nfactor(R) with QR of the (Dl p, Dr) matrix (mps.py:532-539, 772-785).
+        rank_tol > 0 (truncating passes only): tn_qr stops once the rest of R is below rank_tol of its scale, so the new
+        bond may be smaller than min(Dl p, Dr) — the rows dropped are the ones truncateC's SVD deflates anyway."""
         Dl, p, Dr = self.A[n].shape
-        Q, R = ops.qr(self.A[n].view(Dl * p, Dr), overwrite=True)
-        k = R.shape[0]
+        kf = min(Dl * p, Dr)
+        Q = torch.empty((Dl * p, kf), dtype=torch.float64, device=self.A[n].device)
+        R = torch.empty((kf, Dr), dtype=torch.float64, device=self.A[n].device)
+        _, _, k = ops.qr_into(self.A[n].view(Dl * p, Dr), Q, R, overwrite=True, rank_tol=rank_tol)
+        if k < kf:
+            Q, R = Q[:, :k].contiguous(), R[:k].contiguous()
         self._nfs.append(ops.normalize_pow2_(R))
         if R.shape == (1, 1):            # mps.py:778-780 (diag(R) >= 0, so sign(C) = 1): the norm is dropped
             R = torch.ones_like(R)
@@ -193,14 +199,16 @@ class MPS:
         self.D[n + 1] = k
         self.pC = n + 1
 
-    def orth_right(self, n):
-        """A[n] -> C Q with QR of the transposed (p Dr, Dl) view (mps.py:541-548, 787-800)."""
+    def orth_right(self, n, rank_tol=0.0):
+        """A[n] -> C Q with QR of the transposed (p Dr, Dl) view (mps.py:541-548, 787-800); rank_tol as in orth_left."""
         Dl, p, Dr = self.A[n].shape
-        k = min(p * Dr, Dl)
+        kf = min(p * Dr, Dl)
         dev = self.A[n].device
-        Qt = torch.empty((k, p * Dr), dtype=torch.float64, device=dev)      # Q^T, i.e. the new right-canonical site
-        Ct = torch.empty((Dl, k), dtype=torch.float64, device=dev)          # R^T
-        ops.qr_into(self.A[n].view(Dl, p * Dr).t(), Qt.t(), Ct.t(), overwrite=True)
+        Qt = torch.empty((kf, p * Dr), dtype=torch.float64, device=dev)     # Q^T, i.e. the new right-canonical site
+        Ct = torch.empty((Dl, kf), dtype=torch.float64, device=dev)         # R^T
+        _, _, k = ops.qr_into(self.A[n].view(Dl, p * Dr).t(), Qt.t(), Ct.t(), overwrite=True, rank_tol=rank_tol)
+        if k < kf:
+            Qt, Ct = Qt[:k].contiguous(), Ct[:, :k].contiguous()
         self._nfs.append(ops.normalize_pow2_(Ct))
         if Ct.shape == (1, 1):
             Ct = torch.ones_like(Ct)
@@ -233,7 +241,9 @@ class MPS:
         self.pC = 0
         for n in range(self.L):
             self.attach_CA()
-            self.orth_left(n)
+            # truncating pass: left part canonical, right part canonical -> the scale of C is the Schmidt scale, so rows of
+            # R below 2^-56 of it can be skipped already in the QR (they are deflated by the SVD of truncateC)
+            self.orth_left(n, rank_tol=ops.RANK_TOL if (compress and 0 < n + 1 < self.L) else 0.0)
             if compress:
                 self.truncateC(Dmax, tol)
         self.R[-1] = None
@@ -244,7 +254,7 @@ class MPS:
         self.pC = self.L
         for n in range(self.L - 1, -1, -1):
             self.attach_AC()
-            self.orth_right(n)
+            self.orth_right(n, rank_tol=ops.RANK_TOL if (compress and 0 < n < self.L) else 0.0)
             if compress:
                 self.truncateC(Dmax, tol)
         self.R[-1] = None

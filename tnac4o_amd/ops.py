@@ -84,8 +84,13 @@ def absorb(A, W, hconj):
     return out
 
 
-def qr_into(T, Q, R, overwrite=False, nb=None):
-    """Economic QR of the 2-D view T into the (strided) views Q (m x k) and R (k x n); diag(R) >= 0."""
+RANK_TOL = 2.0 ** -56         # the deflation threshold of the Jacobi SVD (svd.hip)
+
+
+def qr_into(T, Q, R, overwrite=False, nb=None, rank_tol=0.0):
+    """Economic QR of the 2-D view T into the (strided) views Q (m x k) and R (k x n); diag(R) >= 0.
+    rank_tol > 0 enables the early exit of tn_qr; the number of columns produced is returned as third value
+    (use Q[:, :keff], R[:keff])."""
     _need_gpu(T)
     m, n = T.shape
     if not overwrite:
@@ -94,9 +99,10 @@ def qr_into(T, Q, R, overwrite=False, nb=None):
     L = lib()
     wsb = L.tn_qr_ws_bytes(m, n, nb)
     ws = workspace(wsb, 0)
+    keff = C.c_int64(min(m, n))
     check(L.tn_qr(T.data_ptr(), T.stride(0), T.stride(1), m, n, Q.data_ptr(), Q.stride(0), Q.stride(1), R.data_ptr(),
-                  R.stride(0), R.stride(1), nb, ws.data_ptr(), wsb, _stream()))
-    return Q, R
+                  R.stride(0), R.stride(1), nb, float(rank_tol), C.byref(keff), ws.data_ptr(), wsb, _stream()))
+    return Q, R, int(keff.value)
 
 
 def qr(T, overwrite=False, nb=None):
@@ -104,7 +110,8 @@ def qr(T, overwrite=False, nb=None):
     k = min(m, n)
     Q = torch.empty((m, k), dtype=torch.float64, device=T.device)
     R = torch.empty((k, n), dtype=torch.float64, device=T.device)
-    return qr_into(T, Q, R, overwrite, nb)
+    qr_into(T, Q, R, overwrite, nb)
+    return Q, R
 
 
 def svd_trunc(Cm, Dmax, tol):
