@@ -31,19 +31,55 @@ import torch         # noqa: E402
 
 FAMILIES = ['gemm_kernel<128,128>', 'gemm_kernel<128,32>', 'gemm_kernel<32,128>', 'gemm_kernel<64,64>',
             'splitk_reduce_kernel', 'absorb_kernel', 'gram_partial_kernel', 'eig_small_kernel',
-            'rows_times_small_kernel', 'small_t_times_vecs_kernel', 'tsqr_factor/apply_kernel']
+            'rows_times_small_kernel', 'small_t_times_vecs_kernel', 'tsqr_factor/apply_kernel',
+            'lu_reconstruct_kernel', 'qr_aux (diag_qr, assemble_R, init_Q, norms, copies)',
+            'svd_aux (norms, init, gather)', 'misc (nfactor, scaling, builders)']
+COUNTERS = {'qr_nominal': 15, 'svd_nominal': 16, 'svd_stream': 17, 'svdvals_nominal': 18}   # counter-only families
+PHASES = ['gemm_var (attach / projector / environment GEMMs, scaling)', 'absorb', 'qr', 'svd_trunc', 'svdvals', 'mpo_build']
 MFMA_FAM = {0, 1, 2, 3}
 PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X fp64 matrix peak (vendor figure quoted in SURVEY.md §7; not in the microarch guide)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def profile_totals(lib):
-    out = []
-    for f in range(len(FAMILIES)):
-        calls, ms, fl, by = C.c_uint64(0), C.c_double(0), C.c_double(0), C.c_double(0)
-        lib.tn_profile_get(f, C.byref(calls), C.byref(ms), C.byref(fl), C.byref(by))
-        out.append(dict(kernel=FAMILIES[f], calls=int(calls.value), ms=ms.value, flops=fl.value, bytes=by.value))
-    return out
+def _get(lib, phase, f):
+    calls, ms, fl, by = C.c_uint64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    lib.tn_profile_get_phase(phase, f, C.byref(calls), C.byref(ms), C.byref(fl), C.byref(by))
+    return dict(calls=int(calls.value), ms=ms.value, flops=fl.value, bytes=by.value)
+
+
+def profile_totals(lib, phase=-1):
+    return [dict(kernel=FAMILIES[f], **_get(lib, phase, f)) for f in range(len(FAMILIES))]
+
+
+def phase_report(lib):
+    """Sub-timers of SURVEY.md §8(d): summed kernel durations of one single-chain sweep split by the entry point that
+    issued the launch, plus the three SVD-step roofline figures and the nominal QR rate."""
+    rep = {}
+    for ph, name in enumerate(PHASES):
+        t = profile_totals(lib, ph)
+        rep[name] = {'kernel_ms': round(sum(x['ms'] for x in t), 3), 'launches': sum(x['calls'] for x in t)}
+    qr, svd, stream, sv = (_get(lib, -1, COUNTERS[k]) for k in ('qr_nominal', 'svd_nominal', 'svd_stream', 'svdvals_nominal'))
+    t_qr = rep['qr']['kernel_ms'] * 1e-3
+    t_svd = rep['svd_trunc']['kernel_ms'] * 1e-3
+    if t_qr > 0:
+        rep['qr'].update({'calls': qr['calls'], 'nominal_tflops': qr['flops'] / t_qr / 1e12,
+                          'frac_of_f64_mfma_peak': qr['flops'] / t_qr / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                          'compulsory_GBps': qr['bytes'] / t_qr / 1e9})
+    if t_svd > 0:
+        rep['svd_trunc'].update({
+            'calls': svd['calls'], 'executed_sweeps': stream['calls'],
+            'nominal_tflops': svd['flops'] / t_svd / 1e12,
+            'hbm_primary_compulsory_GBps': svd['bytes'] / t_svd / 1e9,
+            'hbm_primary_frac': svd['bytes'] / t_svd / 1e9 / PEAK_HBM_GBS,
+            'hbm_secondary_jacobi_streaming_model_GBps': stream['bytes'] / t_svd / 1e9,
+            'hbm_secondary_frac': stream['bytes'] / t_svd / 1e9 / PEAK_HBM_GBS,
+            'hbm_tertiary_pmc': None,
+            'note': 'block Jacobi (32-wide blocks): the pair Gram/apply are MFMA GEMMs on L2/Infinity-Cache-resident data, '
+                    'so the streaming model of a column-pair Jacobi overstates the bytes actually moved; the step is '
+                    'latency-bound (eig_small), not HBM-bound'})
+    if sv['calls']:
+        rep['svdvals'].update({'calls': sv['calls']})
+    return rep
 
 
 def main():
@@ -57,6 +93,8 @@ def main():
     ap.add_argument('--concurrent', type=int, default=4,
                     help='independent sweeps (lattice rotations of one instance) interleaved per GPU, one stream each')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--sample', type=int, default=8,
+                    help='in the timed region bracket every n-th launch of the dominant kernel family with events')
     ap.add_argument('--no-search', action='store_true', help='skip the (untimed) full search_ground_state figure')
     args = ap.parse_args()
 
@@ -104,6 +142,7 @@ def main():
     # the roofline duration is measured inside the timed region at small overhead.
     warm_prof, single_ms = None, None
     mask_all = (1 << len(FAMILIES)) - 1
+    phases = None
     if not args.no_profile and args.warmup > 0:
         lib.tn_profile_reset()
         lib.tn_profile_enable(mask_all)
@@ -113,12 +152,14 @@ def main():
         torch.cuda.synchronize()
         single_ms = 1e3 * (time.perf_counter() - t0)
         warm_prof = profile_totals(lib)
+        phases = phase_report(lib)
         lib.tn_profile_enable(0)
     for _ in range(args.warmup):
         step()
     if not args.no_profile:
         dom_mask = mask_all if warm_prof is None else 1 << max(range(len(warm_prof)), key=lambda i: warm_prof[i]['ms'])
         lib.tn_profile_reset()
+        lib.tn_profile_sample(max(1, args.sample))
         lib.tn_profile_enable(dom_mask)
     barrier()
     t0 = time.perf_counter()
@@ -130,6 +171,7 @@ def main():
     if not args.no_profile:
         prof = profile_totals(lib)
         lib.tn_profile_enable(0)
+        lib.tn_profile_sample(1)
     # second headline, outside the timed region: one full search_ground_state (sweep + 256-site beam,
     # M = 1024) of rotation 0 on a single chain
     search_ms = None
@@ -175,8 +217,10 @@ def main():
             else:
                 ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9 if d['ms'] > 0 else 0.0
                 roof = {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS}
-            roof.update({'traffic': None, 'kernel': d['kernel'], 'launches': d['calls'], 'avg_launch_ms': avg_ms,
-                         'summed_duration_over_wall': d['ms'] / (1e3 * dt) if dt > 0 else 0.0,
+            roof.update({'traffic': None, 'kernel': d['kernel'], 'launches_timed': d['calls'],
+                         'launch_sampling': 'every %d-th launch of this family bracketed by HIP events on its stream, inside '
+                                            'the timed region' % max(1, args.sample),
+                         'avg_launch_ms': avg_ms,
                          'algorithmic_flops_per_launch': d['flops'] / max(1, d['calls']),
                          'algorithmic_bytes_per_launch': d['bytes'] / max(1, d['calls']),
                          'note': 'single-workgroup LDS-resident Jacobi step: latency-bound, far from either roofline'
@@ -188,6 +232,8 @@ def main():
                                           if warm_prof is not None else 'timed sweeps')
             out['kernel_time_ms_per_sweep'] = {p['kernel']: round(p['ms'] / nsw, 3) for p in table}
             out['kernel_launches_per_sweep'] = {p['kernel']: p['calls'] // nsw for p in table}
+            if phases is not None:
+                out['phase_kernel_time_single_chain_sweep'] = phases
             gm = [p for i, p in enumerate(table) if i in MFMA_FAM and p['ms'] > 0]
             if gm:
                 fl, ms = sum(p['flops'] for p in gm), sum(p['ms'] for p in gm)

@@ -103,12 +103,23 @@ int tn_nfactor_batched(double* x, int64_t batch, int64_t len, void* stream);
 
 /* ---- measurement: bracket every launch of the selected kernel families with HIP events on the launch stream.
  * family ids: 0-3 gemm_kernel<128,128> / <128,32> / <32,128> / <64,64> (all operand layouts), 4 splitk_reduce,
- * 5 absorb, 6 gram_partial, 7 eig_small, 8 rows_times_small, 9 small_t_times_vecs, 10 tsqr_factor/apply.
+ * 5 absorb, 6 gram_partial, 7 eig_small, 8 rows_times_small, 9 small_t_times_vecs, 10 tsqr_factor/apply,
+ * 11 lu_reconstruct, 12 QR auxiliaries (diag_qr, assemble_R, init_Q, norms, copies), 13 SVD auxiliaries (norms, init,
+ * gather), 14 misc (nfactor, scaling, builders, beam kernels).
  * mask bit f enables family f.  tn_profile_get synchronises the recorded events and returns totals since the last
- * reset: launches, summed duration (ms), algorithmic flops and bytes (SURVEY.md §8d counts). */
+ * reset: launches, summed duration (ms), algorithmic flops and bytes (SURVEY.md §8d counts).
+ * Counter-only families (no events; active whenever any family is enabled): 15 tn_qr nominal (calls, 4mn^2-4/3n^3,
+ * 8(2mn+n^2)), 16 tn_svd_trunc nominal (14mn^2+8n^3, 8(2mn+n^2+n)), 17 Jacobi streaming model (calls = executed
+ * sweeps, bytes = sweeps*(n-1)*16*n*(m+n)), 18 tn_svdvals nominal (4mn^2-4/3n^3, 8(mn+n)).
+ * tn_profile_get_phase splits the same totals by the entry point that issued the launch: phase 0 other (attach /
+ * projector / environment GEMMs, scaling), 1 tn_absorb, 2 tn_qr, 3 tn_svd_trunc, 4 tn_svdvals, 5 MPO builders;
+ * phase -1 = all. */
 void tn_profile_enable(unsigned mask);
 void tn_profile_reset(void);
+/* bracket only every `every`-th launch of an enabled family (default 1 = all): totals then cover the sampled launches */
+void tn_profile_sample(unsigned every);
 int tn_profile_get(int family, uint64_t* calls_host, double* ms_host, double* flops_host, double* bytes_host);
+int tn_profile_get_phase(int phase, int family, uint64_t* calls_host, double* ms_host, double* flops_host, double* bytes_host);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,9 @@ SIGNATURES = {
     'tn_mpo_from_factor': (_int, [_ptr] * 3 + [_i64] * 5 + [_ptr, _ptr]),
     'tn_profile_enable': (None, [C.c_uint]),
     'tn_profile_reset': (None, []),
+    'tn_profile_sample': (None, [C.c_uint]),
     'tn_profile_get': (_int, [_int, C.POINTER(C.c_uint64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64)]),
+    'tn_profile_get_phase': (_int, [_int, _int, C.POINTER(C.c_uint64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64)]),
 }
 
 

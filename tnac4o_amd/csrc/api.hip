@@ -47,10 +47,18 @@ int tn_version(void) { return 1; }
 
 void tn_profile_enable(unsigned mask) { prof_set_mask(mask); }
 void tn_profile_reset(void) { prof_reset(); }
+void tn_profile_sample(unsigned every) { prof_set_sample(every); }
 int tn_profile_get(int family, uint64_t* calls_host, double* ms_host, double* flops_host, double* bytes_host) {
     TN_CHECK_ARG(family >= 0 && family < PROF_NFAM, "unknown kernel family");
     TN_CHECK_ARG(calls_host && ms_host && flops_host && bytes_host, "null output");
-    prof_get(family, calls_host, ms_host, flops_host, bytes_host);
+    prof_get(-1, family, calls_host, ms_host, flops_host, bytes_host);
+    return 0;
+}
+int tn_profile_get_phase(int phase, int family, uint64_t* calls_host, double* ms_host, double* flops_host, double* bytes_host) {
+    TN_CHECK_ARG(phase >= -1 && phase < PH_N, "unknown phase");
+    TN_CHECK_ARG(family >= 0 && family < PROF_NFAM, "unknown kernel family");
+    TN_CHECK_ARG(calls_host && ms_host && flops_host && bytes_host, "null output");
+    prof_get(phase, family, calls_host, ms_host, flops_host, bytes_host);
     return 0;
 }
 
@@ -77,6 +85,7 @@ int64_t tn_gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch) { retur
 int tn_absorb(const double* A, const double* W, double* out, int64_t Dl, int64_t pold, int64_t Dr, int64_t ba, int64_t po,
               int64_t bb, int64_t pi, int hconj, void* stream) {
     TN_CHECK_ARG(A && W && out, "null operand");
+    ProfPhase ph(PH_ABSORB);
     return absorb(ST, A, W, out, Dl, pold, Dr, ba, po, bb, pi, hconj);
 }
 
@@ -84,6 +93,9 @@ int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, in
           int64_t rcs, int nb, double rank_tol, int64_t* keff_host, void* ws, int64_t ws_bytes, void* stream) {
     TN_CHECK_ARG(A && Q && R && ws, "null operand");
     TN_CHECK_ARG(rank_tol >= 0.0 && rank_tol < 1.0, "rank_tol out of range");
+    ProfPhase ph(PH_QR);
+    const double dm = (double)m, dn = (double)(n < m ? n : m);
+    prof_note(PROF_QR_NOMINAL, 1, 4.0 * dm * dn * dn - 4.0 / 3.0 * dn * dn * dn, 8.0 * (2.0 * dm * dn + dn * dn));
     return qr_factor(ST, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host);
 }
 int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_ws_bytes(m, n, nb); }
@@ -92,12 +104,23 @@ int tn_svd_trunc(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n
                  int64_t urs, int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_host,
                  double* discarded_host, int* sweeps_host, int* info_host, void* ws, int64_t ws_bytes, void* stream) {
     TN_CHECK_ARG(C && U && S && Vt && ws && keep_host, "null operand");
-    return svd_trunc(ST, C, crs, ccs, k, n, Dmax, tol, U, urs, ucs, S, Vt, vrs, vcs, keep_host, discarded_host, sweeps_host,
-                     info_host, ws, ws_bytes);
+    ProfPhase ph(PH_SVD);
+    int sweeps = 0;
+    const int rc = svd_trunc(ST, C, crs, ccs, k, n, Dmax, tol, U, urs, ucs, S, Vt, vrs, vcs, keep_host, discarded_host, &sweeps,
+                             info_host, ws, ws_bytes);
+    if (sweeps_host) *sweeps_host = sweeps;
+    // nominal counts of SURVEY.md 8(d) with m = max(k, n), n = min(k, n)
+    const double dm = (double)(k > n ? k : n), dn = (double)(k > n ? n : k);
+    prof_note(PROF_SVD_NOMINAL, 1, 14.0 * dm * dn * dn + 8.0 * dn * dn * dn, 8.0 * (2.0 * dm * dn + dn * dn + dn));
+    prof_note(PROF_SVD_STREAM, sweeps, 0.0, (double)sweeps * (dn - 1.0) * 16.0 * dn * (dm + dn));
+    return rc;
 }
 int tn_svdvals(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* S_host, int* sweeps_host,
                int* info_host, void* ws, int64_t ws_bytes, void* stream) {
     TN_CHECK_ARG(C && S_host && ws, "null operand");
+    ProfPhase ph(PH_SVDVALS);
+    const double dm = (double)(k > n ? k : n), dn = (double)(k > n ? n : k);
+    prof_note(PROF_SVDVALS_NOMINAL, 1, 4.0 * dm * dn * dn - 4.0 / 3.0 * dn * dn * dn, 8.0 * (dm * dn + dn));
     return svd_vals(ST, C, crs, ccs, k, n, S_host, sweeps_host, info_host, ws, ws_bytes);
 }
 int64_t tn_svd_ws_bytes(int64_t k, int64_t n, int vectors) { return svd_ws_bytes(k, n, vectors); }
@@ -125,11 +148,13 @@ int tn_peps_factor(const double* Es, const double* E1, const double* E4, const d
                    const double* Xd, const int32_t* dmap, const int32_t* rmap, int64_t q, int64_t nl, int64_t nu, double* F,
                    void* stream) {
     TN_CHECK_ARG(Es && E1 && E4 && Xu && Xl && Xr && Xd && dmap && rmap && F, "null operand");
+    ProfPhase ph(PH_BUILD);
     return peps_factor(ST, Es, E1, E4, Xu, Xl, Xr, Xd, dmap, rmap, q, nl, nu, F);
 }
 int tn_mpo_from_factor(const double* F, const int32_t* dmap, const int32_t* rmap, int64_t q, int64_t nl, int64_t nu, int64_t pd,
                        int64_t br, double* W, void* stream) {
     TN_CHECK_ARG(F && dmap && rmap && W, "null operand");
+    ProfPhase ph(PH_BUILD);
     return mpo_from_factor(ST, F, dmap, rmap, q, nl, nu, pd, br, W);
 }
 int tn_nfactor_batched(double* x, int64_t batch, int64_t len, void* stream) {

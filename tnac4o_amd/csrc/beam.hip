@@ -100,8 +100,8 @@ int calc_pn(hipStream_t st, const double* T1, const double* RR, const double* F,
     const int64_t lds = (p * Dr + Dr * br + p * br + q) * 8;
     TN_CHECK_ARG(lds <= 150 * 1024, "site too large for calc_pn");
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)calc_pn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(calc_pn_kernel, dim3((unsigned)nb), dim3(256), (size_t)lds, st, T1, RR, F, dmap, rmap, pref, suf, lidx,
-                       uidx, (int)q, (int)nl, (int)nu, (int)p, (int)Dr, (int)br, P, minP);
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(calc_pn_kernel, dim3((unsigned)nb), dim3(256), (size_t)lds, st, T1, RR, F, dmap, rmap, pref, suf, lidx,
+                       uidx, (int)q, (int)nl, (int)nu, (int)p, (int)Dr, (int)br, P, minP));
     TN_CHECK_LAUNCH("calc_pn_kernel");
     return 0;
 }
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void nfactor_batched_kernel(double* __restrict
 
 int nfactor_batched(hipStream_t st, double* x, int64_t batch, int64_t len) {
     if (batch <= 0 || len <= 0) return 0;
-    hipLaunchKernelGGL(nfactor_batched_kernel, dim3((unsigned)batch), dim3(256), 0, st, x, len);
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(nfactor_batched_kernel, dim3((unsigned)batch), dim3(256), 0, st, x, len));
     TN_CHECK_LAUNCH("nfactor_batched_kernel");
     return 0;
 }

@@ -53,13 +53,35 @@ static __device__ __forceinline__ double fast_rcp(double x) {
 
 // ---- optional event timing per kernel family (prof.hip) ---------------------------------------------
 enum { PROF_GEMM_128x128 = 0, PROF_GEMM_128x32, PROF_GEMM_32x128, PROF_GEMM_64x64, PROF_SPLITK_REDUCE, PROF_ABSORB,
-       PROF_GRAM, PROF_EIG, PROF_ROWS_SMALL, PROF_VECS_SMALL, PROF_TSQR, PROF_NFAM };
+       PROF_GRAM, PROF_EIG, PROF_ROWS_SMALL, PROF_VECS_SMALL, PROF_TSQR,
+       PROF_LU,        // lu_reconstruct_kernel (Householder reconstruction of a panel)
+       PROF_QR_AUX,    // diag_qr, assemble_R, init_Q, column norms, panel copies
+       PROF_SVD_AUX,   // vector norms, init, gather of the Jacobi SVD
+       PROF_MISC,      // nfactor / scaling / builders / beam kernels
+       PROF_NKERNEL,   // ---- families above bracket kernel launches with events; the ones below are pure counters ----
+       PROF_QR_NOMINAL = PROF_NKERNEL,   // per tn_qr call: calls, 4mn^2 - 4/3 n^3 flops, 8(2mn + n^2) bytes
+       PROF_SVD_NOMINAL,                 // per tn_svd_trunc call: 14mn^2 + 8n^3 flops, 8(2mn + n^2 + n) bytes
+       PROF_SVD_STREAM,                  // per tn_svd_trunc call: calls += executed sweeps, bytes += sweeps*(n-1)*16*n*(m+n)
+       PROF_SVDVALS_NOMINAL,             // per tn_svdvals call: 4mn^2 - 4/3 n^3 flops, 8(mn + n) bytes
+       PROF_NFAM };
+// phase a launch is attributed to (thread-local; set by the entry points that own a phase)
+enum { PH_OTHER = 0, PH_ABSORB, PH_QR, PH_SVD, PH_SVDVALS, PH_BUILD, PH_N };
 bool prof_on(int fam);
 void prof_begin(hipStream_t st, int fam);
 void prof_end(hipStream_t st, int fam, double flops, double bytes);
+void prof_note(int fam, double calls, double flops, double bytes);   // counter-only families
+int prof_phase(int phase);                                           // returns the previous phase
+struct ProfPhase {                                                    // scoped phase
+    int prev;
+    explicit ProfPhase(int ph) : prev(prof_phase(ph)) {}
+    ~ProfPhase() { prof_phase(prev); }
+};
+// bracket one kernel launch of a family that has no flop/byte model
+#define TN_PROF_LAUNCH(st, fam, launch) do { prof_begin(st, fam); launch; prof_end(st, fam, 0.0, 0.0); } while (0)
 void prof_set_mask(unsigned mask);
+void prof_set_sample(unsigned n);
 void prof_reset();
-void prof_get(int fam, uint64_t* calls, double* ms, double* flops, double* bytes);
+void prof_get(int phase, int fam, uint64_t* calls, double* ms, double* flops, double* bytes);   // phase < 0: all phases
 
 // ---- strided matrix view (element strides) -------------------------------------------------
 struct Mat {

@@ -43,9 +43,9 @@ int nfactor(hipStream_t st, const double* x, int64_t n, double* out2, void* slot
     if (e != hipSuccess) return hip_fail(e, "memset slot");
     int64_t nb = cdiv(n, 256 * 8);
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, n, (unsigned long long*)slot8);
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, n, (unsigned long long*)slot8));
     TN_CHECK_LAUNCH("absmax_bits_kernel");
-    hipLaunchKernelGGL(nfactor_finish_kernel, dim3(1), dim3(1), 0, st, (const unsigned long long*)slot8, out2);
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(nfactor_finish_kernel, dim3(1), dim3(1), 0, st, (const unsigned long long*)slot8, out2));
     TN_CHECK_LAUNCH("nfactor_finish_kernel");
     return 0;
 }
@@ -54,7 +54,7 @@ int scale_by(hipStream_t st, double* x, int64_t n, const double* scalar_dev) {
     if (n <= 0) return 0;
     int64_t nb = cdiv(n, 256 * 4);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, n, scalar_dev);
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, n, scalar_dev));
     TN_CHECK_LAUNCH("scale_by_kernel");
     return 0;
 }
@@ -74,7 +74,7 @@ int scale_phys(hipStream_t st, double* A, int64_t Dl, int64_t p, int64_t Dr, con
     if (n <= 0) return 0;
     int64_t nb = cdiv(n, 256 * 4);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(scale_phys_kernel, dim3((unsigned)nb), dim3(256), 0, st, A, Dl, p, Dr, diag, inv);
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(scale_phys_kernel, dim3((unsigned)nb), dim3(256), 0, st, A, Dl, p, Dr, diag, inv));
     TN_CHECK_LAUNCH("scale_phys_kernel");
     return 0;
 }

@@ -46,8 +46,8 @@ int peps_factor(hipStream_t st, const double* Es, const double* E1, const double
                 const double* Xr, const double* Xd, const int32_t* dmap, const int32_t* rmap, int64_t q, int64_t nl, int64_t nu,
                 double* F) {
     TN_CHECK_ARG(q >= 1 && nl >= 1 && nu >= 1, "non-positive dimension");
-    hipLaunchKernelGGL(peps_factor_kernel, dim3((unsigned)cdiv(q * nl * nu, 256)), dim3(256), 0, st, Es, E1, E4, Xu, Xl, Xr, Xd,
-                       dmap, rmap, (int)q, (int)nl, (int)nu, F);
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(peps_factor_kernel, dim3((unsigned)cdiv(q * nl * nu, 256)), dim3(256), 0, st, Es, E1, E4, Xu, Xl, Xr, Xd,
+                       dmap, rmap, (int)q, (int)nl, (int)nu, F));
     TN_CHECK_LAUNCH("peps_factor_kernel");
     return 0;
 }
@@ -56,8 +56,8 @@ int mpo_from_factor(hipStream_t st, const double* F, const int32_t* dmap, const 
                     int64_t pd, int64_t br, double* W) {
     TN_CHECK_ARG(q >= 1 && nl >= 1 && nu >= 1 && pd >= 1 && br >= 1, "non-positive dimension");
     TN_CHECK_ARG(q <= 8192, "too many cell states");
-    hipLaunchKernelGGL(mpo_from_factor_kernel, dim3((unsigned)cdiv(nl * pd * br * nu, 256)), dim3(256), (size_t)(2 * q * 4), st, F,
-                       dmap, rmap, (int)q, (int)nl, (int)nu, (int)pd, (int)br, W);
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(mpo_from_factor_kernel, dim3((unsigned)cdiv(nl * pd * br * nu, 256)), dim3(256), (size_t)(2 * q * 4), st, F,
+                       dmap, rmap, (int)q, (int)nl, (int)nu, (int)pd, (int)br, W));
     TN_CHECK_LAUNCH("mpo_from_factor_kernel");
     return 0;
 }

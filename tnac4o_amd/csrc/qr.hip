@@ -35,8 +35,8 @@ int copy_mat(hipStream_t st, const double* S, int64_t srs, int64_t scs, double* 
              int64_t n) {
     if (m <= 0 || n <= 0) return 0;
     const int colfast = (dcs == 1 || scs == 1) ? 1 : 0;
-    hipLaunchKernelGGL(copy_mat_kernel, dim3((unsigned)cdiv(m * n, 256)), dim3(256), 0, st, S, srs, scs, D, drs, dcs, m,
-                       n, colfast);
+    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(copy_mat_kernel, dim3((unsigned)cdiv(m * n, 256)), dim3(256), 0, st, S, srs, scs, D, drs, dcs, m,
+                       n, colfast));
     TN_CHECK_LAUNCH("copy_mat_kernel");
     return 0;
 }
@@ -423,7 +423,7 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
     if (reveal) {
         hipError_t e = hipMemsetAsync(slots, 0, 16, st);
         if (e != hipSuccess) return hip_fail(e, "memset slots");
-        hipLaunchKernelGGL(colnorm2_max_kernel, dim3((unsigned)n), dim3(256), 0, st, A, rs, cs, m, n, slots);
+        TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_max_kernel, dim3((unsigned)n), dim3(256), 0, st, A, rs, cs, m, n, slots));
         TN_CHECK_LAUNCH("colnorm2_max_kernel");
     }
     // Y shares A's fast direction so panel kernels coalesce the same way
@@ -455,8 +455,8 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
                 if ((rc = rows_times_small(st, Yp.p, yrs, ycs, mp, b, w.Js))) return rc;
                 dbg_check(st, Yp.p, yrs, ycs, mp < 64 ? mp : 64, b, "W", p, it);
                 if (mode == 0) {
-                    hipLaunchKernelGGL(refill_dead_kernel, dim3((unsigned)cdiv(mp, 256)), dim3(256), 0, st, Yp.p, yrs, ycs, mp,
-                                       b, w.dead, (uint64_t)(0x9E3779B97F4A7C15ULL * (uint64_t)(p * 4 + it + 1)));
+                    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(refill_dead_kernel, dim3((unsigned)cdiv(mp, 256)), dim3(256), 0, st, Yp.p, yrs, ycs, mp,
+                                       b, w.dead, (uint64_t)(0x9E3779B97F4A7C15ULL * (uint64_t)(p * 4 + it + 1))));
                     TN_CHECK_LAUNCH("refill_dead_kernel");
                 }
             }
@@ -465,11 +465,11 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         double* Tp = w.T + (int64_t)p * nb * nb;
         Mat Wqp = sub(Wqm, j0, j0), Wp = mat(w.W, wrs, wcs);
         if (nb == 32)
-            hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT, w.UTq,
-                               Wp.p, wrs, wcs, Wqp.p);
+            TN_PROF_LAUNCH(st, PROF_LU, hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT, w.UTq,
+                               Wp.p, wrs, wcs, Wqp.p));
         else
-            hipLaunchKernelGGL((lu_reconstruct_kernel<64>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT, w.UTq,
-                               Wp.p, wrs, wcs, Wqp.p);
+            TN_PROF_LAUNCH(st, PROF_LU, hipLaunchKernelGGL((lu_reconstruct_kernel<64>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT, w.UTq,
+                               Wp.p, wrs, wcs, Wqp.p));
         TN_CHECK_LAUNCH("lu_reconstruct_kernel");
         dbg_check(st, Tp, b, 1, b, b, "T", p, 9);
         dbg_check(st, w.Uinv, b, 1, b, b, "Uinv", p, 9);
@@ -493,8 +493,8 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
             const int64_t j1 = j0 + b;
             hipError_t e = hipMemsetAsync(slots + 1, 0, 8, st);
             if (e != hipSuccess) return hip_fail(e, "memset slot");
-            hipLaunchKernelGGL(colnorm2_max_kernel, dim3((unsigned)(n - j1)), dim3(256), 0, st, sub(Am, j1, j1).p, rs, cs, m - j1,
-                               n - j1, slots + 1);
+            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_max_kernel, dim3((unsigned)(n - j1)), dim3(256), 0, st, sub(Am, j1, j1).p, rs, cs, m - j1,
+                               n - j1, slots + 1));
             TN_CHECK_LAUNCH("colnorm2_max_kernel");
             double h[2];
             if ((e = hipMemcpyAsync(h, slots, 16, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy norms");
@@ -509,18 +509,18 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
     }
     if (keff_host) *keff_host = k;
     // --- triangularise the diagonal blocks, assemble R
-    if (nb == 32) hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri);
-    else hipLaunchKernelGGL((diag_qr_kernel<64>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri);
+    if (nb == 32) TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri));
+    else TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<64>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri));
     TN_CHECK_LAUNCH("diag_qr_kernel");
     dbg_check(st, w.Z, nb, 1, (int64_t)P * nb, nb, "Z", -1, 0);
     dbg_check(st, w.Tri, nb, 1, (int64_t)P * nb, nb, "Tri", -1, 0);
-    hipLaunchKernelGGL(assemble_R_kernel, dim3((unsigned)cdiv(k * n, 256)), dim3(256), 0, st, A, rs, cs, nb, k, n, w.Z,
-                       w.Tri, R, rrs, rcs);
+    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(assemble_R_kernel, dim3((unsigned)cdiv(k * n, 256)), dim3(256), 0, st, A, rs, cs, nb, k, n, w.Z,
+                       w.Tri, R, rrs, rcs));
     TN_CHECK_LAUNCH("assemble_R_kernel");
     // --- Q = H_1 ... H_P [Z; 0]
     const int qcolfast = (qcs == 1) ? 1 : 0;
-    hipLaunchKernelGGL(init_Q_kernel, dim3((unsigned)cdiv(m * k, 256)), dim3(256), 0, st, Q, qrs, qcs, m, k, nb, w.Z,
-                       qcolfast);
+    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(init_Q_kernel, dim3((unsigned)cdiv(m * k, 256)), dim3(256), 0, st, Q, qrs, qcs, m, k, nb, w.Z,
+                       qcolfast));
     TN_CHECK_LAUNCH("init_Q_kernel");
     Mat Qm = mat(Q, qrs, qcs);
     for (int p = P - 1; p >= 0; --p) {

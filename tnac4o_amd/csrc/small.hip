@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
     __shared__ double dsc[NB];
     __shared__ double rc[NB / 2], rsn[NB / 2];
     __shared__ int rp[NB / 2], rq[NB / 2];
-    __shared__ int cnt, total, stepflag;
+    __shared__ int cnt, total;
+    __shared__ int stepflag[NB];            // one flag per round-robin step (no reset barrier inside the sweep)
     __shared__ double red[256];
     const int tid = threadIdx.x, grp = blockIdx.x;
     const int n = (nvec + 1) & ~1;          // even working size (a padding index never rotates)
@@ -172,10 +173,9 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
         const double tol = 8.881784197001252e-16;      // 2^-50
         for (int sweep = 0; sweep < max_sweeps; ++sweep) {
             if (tid == 0) cnt = 0;
+            if (tid < NB) stepflag[tid] = 0;
             __syncthreads();
             for (int s = 0; s < NB - 1; ++s) {
-                if (tid == 0) stepflag = 0;
-                __syncthreads();
                 if (tid < HP) {
                     int p, q;
                     rr_pair(NB, s, tid, p, q);
@@ -193,12 +193,12 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                         c = fast_rsqrt(1.0 + t * t);
                         sn = t * c;
                         atomicAdd(&cnt, 1);
-                        stepflag = 1;
+                        stepflag[s] = 1;
                     }
                     rc[tid] = c; rsn[tid] = sn; rp[tid] = p; rq[tid] = q;
                 }
                 __syncthreads();
-                if (stepflag == 0) continue;                       // uniform: nothing to rotate in this step
+                if (stepflag[s] == 0) continue;                    // uniform: nothing to rotate in this step
                 {   // G <- R^T G R as independent 2x2 blocks (pair a x pair b);  J <- J R as (row i, pair b)
                     constexpr int GB = HP * HP / 256, JB = NB * HP / 256;
                     double g00[GB], g01[GB], g10[GB], g11[GB], jp[JB], jq[JB];

@@ -149,7 +149,7 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
                        SvdWs& w, std::vector<double>& hostS, std::vector<int>& hostOrder, int* sweeps_out, int* info) {
     hipError_t e;
     int rc;
-    hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nv), dim3(256), 0, st, M, vs, es, L, w.norms);
+    TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nv), dim3(256), 0, st, M, vs, es, L, w.norms));
     TN_CHECK_LAUNCH("vec_norm2_kernel");
     std::vector<double> hn(nv);
     if ((e = hipMemcpyAsync(hn.data(), w.norms, nv * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy norms");
@@ -169,8 +169,8 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     const int nblk = (int)(nvp / SVD_W), ng = nblk / 2, nr = nblk - 1;
     if ((e = hipMemcpyAsync(w.live, live.data(), nvl * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy live");
     const int64_t pitch = L + (vectors ? nv : 0);
-    hipLaunchKernelGGL(svd_init_kernel, dim3((unsigned)nvp), dim3(256), 0, st, M, vs, es, L, nv, w.live, nvl, w.X,
-                       vectors ? w.P : nullptr, pitch);
+    TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_init_kernel, dim3((unsigned)nvp), dim3(256), 0, st, M, vs, es, L, nv, w.live, nvl, w.X,
+                       vectors ? w.P : nullptr, pitch));
     TN_CHECK_LAUNCH("svd_init_kernel");
     std::vector<int> pairs;
     round_robin(nblk, pairs);
@@ -214,7 +214,7 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     }
     if (sweeps_out) *sweeps_out = sweeps;
     if (info) *info = converged ? 0 : 1;
-    hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nvp), dim3(256), 0, st, w.X, pitch, 1, L, w.norms);
+    TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nvp), dim3(256), 0, st, w.X, pitch, 1, L, w.norms));
     TN_CHECK_LAUNCH("vec_norm2_kernel");
     std::vector<double> hs(nvp);
     if ((e = hipMemcpyAsync(hs.data(), w.norms, nvp * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy S");
@@ -261,11 +261,11 @@ int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t
     if ((e = hipMemcpyAsync(S, w.Ssorted, keep * 8, hipMemcpyDeviceToDevice, st)) != hipSuccess) return hip_fail(e, "copy S");
     // rows: left = U (k x keep), right = Vt.  columns (C^T was factored): left = Vt^T, right = U^T.
     if (rows)
-        hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, w.order, w.Ssorted,
-                           U, urs, ucs, Vt, vrs, vcs);
+        TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, w.order, w.Ssorted,
+                           U, urs, ucs, Vt, vrs, vcs));
     else
-        hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, w.order, w.Ssorted,
-                           Vt, vcs, vrs, U, ucs, urs);
+        TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, w.order, w.Ssorted,
+                           Vt, vcs, vrs, U, ucs, urs));
     TN_CHECK_LAUNCH("svd_gather_kernel");
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync gather");   // hS/hO go out of scope
     return 0;
