@@ -416,12 +416,20 @@ class RefSolver:
         return Pn, mPn
 
     def search_ground_state(self, M=2 ** 10, relative_P_cutoff=1e-6, min_dEng=1e-12, graduate_truncation=True,
-                            Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20, trace=None):
+                            Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20, trace=None, sweep_hook=None,
+                            pn_gather=None):
         """Row-major branch-and-bound (tnac4o.py:381-551).  ``trace`` (a list) receives the
-        (ny, nx, newprob, minprob) tables of every site-step when given (for golden checks)."""
+        (ny, nx, newprob, minprob) tables of every site-step when given (for golden checks).
+        ``sweep_hook(solver, run_sweep)`` / ``pn_gather(compute, nb, q)``: optional injection points used by the CPU
+        multi-rank tests to wrap the sweep and the per-branch table in the product's sharding helpers; with both None
+        this is the plain reference algorithm."""
         M_ = M
-        self._setup_rhoT(graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV,
-                         max_sweeps=max_sweeps)
+        kw_sweep = dict(graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps)
+        if sweep_hook is None:
+            self._setup_rhoT(**kw_sweep)
+        else:
+            sweep_hook(self, lambda: self._setup_rhoT(**kw_sweep))
+        gather = pn_gather
         Nx, Ny = self.Nx, self.Ny
         vind = np.zeros((1, Nx + 1), dtype=self.indtype)
         states = np.zeros((1, Nx * Ny), dtype=self.indtype)
@@ -435,12 +443,17 @@ class RefSolver:
             for nx in range(Nx):
                 q, nb = self.N[ny][nx], prob.size
                 F, dmap, rmap, _, _ = self.peps_factor(ny, nx)
-                newprob = np.zeros((nb, q))
-                minprob = np.zeros(nb)
-                for k in range(nb):
-                    t = tuple(vind[k])
-                    newprob[k], minprob[k] = self.conditional_probabilities(
-                        F[:, t[nx], t[nx + 1]], dmap, rmap, RLl[t[:nx]], top.A[nx], RRl[Nx - nx - 1][t[nx + 2:]])
+                def pn_slice(lo, hi):
+                    P, mP = np.zeros((hi - lo, q)), np.zeros(hi - lo)
+                    for k in range(lo, hi):
+                        t = tuple(vind[k])
+                        P[k - lo], mP[k - lo] = self.conditional_probabilities(
+                            F[:, t[nx], t[nx + 1]], dmap, rmap, RLl[t[:nx]], top.A[nx], RRl[Nx - nx - 1][t[nx + 2:]])
+                    return P, mP
+                if gather is None:
+                    newprob, minprob = pn_slice(0, nb)
+                else:
+                    newprob, minprob = gather(pn_slice, nb, q)
                 if trace is not None:
                     trace.append((ny, nx, newprob.copy(), minprob.copy(), vind.copy()))
                 with np.errstate(divide='ignore'):

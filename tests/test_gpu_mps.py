@@ -320,3 +320,51 @@ def test_product_path_uses_hip_library():
     for name in ('tnac4o_amd.tnac4o', 'tnac4o_amd.mps', 'tnac4o_amd.ops', 'tnac4o_amd._lib', 'tnac4o_amd.auxx'):
         src = open(sys.modules[name].__file__).read()
         assert 'oracle' not in src.replace("'oracle' not in", '')
+
+
+BEAM_GPU_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np, torch, torch.distributed as dist
+import golden_inputs as gi
+import tnac4o_amd
+from tnac4o_amd.parallel import solve_rotations
+torch.cuda.set_device(0)
+dist.init_process_group('gloo')          # two ranks share the one GPU of the test box, so the exchange runs over gloo
+J = gi.droplet_J(128, 1)
+make = lambda: tnac4o_amd.tnac4o(mode='Ising', Nx=4, Ny=4, Nc=8, J=J, beta=3.0)
+res = solve_rotations(make, rotations=(0,), beam_shards=2, M=256, relative_P_cutoff=1e-8, Dmax=16)
+res['state'] = [int(x) for x in res['state']]
+print('RESULT ' + json.dumps(res), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_beam_sharded_product_path_two_ranks():
+    """SURVEY.md 8e-ii on the product path: 2 processes (one GPU, gloo) split every site-step's branches; both must
+    reproduce the single-process result and the reference's golden ground state."""
+    import subprocess
+    import sys as _sys
+    import json as _json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = BEAM_GPU_WORKER % dict(root=root)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
+    procs = [subprocess.Popen([_sys.executable, '-c', code], env=dict(env, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0'),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+        outs.append(_json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][-1][7:]))
+    assert outs[0] == outs[1]
+    import tnac4o_amd
+    J = gi.droplet_J(128, 1)
+    s = tnac4o_amd.tnac4o(mode='Ising', Nx=4, Ny=4, Nc=8, J=J, beta=3.0)
+    s.search_ground_state(M=256, relative_P_cutoff=1e-8, Dmax=16)
+    assert outs[0]['energy'] == float(s.energy[0])
+    assert outs[0]['state'] == [int(x) for x in s.states[0]]
+    assert outs[0]['probability'] == pytest.approx(float(s.probability[0]), abs=1e-12)
+    E, _ = gi.golden_groundstate(128, 1)
+    assert outs[0]['energy'] == pytest.approx(E, abs=1e-5)

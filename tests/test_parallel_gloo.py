@@ -67,3 +67,71 @@ def test_rotations_sharded_over_two_ranks(rots):
     assert ser['energy'] == a['energy'] and ser['degeneracy'] == a['degeneracy'] and ser['rotation'] == a['rotation']
     assert [int(x) for x in ser['state']] == a['state']
     assert ser['probability'] == pytest.approx(a['probability'], abs=1e-12)
+
+
+BEAM_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np, torch, torch.distributed as dist
+import golden_inputs as gi
+from sharded_ref import ShardedRef
+from tnac4o_amd.parallel import solve_rotations
+dist.init_process_group('gloo')
+J = gi.droplet_J(128, %(inst)d)
+make = lambda: ShardedRef(mode='Ising', Nx=4, Ny=4, Nc=8, J=J, beta=3.0)
+res = solve_rotations(make, rotations=%(rots)r, beam_shards=%(shards)d, M=64, relative_P_cutoff=1e-6, Dmax=8)
+res['state'] = [int(x) for x in res['state']]
+res['rank'] = dist.get_rank()
+print('RESULT ' + json.dumps(res), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def run_beam_world(nproc, rots, shards, inst, port):
+    code = BEAM_WORKER % dict(root=ROOT, rots=tuple(rots), shards=shards, inst=inst)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='2', OPENBLAS_NUM_THREADS='2')
+    procs = []
+    for r in range(nproc):
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, '-c', code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0, err[-2000:]
+        line = [l for l in out.splitlines() if l.startswith('RESULT ')][-1]
+        outs.append(json.loads(line[7:]))
+    return outs
+
+
+@pytest.mark.parametrize('nproc,rots,inst', [(2, (0,), 1), (4, (0, 3), 2)])
+def test_beam_sharded_inside_a_rotation(nproc, rots, inst):
+    """SURVEY.md 8e-ii: teams of 2 ranks per rotation; the team's first rank sweeps and broadcasts rhoT, every site-step's
+    branches are split between the two, one all-gather per step; every rank must end with the serial result."""
+    outs = run_beam_world(nproc, rots, 2, inst, 29560 + nproc)
+    for o in outs[1:]:
+        for k in ('energy', 'degeneracy', 'rotation', 'probability', 'state', 'records'):
+            assert o[k] == outs[0][k]
+    assert [r['rotation'] for r in outs[0]['records']] == list(rots)       # one record per rotation (the owner's)
+    from oracle import solver_ref as sr
+    from tnac4o_amd.parallel import solve_rotations
+    J = gi.droplet_J(128, inst)
+    ser = solve_rotations(lambda: sr.RefSolver(mode='Ising', Nx=4, Ny=4, Nc=8, J=J, beta=3.0), rotations=rots, M=64,
+                          relative_P_cutoff=1e-6, Dmax=8)
+    a = outs[0]
+    assert ser['energy'] == a['energy'] and ser['degeneracy'] == a['degeneracy'] and ser['rotation'] == a['rotation']
+    assert [int(x) for x in ser['state']] == a['state']
+    assert ser['probability'] == a['probability']               # same arithmetic on the same tables: bit-identical
+    for r1, r2 in zip(ser['records'], a['records']):
+        assert r1 == r2
+
+
+def test_shard_range_partitions():
+    from tnac4o_amd.parallel import shard_range
+    for n in (0, 1, 5, 64, 1000):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_range(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            sizes = [h - l for l, h in cuts]
+            assert max(sizes) - min(sizes) <= 1

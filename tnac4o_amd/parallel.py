@@ -2,6 +2,12 @@
 sequential loop), so they shard across ranks with no data-path collective; one all-gather of a < 3 KB record per
 rotation merges the results (energy = min, degeneracy = max over the minimisers, as e06:107-109 does).
 
+Second axis: inside one rotation the <= M branches of the beam are independent until the merge /
+top-M of a site-step (tnac4o.py:437-537).  With `beam_shards` = B > 1 the ranks form sub-groups of B: the sub-group's
+first rank computes the boundary-MPS sweep (a sequential chain, not shardable) and broadcasts rhoT to its partners; at
+every site-step each rank evaluates the conditional probabilities of its contiguous slice of the branches and one
+all-gather inside the sub-group rebuilds the full table, after which every rank runs the identical deterministic merge.
+
 One process per GPU (torchrun); backend 'nccl' is RCCL over xGMI on ROCm, 'gloo' is used by the CPU tests.  The
 solver is injected (`make_solver`) so that the sharding / gather / merge logic can be exercised without a GPU.
 """
@@ -40,6 +46,102 @@ def run_concurrent(fns):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- beam sharding
+def shard_range(n, rank, world):
+    """Contiguous slice [lo, hi) of n items owned by `rank` (the first n % world ranks get one more)."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _group_info(group):
+    if group is None or not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def _comm_device(group):
+    return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+
+
+def gather_branch_tables(compute, nb, q, group):
+    """Conditional-probability tables of all nb branches from per-rank slices.
+
+    compute(lo, hi) -> (P, minP): P (hi-lo, q) and minP (hi-lo,) as float64 torch tensors or numpy arrays, for the
+    branches lo..hi-1.  Every rank of `group` gets the complete (nb, q) / (nb,) tables as numpy arrays, assembled in
+    branch order, so whatever follows (cut-off, merge, top-M) is identical on all of them.  One all_gather per call."""
+    rank, world = _group_info(group)
+    if world == 1:
+        P, mP = compute(0, nb)
+        P = P.cpu().numpy() if torch.is_tensor(P) else np.asarray(P)
+        mP = mP.cpu().numpy() if torch.is_tensor(mP) else np.asarray(mP)
+        return P, mP
+    lo, hi = shard_range(nb, rank, world)
+    chunk = -(-int(nb) // world)                      # slices are padded to the largest one
+    dev = _comm_device(group)
+    buf = torch.zeros((chunk, q + 1), dtype=torch.float64, device=dev)
+    if hi > lo:
+        P, mP = compute(lo, hi)
+        buf[:hi - lo, :q] = torch.as_tensor(P, dtype=torch.float64).to(dev)
+        buf[:hi - lo, q] = torch.as_tensor(mP, dtype=torch.float64).to(dev)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    full = np.empty((nb, q + 1))
+    for r in range(world):
+        l, h = shard_range(nb, r, world)
+        if h > l:
+            full[l:h] = out[r][:h - l].cpu().numpy()
+    return np.ascontiguousarray(full[:, :q]), np.ascontiguousarray(full[:, q])
+
+
+def broadcast_site_tensors(rows, group):
+    """Broadcast a list (rows) of lists (sites) of float64 arrays from the first rank of `group` to the others.
+
+    rows: on the source the tensors (numpy arrays or torch tensors); ignored elsewhere.  Returns the same nested list on
+    every rank (numpy arrays for gloo, device tensors for nccl; the source gets its own objects back).  One broadcast of
+    the shapes and one flat buffer per row."""
+    rank, world = _group_info(group)
+    if world == 1:
+        return rows
+    src = dist.get_global_rank(group, 0)
+    dev = _comm_device(group)
+    meta = [[tuple(int(x) for x in a.shape) for a in row] for row in rows] if rank == 0 else None
+    box = [meta]
+    dist.broadcast_object_list(box, src=src, group=group)
+    meta = box[0]
+    out = []
+    for i, shapes in enumerate(meta):
+        n = sum(int(np.prod(sh)) for sh in shapes)
+        if rank == 0:
+            flat = torch.cat([torch.as_tensor(a, dtype=torch.float64).reshape(-1).to(dev) for a in rows[i]]) if n else \
+                torch.empty(0, dtype=torch.float64, device=dev)
+        else:
+            flat = torch.empty(n, dtype=torch.float64, device=dev)
+        if n:
+            dist.broadcast(flat, src=src, group=group)
+        if rank == 0:
+            out.append(rows[i])
+            continue
+        row, off = [], 0
+        for sh in shapes:
+            k = int(np.prod(sh))
+            t = flat[off:off + k].reshape(sh)
+            row.append(t.clone() if dev.type == 'cuda' else t.numpy().copy())
+            off += k
+        out.append(row)
+    return out
+
+
+def broadcast_object(obj, group):
+    """Small python object from the first rank of `group` to all of its ranks."""
+    rank, world = _group_info(group)
+    if world == 1:
+        return obj
+    box = [obj if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group)
+    return box[0]
+
+
 _HEAD = 6       # energy, degeneracy, log2 P, discarded log2 P, negative probability, rotation
 
 
@@ -56,8 +158,12 @@ def _pack(s, rot, ncell):
 
 
 def solve_rotations(make_solver, rotations=(0, 1, 2, 3), precondition=False, min_dEng=1e-12, group=None,
-                    concurrent=False, **search_kwargs):
+                    concurrent=False, beam_shards=1, **search_kwargs):
     """Solve the same instance from several lattice rotations, sharded round-robin over the ranks of `group`.
+
+    beam_shards = B > 1 (world size divisible by B; `group` must be the default group): consecutive ranks form
+    sub-groups of B that work on the same rotation with the beam split between them (see the module docstring); the
+    rotations are then dealt round-robin to the world/B sub-groups.
 
     concurrent=True runs the rotations assigned to this rank at the same time (threads + streams, GPU only).
     make_solver() -> a fresh solver exposing rotate_graph / precondition / search_ground_state and the result
@@ -69,18 +175,40 @@ def solve_rotations(make_solver, rotations=(0, 1, 2, 3), precondition=False, min
     rank = dist.get_rank(group) if ready else 0
     world = dist.get_world_size(group) if ready else 1
     rotations = list(rotations)
-    slots = (len(rotations) + world - 1) // world
-    mine = [r for i, r in enumerate(rotations) if i % world == rank]
+    B = int(beam_shards)
+    beam_group, owner = None, True
+    if B > 1:
+        if not ready or world % B:
+            raise ValueError('beam_shards=%d needs an initialised process group whose size it divides' % B)
+        if group is not None:
+            raise ValueError('beam_shards > 1 works on the default process group')
+        ngroups = world // B
+        for g in range(ngroups):                  # every rank creates every sub-group (torch.distributed rule)
+            h = dist.new_group(list(range(g * B, (g + 1) * B)))
+            if g == rank // B:
+                beam_group = h
+        owner = (rank % B == 0)
+        team, nteams = rank // B, ngroups
+    else:
+        team, nteams = rank, world
+    slots = (len(rotations) + nteams - 1) // nteams
+    mine = [r for i, r in enumerate(rotations) if i % nteams == team]
     local, ncell = [], None
 
     def one(rot):
         s = make_solver()
         if rot:
             s.rotate_graph(rot)
-        if precondition:
+        if precondition:                          # deterministic, so the partners of a beam team repeat it identically
             s.precondition(mode='balancing')
-        s.search_ground_state(**search_kwargs)
-        return _pack(s, rot, s.states.shape[1])
+        if beam_group is not None:
+            s.search_ground_state(beam_group=beam_group, **search_kwargs)
+        else:
+            s.search_ground_state(**search_kwargs)
+        rec = _pack(s, rot, s.states.shape[1])
+        if not owner:
+            rec[0] = np.nan                       # partners hold the same result; only the owner's record is counted
+        return rec
     if concurrent and len(mine) > 1:        # this rank's rotations interleave on the GPU, one stream each
         local = run_concurrent([(lambda r=rot: one(r)) for rot in mine])
     else:

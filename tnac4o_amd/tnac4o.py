@@ -481,13 +481,42 @@ class tnac4o:
             levels.append((keys, RR))
         return levels
 
+    def _setup_rhoT_shared(self, group, **kw):
+        """The sweep on the first rank of `group`, then rhoT (and its diagnostics) broadcast to the partners
+        (the sweep is a sequential chain; only the beam is split)."""
+        import torch.distributed as dist
+        from . import parallel
+        owner = dist.get_rank(group) == 0
+        if owner:
+            self._setup_rhoT(**kw)
+        rows = parallel.broadcast_site_tensors([m.A for m in self.rhoT] if owner else None, group)
+        diag = parallel.broadcast_object((list(self.rhoT_overlap), list(self.rhoT_discarded)) if owner else None, group)
+        if not owner:
+            self.rhoT = []
+            dev = torch.device('cuda', torch.cuda.current_device())
+            for A in rows:
+                m = mps.MPS(d=1, L=self.Nx, Dmax=1, initial='X')
+                A = [torch.as_tensor(a, dtype=torch.float64).to(dev) for a in A]      # gloo hands back host arrays
+                m.A = A
+                m.D = [int(A[0].shape[0])] + [int(a.shape[2]) for a in A]
+                self.rhoT.append(m)
+            self.rhoT_overlap, self.rhoT_discarded = diag
+
     def search_ground_state(self, M=2 ** 10, relative_P_cutoff=1e-6, min_dEng=1e-12, graduate_truncation=True,
-                            Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20, trace=None):
+                            Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20, trace=None, beam_group=None):
         """Row-major branch-and-bound for the most probable configuration (tnac4o.py:381-551).  Results are stored in
         energy, degeneracy, states, probability (log2), discarded_probability, negative_probability.
-        ``trace`` (a list) receives (ny, nx, Pn table, minPn, vind) of every site-step when given (parity tests)."""
+        ``trace`` (a list) receives (ny, nx, Pn table, minPn, vind) of every site-step when given (parity tests).
+        ``beam_group`` (a torch.distributed group): the ranks of the group work on this one solve together -- the first
+        computes the sweep, every site-step's branches are split between them (parallel.gather_branch_tables) and each
+        rank ends with the complete, identical result."""
+        from . import parallel
         self.logger.info('Searching ground state with beta = %.2f', self.beta)
-        self._setup_rhoT(graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps)
+        kw_sweep = dict(graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps)
+        if beam_group is None:
+            self._setup_rhoT(**kw_sweep)
+        else:
+            self._setup_rhoT_shared(beam_group, **kw_sweep)
         Nx, Ny = self.Nx, self.Ny
         vind = np.zeros((1, Nx + 1), dtype=self.indtype)
         states = np.zeros((1, Nx * Ny), dtype=self.indtype)
@@ -513,12 +542,13 @@ class tnac4o:
                 skeys, RR = levels[Nx - nx - 1]
                 _, suf = _unique_rows(np.vstack([skeys, vind[:, nx + 2:]]))
                 suf = suf[len(skeys):]
-                P, mP = ops.calc_pn(T1, RR, F, dmap, rmap, _dev_i32(pref), _dev_i32(suf), _dev_i32(vind[:, nx]),
-                                    _dev_i32(vind[:, nx + 1]))
-                newprob = P.cpu().numpy()
-                minprob = float(mP.min().item())
+                def pn_slice(lo, hi):                                        # K8 on the branches lo..hi-1
+                    return ops.calc_pn(T1, RR, F, dmap, rmap, _dev_i32(pref[lo:hi]), _dev_i32(suf[lo:hi]),
+                                       _dev_i32(vind[lo:hi, nx]), _dev_i32(vind[lo:hi, nx + 1]))
+                newprob, mP = parallel.gather_branch_tables(pn_slice, nb, q, beam_group)
+                minprob = float(mP.min())
                 if trace is not None:
-                    trace.append((ny, nx, newprob.copy(), mP.cpu().numpy(), vind.copy()))
+                    trace.append((ny, nx, newprob.copy(), mP.copy(), vind.copy()))
 
                 with np.errstate(divide='ignore'):
                     newprob = np.log2(newprob)
