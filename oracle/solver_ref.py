@@ -536,6 +536,63 @@ class RefSolver:
         return Eng
 
     # ------------------------------------------------------------------ output
+    def gibbs_sampling(self, M=2 ** 10, graduate_truncation=True, Dmax=32, tolS=1e-15, tolV=1e-10, max_sweeps=20):
+        """Gibbs sampling cell by cell (tnac4o.py:553-650); numpy's global generator, one rand(M) per cell."""
+        self._setup_rhoT(graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV,
+                         max_sweeps=max_sweeps)
+        Nx, Ny = self.Nx, self.Ny
+        vind = np.zeros((M, Nx + 1), dtype=int)
+        states = np.zeros((M, Nx * Ny), dtype=int)
+        Eng = np.zeros(M)
+        globalmin = 1.0
+        for ny in range(Ny):
+            RRl = self._setup_RR(vind, ny)
+            RLl = {(): np.ones(1)}
+            top = self.rhoT[ny + 1]
+            for nx in range(Nx):
+                q = self.N[ny][nx]
+                F, dmap, rmap, _, _ = self.peps_factor(ny, nx)
+                newprob = np.zeros((M, q))
+                minprob = np.zeros(M)
+                seen = {}
+                for kk in range(M):                                          # :601-612
+                    t = tuple(vind[kk])
+                    if t in seen:
+                        newprob[kk] = newprob[seen[t]]
+                        minprob[kk] = minprob[seen[t]]
+                    else:
+                        seen[t] = kk
+                        newprob[kk], minprob[kk] = self.conditional_probabilities(
+                            F[:, t[nx], t[nx + 1]], dmap, rmap, RLl[t[:nx]], top.A[nx], RRl[Nx - nx - 1][t[nx + 2:]])
+                minprob = np.min(minprob)
+                newprob = newprob.cumsum(axis=1)                             # :616-622
+                rr = np.random.rand(M)
+                indc = np.zeros(M, dtype=int)
+                for kk in range(M):
+                    indc[kk] = np.searchsorted(newprob[kk], rr[kk])
+                states[:, ny * Nx + nx] = indc
+                vind[:, nx] = self._ind_bond_down(indc, ny, nx)
+                vind[:, nx + 1] = self._ind_bond_right(indc, ny, nx)
+                Eng += self._update_Eng(states, ny, nx)
+                RLnew = {}                                                   # :628-636
+                for row in vind:
+                    t = tuple(row[:nx + 1])
+                    if t not in RLnew:
+                        r = np.dot(RLl[t[:-1]], top.A[nx][:, t[-1], :])
+                        r *= 1 / mr.pow2_floor_max(r)
+                        RLnew[t] = r
+                RLl = RLnew
+                globalmin = min(globalmin, minprob)
+            vind[:, 1:] = vind[:, :-1]
+            vind[:, 0] = 0
+        self.energy = Eng
+        self.degeneracy = 0
+        self.states = states[:, self.order]
+        self.probability = np.zeros(1)
+        self.discarded_probability = 0
+        self.negative_probability = min(globalmin, 0)
+        return Eng
+
     def binary_states(self, number=-1):
         """tnac4o.py:261-288: 1 = spin up, 0 = spin down, 2 = inactive."""
         ns = self.states.shape[0]

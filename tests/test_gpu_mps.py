@@ -368,3 +368,21 @@ def test_beam_sharded_product_path_two_ranks():
     assert outs[0]['probability'] == pytest.approx(float(s.probability[0]), abs=1e-12)
     E, _ = gi.golden_groundstate(128, 1)
     assert outs[0]['energy'] == pytest.approx(E, abs=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rot,chi,M,seed', [(0, 16, 64, 1234), (1, 8, 32, 99)])
+def test_gibbs_sampling_golden(rot, chi, M, seed):
+    """Gibbs sampling (tnac4o.py:553-650) on the HIP path draws the reference's configurations for a seeded run
+    (the conditional tables agree to ~1e-12, so a uniform draw would have to fall that close to a boundary to differ)."""
+    g = load('g8_gibbs.npz')
+    tag = 'r%d_chi%d_M%d_seed%d' % (rot, chi, M, seed)
+    s = gpu_solver(rot=rot)
+    np.random.seed(seed)
+    E = s.gibbs_sampling(M=M, Dmax=chi)
+    assert len(s.states) == M
+    assert np.array_equal(np.asarray(s.states).astype(np.int64), g[tag + '_states'].astype(np.int64))
+    np.testing.assert_allclose(E, g[tag + '_energy'], rtol=0, atol=1e-10)
+    assert np.array_equal(s.binary_states(), g[tag + '_bits'])
+    from tnac4o_amd import auxx
+    assert np.abs(auxx.energy_Jij(gi.droplet_J(128, 1), s.binary_states()) - E).max() < 1e-6

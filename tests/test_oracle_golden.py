@@ -224,3 +224,19 @@ def test_g7_L512():
     E, bits = gi.golden_groundstate(512, 1)
     assert s.energy[0] == pytest.approx(E, abs=1e-5)
     assert np.array_equal(s.binary_states()[0], bits)
+
+
+# ---------------------------------------------------------------- G8: Gibbs sampling
+@pytest.mark.parametrize('rot,chi,M,seed', [(0, 16, 64, 1234), (1, 8, 32, 99)])
+def test_g8_gibbs_sampling(rot, chi, M, seed):
+    g = load('g8_gibbs.npz')
+    tag = 'r%d_chi%d_M%d_seed%d' % (rot, chi, M, seed)
+    s = solver(rot=rot)
+    np.random.seed(seed)
+    E = s.gibbs_sampling(M=M, Dmax=chi)
+    assert np.array_equal(np.asarray(s.states), g[tag + '_states'])          # same draws, same configurations
+    np.testing.assert_allclose(E, g[tag + '_energy'], rtol=0, atol=1e-10)
+    assert np.array_equal(s.binary_states(), g[tag + '_bits'])
+    assert s.negative_probability == pytest.approx(float(g[tag + '_neg'][0]), abs=1e-12)
+    # the reference's own consistency check (examples/test_examples.py:36-56): energies recomputed from the bit strings
+    assert np.abs(sr.energy_Jij(gi.droplet_J(128, 1), s.binary_states()) - E).max() < 1e-6

@@ -9,4 +9,4 @@ gfx950); importing works without a GPU, running anything does not.
 """
 from .auxx import load_Jij, round_Jij, minus_Jij, Jij_f2p, energy_Jij, energy_RMF  # noqa: F401
 from . import mps  # noqa: F401
-from .tnac4o import tnac4o  # noqa: F401
+from .tnac4o import tnac4o, load  # noqa: F401

@@ -51,6 +51,26 @@ def energy_RMF(J, states):
     return E
 
 
+def save_states_txt(file_name, energies, bit_strings):
+    """States as text, one per line: energy then the bit string (1 = spin up, 0 = spin down) -- the format of the
+    reference's sampling / search scripts (examples/e02_sample_droplet_instances.py:125-134)."""
+    bit_strings = np.asarray(bit_strings)
+    L = bit_strings.shape[1]
+    with open(file_name, 'w') as f:
+        print("# One line per state; First column is the energy, the rest is a state; \
+                1 = spin up = si=+1; 0 = spin down = si=-1", file=f)
+        for E, st in zip(energies, bit_strings):
+            row = np.zeros(L + 1)
+            row[0], row[1:] = E, st
+            np.savetxt(f, row.reshape(1, L + 1), fmt=' '.join(['%4.6f'] + ['%i'] * L), delimiter=' ')
+
+
+def load_states_txt(file_name):
+    """Inverse of save_states_txt: (energies, bit strings)."""
+    a = np.atleast_2d(np.loadtxt(file_name, comments='#'))
+    return a[:, 0], a[:, 1:].astype(np.int8)
+
+
 def synthetic_chimera(Nx, Ny, seed):
     """Seeded chimera couplings with the droplet instances' topology: per cell 8 fields,
     K4,4 between spins {0..3} and {4..7}, spins 0-3 couple downwards, 4-7 to the right; values are

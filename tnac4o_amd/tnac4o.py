@@ -93,6 +93,29 @@ def _merge_groups(inv, Eng, prob, deg, min_dEng):
     return indn, degn, probn
 
 
+def load(file_name):
+    """Load a solution written by `tnac4o.save` -- by this package or by the reference (same .npy pickle of a dict,
+    tnac4o.py:31-75).  Couplings are not stored, so the returned instance only carries the results (energy, states, ...)
+    and what `binary_states` needs."""
+    d = np.load(file_name, allow_pickle=True).item()
+    ins = tnac4o(mode=d.get('mode'), Nx=d.get('Nx'), Ny=d.get('Ny'), Nc=d.get('Nc'), beta=d.get('beta'))
+    for k in ('energy', 'probability', 'degeneracy', 'states', 'discarded_probability', 'negative_probability'):
+        setattr(ins, k, d.get(k))
+    if d.get('rotation') is not None:
+        ins.rotation = d.get('rotation')
+    if ins.mode == 'Ising':
+        ins.ind0 = d.get('ind')
+        ins.adj = np.zeros((0, 0))
+    else:
+        ins.ind0, ins.adj = [], []
+    if d.get('excitations_encoding') is not None:          # droplet bookkeeping of the reference (:64-74): carried over
+        for k in ('excitations_encoding', 'd', 'invd', 'el', 'free_d'):
+            setattr(ins, k, d.get(k))
+        if ins.excitations_encoding > 1 and ins.mode == 'Ising':
+            ins.adj = d.get('adj')
+    return ins
+
+
 class tnac4o:
     """Ising ('Ising') or Random-Markov-Field ('RMF') problem on an Nx x Ny lattice of cells (tnac4o.py:145-198)."""
 
@@ -121,6 +144,7 @@ class tnac4o:
         self.states = np.zeros((0, Nx * Ny), dtype=self.indtype)
         self.discarded_probability = -np.inf
         self.negative_probability = 0.0
+        self.ind0, self.J0 = [], []
         if J is not None:
             if mode == 'Ising':
                 Jd = np.zeros((self.L, self.L))              # upper triangular accumulation (tnac4o.py:176-181)
@@ -606,6 +630,66 @@ class tnac4o:
         self.negative_probability = min(globalmin, 0)
         return Eng
 
+    def gibbs_sampling(self, M=2 ** 10, graduate_truncation=True, Dmax=32, tolS=1e-15, tolV=1e-10, max_sweeps=20):
+        """Draw M configurations from the Boltzmann distribution, cell by cell from the conditional probabilities of the
+        boundary-MPS contraction (tnac4o.py:553-650).  Uses numpy's global generator like the reference (np.random.rand,
+        one vector of M numbers per cell), so a seeded run draws the same configurations.  Stores energy (M,), states
+        (M, Nx*Ny), negative_probability; returns the sampled energies."""
+        self.logger.info('Sampling with beta = %.2f', self.beta)
+        self._setup_rhoT(graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps)
+        Nx, Ny = self.Nx, self.Ny
+        vind = np.zeros((M, Nx + 1), dtype=np.int64)           # plain ints here, as in the reference (:584-585)
+        states = np.zeros((M, Nx * Ny), dtype=np.int64)
+        Eng = np.zeros(M)
+        globalmin = 1.0
+        dev = self.rhoT[0].A[0].device
+        for ny in range(Ny):
+            self.logger.info('Row %d / %d', ny + 1, Ny)
+            levels = self._setup_RR(vind, ny)
+            top = self.rhoT[ny + 1]
+            pkeys = np.zeros((1, 0), dtype=vind.dtype)
+            RL = torch.ones((1, 1), dtype=torch.float64, device=dev)
+            for nx in range(Nx):
+                q = int(self.N[ny][nx])
+                F, dmap, rmap, _, _ = self._peps_factor_dev(ny, nx)
+                AT = top.A[nx]
+                Dl, p, Dr = AT.shape
+                T1 = ops.mm(RL, AT.view(Dl, p * Dr)).view(-1, p, Dr)
+                # distinct boundary configurations only (the reference's `seen` dictionary, :601-612)
+                uvind, uinv = _unique_rows(vind)
+                _, pref = _unique_rows(np.vstack([pkeys, uvind[:, :nx]]))
+                pref = pref[len(pkeys):]
+                skeys, RR = levels[Nx - nx - 1]
+                _, suf = _unique_rows(np.vstack([skeys, uvind[:, nx + 2:]]))
+                suf = suf[len(skeys):]
+                P, mP = ops.calc_pn(T1, RR, F, dmap, rmap, _dev_i32(pref), _dev_i32(suf), _dev_i32(uvind[:, nx]),
+                                    _dev_i32(uvind[:, nx + 1]))
+                newprob = P.cpu().numpy()[uinv]
+                minprob = float(mP.min().item())
+                newprob = newprob.cumsum(axis=1)                             # :616-622
+                rr = np.random.rand(M)
+                indc = np.array([np.searchsorted(newprob[kk], rr[kk]) for kk in range(M)], dtype=np.int64)
+                states[:, ny * Nx + nx] = indc
+                vind[:, nx] = self._ind_bond_down(indc, ny, nx)
+                vind[:, nx + 1] = self._ind_bond_right(indc, ny, nx)
+                Eng += self._update_Eng(states, ny, nx)
+                nkeys, _ = _unique_rows(vind[:, :nx + 1])                    # left environments (:628-636)
+                _, par = _unique_rows(np.vstack([pkeys, nkeys[:, :nx]]))
+                par = par[len(pkeys):]
+                RL = T1[torch.as_tensor(par, device=dev), torch.as_tensor(nkeys[:, nx].astype(np.int64), device=dev)].contiguous()
+                ops.nfactor_batched_(RL)
+                pkeys = nkeys
+                globalmin = min(globalmin, minprob)
+            vind[:, 1:] = vind[:, :-1]
+            vind[:, 0] = 0
+        self.energy = Eng
+        self.degeneracy = 0
+        self.states = states[:, self.order]
+        self.probability = np.zeros(1)
+        self.discarded_probability = 0
+        self.negative_probability = min(globalmin, 0)
+        return Eng
+
     # ------------------------------------------------------------------------------------ output
     def binary_states(self, number=-1):
         """Bit strings: 1 spin up, 0 spin down, 2 inactive (tnac4o.py:261-288)."""
@@ -621,6 +705,30 @@ class tnac4o:
                 act = self.ind0[ny][nx]
                 out[:, act] = (1 - _bits(len(act)))[self.states[:ns, k]]
         return out
+
+    def save(self, file_name):
+        """Save the solution to a .npy file readable by `load` here and by the reference's `tnac4o.load`
+        (tnac4o.py:200-231: a pickled dict with these keys)."""
+        d = {'mode': self.mode, 'rotation': self.rotation, 'energy': self.energy, 'probability': self.probability,
+             'degeneracy': self.degeneracy, 'states': self.states, 'discarded_probability': self.discarded_probability,
+             'negative_probability': self.negative_probability, 'Nx': self.Nx_model, 'Ny': self.Ny_model, 'Nc': self.Nc,
+             'beta': self.beta}
+        if self.mode == 'Ising':
+            d['ind'] = self.ind0
+        if hasattr(self, 'excitations_encoding'):
+            for k in ('excitations_encoding', 'd', 'invd', 'el', 'free_d'):
+                d[k] = getattr(self, k)
+            if self.excitations_encoding > 1 and self.mode == 'Ising':
+                import scipy.sparse
+                d['adj'] = scipy.sparse.csr_matrix(self.adj)
+        np.save(file_name, d)
+
+    def show_properties(self):
+        """tnac4o.py:233-241."""
+        print("L:     ", self.L)
+        print("Ny:    ", self.Ny)
+        print("Nx:    ", self.Nx)
+        print("Beta:  ", self.beta)
 
     def show_solution(self, state=False):
         """tnac4o.py:244-259."""

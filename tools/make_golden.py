@@ -4,7 +4,7 @@
 Runs ONLY in the authoring container (needs /root/reference); neither the tests nor the GPU
 box ever import the reference.  Inputs come from tests/golden_inputs.py (seeded) or from the
 reference's own instance files copied under tests/golden/instances/.  Outputs are data only
-(SURVEY.md §8c G1-G7).  Usage:  python tools/make_golden.py [g1 g2 ... g7]
+(G8 = Gibbs sampling, §8f-2).  Usage:  python tools/make_golden.py [g1 g2 ... g8]
 """
 import json
 import os
@@ -253,8 +253,31 @@ def g7():
         json.dump(res, f, indent=0)
 
 
+def g8():
+    """Gibbs sampling (tnac4o.py:553-650, examples/e02): seeded numpy global generator, droplet L=128 #1."""
+    out = {}
+    for rot, chi, M, seed in ((0, 16, 64, 1234), (1, 8, 32, 99)):
+        s = solver(128, 1, rot)
+        np.random.seed(seed)
+        E = s.gibbs_sampling(M=M, Dmax=chi)
+        tag = 'r%d_chi%d_M%d_seed%d' % (rot, chi, M, seed)
+        out[tag + '_energy'] = np.asarray(E)
+        out[tag + '_states'] = np.asarray(s.states).astype(np.int16)
+        out[tag + '_bits'] = np.asarray(s.binary_states()).astype(np.int8)
+        out[tag + '_neg'] = np.array([s.negative_probability])
+    save('g8_gibbs.npz', **out)
+
+
+def g9():
+    """A result file written by the reference's own `save` (tnac4o.py:200-231) -- data for the I/O compatibility test."""
+    s = solver(128, 1, 1)
+    s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=8)
+    s.save(os.path.join(OUT, 'g9_saved_by_reference.npy'))
+    print('saved', s.energy[0], len(s.energy))
+
+
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+    todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
     for name in todo:
         t = time.time()
         globals()[name]()
