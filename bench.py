@@ -225,6 +225,22 @@ def main():
                          'algorithmic_bytes_per_launch': d['bytes'] / max(1, d['calls']),
                          'note': 'single-workgroup LDS-resident Jacobi step: latency-bound, far from either roofline'
                                  if d['kernel'].startswith('eig_small') or d['kernel'].startswith('tsqr') else ''})
+            # HBM traffic from the PMC counters: rocprofv3's counter mode crashes on this multi-threaded bench, so the
+            # FETCH_SIZE / WRITE_SIZE passes are taken on tools/pmc_probe.py (the same kernels at the bulk shapes of this
+            # workload) and committed under profiles/; the figure is per launch of the probe, next to the probe's own
+            # algorithmic bytes per launch.
+            try:
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['families'].get(d['kernel'])
+            except (OSError, ValueError, KeyError):
+                pm = None
+            if pm:
+                roof['traffic'] = pm['traffic_bytes_per_launch']
+                roof['traffic_detail'] = {
+                    'unit': 'bytes per launch', 'source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                    'separate passes, FETCH_SIZE x2 per the gfx950 correction) on tools/pmc_probe.py: tn_qr 16384 x 1024',
+                    'fetch': pm['fetch_bytes_per_launch'], 'write': pm['write_bytes_per_launch'],
+                    'algorithmic_bytes_per_launch_same_probe': pm.get('algorithmic_bytes_per_launch'),
+                    'traffic_over_algorithmic': pm.get('traffic_over_algorithmic')}
             out['roofline'] = roof
             table = warm_prof if warm_prof is not None else prof
             nsw = 1 if warm_prof is not None else args.steps * G

@@ -158,13 +158,20 @@ __global__ __launch_bounds__(256) void lu_reconstruct_kernel(double* __restrict_
     }
 }
 
-// rows r < nrows:  x = X(r, :b);  X(r,:) <- x S0 (in place),  W1(r,:) <- x S1,  W2(r,:) <- x S2   (all b x b, row-major)
+// rows r < nrows:  x = X(r, :b);  X(r,:) <- x S0 (in place),  W1(r,:) <- x S1,  W2(r,:) <- x S2   (all b x b, row-major).
+// One workgroup per 256 rows.  Row-major operands (cs == 1) go through an LDS tile so that global loads and stores are
+// full 256-byte rows (a thread writing its own row element by element costs 5x the bytes in partial-line writes:
+// WRITE_SIZE 65.7 MB vs 12.6 MB algorithmic on the 16384 x 32 panel, profiles/r01_pmc_*); column-major operands are
+// already coalesced across the threads of a wave.
 template <int NB>
 __global__ __launch_bounds__(256) void rows_times_small3_kernel(double* __restrict__ X, int64_t rs, int64_t cs, int64_t nrows,
                                                                 int b, const double* __restrict__ S0, const double* __restrict__ S1,
                                                                 const double* __restrict__ S2, double* __restrict__ W1, int64_t w1rs,
                                                                 int64_t w1cs, double* __restrict__ W2) {
+    constexpr int P = NB + 1;
+    constexpr bool STAGE = (NB == 32);                   // the 64-wide (first-generation) panels keep the direct form
     __shared__ double Ss[3][NB * NB];
+    __shared__ double tile[STAGE ? 256 * P : 1];
     const int tid = threadIdx.x;
     for (int e = tid; e < NB * NB; e += 256) {
         const int i = e / NB, j = e % NB;
@@ -173,23 +180,114 @@ __global__ __launch_bounds__(256) void rows_times_small3_kernel(double* __restri
         Ss[1][e] = in ? S1[i * b + j] : 0.0;
         Ss[2][e] = in ? S2[i * b + j] : 0.0;
     }
-    __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * 256 + tid;
-    if (r >= nrows) return;
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int nr = (int)((nrows - r0 < 256) ? nrows - r0 : 256);
+    const int64_t r = r0 + tid;
+    const bool live = tid < nr;
+    const bool xrow = STAGE && (cs == 1), wrow = STAGE && (w1cs == 1);
     double x[NB];
+    if (xrow) {
+        for (int e = tid; e < nr * b; e += 256) tile[(e / b) * P + e % b] = X[(r0 + e / b) * rs + e % b];
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NB; ++i) x[i] = (i < b) ? X[r * rs + i * cs] : 0.0;
-    for (int j = 0; j < b; ++j) {
-        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+        for (int i = 0; i < NB; ++i) x[i] = (live && i < b) ? tile[tid * P + i] : 0.0;
+    } else {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            y0 += x[i] * Ss[0][i * NB + j];
-            y1 += x[i] * Ss[1][i * NB + j];
-            y2 += x[i] * Ss[2][i * NB + j];
+        for (int i = 0; i < NB; ++i) x[i] = (live && i < b) ? X[r * rs + i * cs] : 0.0;
+    }
+    __syncthreads();                                     // Ss complete; tile free again
+#pragma unroll 1
+    for (int o = 0; o < 3; ++o) {
+        double* dst = (o == 0) ? X : (o == 1) ? W1 : W2;
+        const int64_t drs = (o == 1) ? w1rs : rs, dcs = (o == 1) ? w1cs : cs;
+        const bool drow = (o == 1) ? wrow : xrow;
+        const double* Sm = Ss[o];
+        if (drow) {
+            for (int j = 0; j < b; ++j) {
+                double y = 0.0;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) y += x[i] * Sm[i * NB + j];
+                tile[tid * P + j] = y;
+            }
+            __syncthreads();
+            for (int e = tid; e < nr * b; e += 256) dst[(r0 + e / b) * drs + e % b] = tile[(e / b) * P + e % b];
+            __syncthreads();
+        } else if (live) {
+            for (int j = 0; j < b; ++j) {
+                double y = 0.0;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) y += x[i] * Sm[i * NB + j];
+                dst[r * drs + j * dcs] = y;
+            }
         }
-        X[r * rs + j * cs] = y0;
-        W1[r * w1rs + j * w1cs] = y1;
-        W2[r * rs + j * cs] = y2;
+    }
+}
+
+// MFMA form of rows_times_small3 for 32-wide panels: one workgroup per 256 rows computes the (256 x 32) . (32 x 96)
+// product [x S0 | x S1 | x S2] on v_mfma_f64_16x16x4_f64 (wave w owns rows 64w .. 64w+63 = 4 row tiles; its A fragments
+// are read from the LDS tile once and kept in registers, so the tile can stage the three outputs one after the other).
+// Every global access is a coalesced pass over the tile, whatever the operand layout.
+typedef double d4q __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void rows_times_small3_mfma_kernel(double* __restrict__ X, int64_t rs, int64_t cs, int64_t nrows,
+                                                                     int b, const double* __restrict__ S0,
+                                                                     const double* __restrict__ S1, const double* __restrict__ S2,
+                                                                     double* __restrict__ W1, int64_t w1rs, int64_t w1cs,
+                                                                     double* __restrict__ W2) {
+    constexpr int NB = 32, P = 36;
+    __shared__ double Ss[3][NB * NB];
+    __shared__ double tile[256 * P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        const bool in = (i < b && j < b);
+        Ss[0][e] = in ? S0[i * b + j] : 0.0;
+        Ss[1][e] = in ? S1[i * b + j] : 0.0;
+        Ss[2][e] = (in && S2) ? S2[i * b + j] : 0.0;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int nr = (int)((nrows - r0 < 256) ? nrows - r0 : 256);
+    // coalesced load of the (nr x b) block: the fast index of e follows the operand's unit stride
+    const bool xrow = (cs == 1);
+    for (int e = tid; e < 256 * NB; e += 256) {
+        const int i = xrow ? e / NB : e % 256, j = xrow ? e % NB : e / 256;
+        tile[i * P + j] = (i < nr && j < b) ? X[(r0 + i) * rs + j * cs] : 0.0;
+    }
+    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;
+    double fa[4][8];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) fa[mt][ks] = tile[(wave * 64 + mt * 16 + li) * P + ks * 4 + lk];
+    __syncthreads();
+#pragma unroll 1
+    for (int o = 0; o < 3; ++o) {
+        double* dst = (o == 0) ? X : (o == 1) ? W1 : W2;
+        if (dst == nullptr) continue;                    // uniform
+        const int64_t drs = (o == 1) ? w1rs : rs, dcs = (o == 1) ? w1cs : cs;
+        const double* Sm = Ss[o];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            double fb[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) fb[ks] = Sm[(ks * 4 + lk) * NB + nt * 16 + li];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                d4q acc = d4q{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[mt][ks], fb[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tile[(wave * 64 + mt * 16 + lk + 4 * r) * P + nt * 16 + li] = acc[r];
+            }
+        }
+        __syncthreads();
+        const bool drow = (dcs == 1);
+        for (int e = tid; e < 256 * NB; e += 256) {
+            const int i = drow ? e / NB : e % 256, j = drow ? e % NB : e / 256;
+            if (i < nr && j < b) dst[(r0 + i) * drs + j * dcs] = tile[i * P + j];
+        }
+        __syncthreads();
     }
 }
 
@@ -477,7 +575,7 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
             dim3 grid((unsigned)cdiv(mp - b, 256));
             prof_begin(st, PROF_ROWS_SMALL);
             if (nb == 32)
-                hipLaunchKernelGGL((rows_times_small3_kernel<32>), grid, dim3(256), 0, st, sub(Yp, b, 0).p, yrs, ycs, mp - b, b,
+                hipLaunchKernelGGL(rows_times_small3_mfma_kernel, grid, dim3(256), 0, st, sub(Yp, b, 0).p, yrs, ycs, mp - b, b,
                                    w.Uinv, w.UT, w.UTq, sub(Wp, b, 0).p, wrs, wcs, sub(Wqp, b, 0).p);
             else
                 hipLaunchKernelGGL((rows_times_small3_kernel<64>), grid, dim3(256), 0, st, sub(Yp, b, 0).p, yrs, ycs, mp - b, b,
