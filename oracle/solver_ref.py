@@ -417,12 +417,13 @@ class RefSolver:
 
     def search_ground_state(self, M=2 ** 10, relative_P_cutoff=1e-6, min_dEng=1e-12, graduate_truncation=True,
                             Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20, trace=None, sweep_hook=None,
-                            pn_gather=None):
+                            pn_gather=None, merge_hook=None):
         """Row-major branch-and-bound (tnac4o.py:381-551).  ``trace`` (a list) receives the
         (ny, nx, newprob, minprob) tables of every site-step when given (for golden checks).
         ``sweep_hook(solver, run_sweep)`` / ``pn_gather(compute, nb, q)``: optional injection points used by the CPU
         multi-rank tests to wrap the sweep and the per-branch table in the product's sharding helpers; with both None
-        this is the plain reference algorithm."""
+        this is the plain reference algorithm.  ``merge_hook(site, parents, order, starts, Eng, prob, states, rep, probn,
+        selected)`` is told about every merge (the droplet bookkeeping of tnac4o.py:843-873 plugs in here in the tests)."""
         M_ = M
         kw_sweep = dict(graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps)
         if sweep_hook is None:
@@ -505,14 +506,19 @@ class RefSolver:
                         degn[k] = deg[same][0]
                         probn[k] = prob[same][0]
                     lo += sz
+                sel = None
+                if probn.size > M_:                                         # :518-526
+                    sel = probn.argpartition(-M_ - 1)
+                    pd_max = max(pd_max, probn[sel[-M_ - 1]])
+                    sel = sel[-M_:]
+                if merge_hook is not None:
+                    starts = np.cumsum([0] + sizes[:-1])
+                    merge_hook(ny * Nx + nx, inds, order, starts, Eng, prob, states, indn, probn,
+                               np.arange(n_grp) if sel is None else sel)
                 vind, prob, deg = vindn, probn, degn
                 states, Eng = states[indn], Eng[indn]
-
-                if prob.size > M_:                                          # :518-526
-                    order = prob.argpartition(-M_ - 1)
-                    pd_max = max(pd_max, prob[order[-M_ - 1]])
-                    order = order[-M_:]
-                    vind, states, prob, Eng, deg = vind[order], states[order], prob[order], Eng[order], deg[order]
+                if sel is not None:
+                    vind, states, prob, Eng, deg = vind[sel], states[sel], prob[sel], Eng[sel], deg[sel]
 
                 RLnew = {}                                                  # :528-535
                 for row in vind:

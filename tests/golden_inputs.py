@@ -66,6 +66,23 @@ def golden_groundstate(L, instance):
     return float(line[2]), np.array([int(x) for x in line[3:]], dtype=np.int8)
 
 
+def e05_rmf():
+    """The model of the reference's minimal RMF example (examples/e05_minimal_RMF.py:33-53, pinned by test_examples.py
+    test_e05: 26 states within dE < 3.1): a 3 x 5 grid of 3-state variables, a unit penalty whenever neighbours differ,
+    and linear fields -1.5, 0, 1.5 on the outer rows / 1.25, 0, -1.25 on the middle row."""
+    Ny, Nx, d = 3, 5, 3
+    fun = {1: 1.0 - np.eye(d), 2: np.array([-1.5, 0.0, 1.5]), 3: np.array([1.25, 0.0, -1.25])}
+    fac = {}
+    for ny in range(Ny):
+        for nx in range(Nx):
+            fac[(ny, nx)] = 3 if ny == 1 else 2
+            if nx + 1 < Nx:
+                fac[(ny, nx, ny, nx + 1)] = 1
+            if ny + 1 < Ny:
+                fac[(ny, nx, ny + 1, nx)] = 1
+    return {'fun': fun, 'fac': fac, 'N': np.full((Ny, Nx), d, dtype=int), 'Nx': Nx, 'Ny': Ny}
+
+
 def minimal_rmf():
     """3x5 RMF with d=3 mirroring the structure of examples/e05 (seeded tables)."""
     rng = np.random.default_rng(5)

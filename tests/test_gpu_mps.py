@@ -386,3 +386,50 @@ def test_gibbs_sampling_golden(rot, chi, M, seed):
     assert np.array_equal(s.binary_states(), g[tag + '_bits'])
     from tnac4o_amd import auxx
     assert np.abs(auxx.energy_Jij(gi.droplet_J(128, 1), s.binary_states()) - E).max() < 1e-6
+
+
+def _spectrum_same(s, g, tag, bits=True):
+    assert len(s.energy) == len(g[tag + '_energy'])
+    np.testing.assert_allclose(s.energy, g[tag + '_energy'], rtol=0, atol=1e-9)
+    got = s.binary_states() if bits else np.asarray(s.states)
+    want = g[tag + ('_bits' if bits else '_states')]
+    assert sorted(map(bytes, np.asarray(got, dtype=np.int16))) == sorted(map(bytes, np.asarray(want, dtype=np.int16)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rot,chi', [(0, 16), (1, 16), (3, 8)])
+def test_low_energy_spectrum_golden(rot, chi, tmp_path):
+    """search_low_energy_spectrum (encoding 1) + decode on the HIP path: the reference's 31 states within dE < 1 of
+    droplet instance 1 (examples/test_examples.py test_e03), same energies and bit strings; result file round trip."""
+    import tnac4o_amd
+    g = load('g10_spectrum.npz')
+    s = gpu_solver(rot=rot)
+    s.search_low_energy_spectrum(excitations_encoding=1, M=1024, relative_P_cutoff=1e-8, Dmax=chi, max_dEng=1.0, lim_hd=0)
+    tag = 'L128_i1_r%d_chi%d' % (rot, chi)
+    assert [len(s.d), len(s.el)] == list(g[tag + '_n_shapes'])
+    f = str(tmp_path / 'spectrum.npy')
+    s.save(f)
+    s.decode_low_energy_states(max_dEng=1.0)
+    assert len(s.energy) == 31
+    _spectrum_same(s, g, tag)
+    t = tnac4o_amd.load(f)                                    # decode again from the saved forest
+    t.decode_low_energy_states(max_dEng=1.0)
+    assert np.array_equal(t.energy, s.energy) and np.array_equal(t.states, s.states)
+
+
+@pytest.mark.gpu
+def test_low_energy_spectrum_rmf_golden():
+    """examples/e05 (test_e05): 26 states within dE < 3.1 of the minimal RMF model, from two lattice rotations."""
+    import tnac4o_amd
+    g = load('g10_spectrum.npz')
+    J = gi.e05_rmf()
+    for rot in (0, 1):
+        s = tnac4o_amd.tnac4o(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=4)
+        if rot:
+            s.rotate_graph(rot)
+        s.search_low_energy_spectrum(excitations_encoding=1, M=1024, relative_P_cutoff=1e-12, Dmax=32, max_dEng=3.1, lim_hd=0)
+        s.decode_low_energy_states(max_dEng=3.1, max_states=100)
+        assert len(s.energy) == 26
+        _spectrum_same(s, g, 'RMF_r%d' % rot, bits=False)
+    with pytest.raises(NotImplementedError):
+        s.search_low_energy_spectrum(excitations_encoding=2)

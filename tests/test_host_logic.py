@@ -117,7 +117,7 @@ def test_fast_unique_and_merge_match_reference_semantics():
             else:
                 degn[k], probn[k] = deg[same][0], prob[same][0]
             lo += sz
-        a, b, c = _merge_groups(i1, Eng, prob, deg, min_dEng)
+        a, b, c, _, _ = _merge_groups(i1, Eng, prob, deg, min_dEng)
         assert np.array_equal(a, indn) and np.array_equal(b, degn) and np.array_equal(c, probn)
 
 
@@ -154,3 +154,68 @@ def test_states_text_format_round_trip(tmp_path):
     assert lines[1].split()[0] == '%4.6f' % E[0] and len(lines[1].split()) == 129
     E2, b2 = auxx.load_states_txt(f)
     assert np.allclose(E2, E, atol=1e-6) and np.array_equal(b2, bits)
+
+
+# ---------------------------------------------------------------- low-energy spectrum bookkeeping
+def _spectrum_check(s, g, tag, bits=True):
+    assert len(s.energy) == len(g[tag + '_energy'])
+    np.testing.assert_allclose(s.energy, g[tag + '_energy'], rtol=0, atol=1e-9)
+    # states with (numerically) equal energies may come out in either order: compare as sets per energy level
+    key = tag + ('_bits' if bits else '_states')
+    got = s.binary_states() if bits else np.asarray(s.states)
+    want = g[key]
+    assert sorted(map(bytes, np.asarray(got, dtype=np.int16))) == sorted(map(bytes, np.asarray(want, dtype=np.int16)))
+
+
+@pytest.mark.parametrize('rot,chi', [(0, 16), (3, 8)])
+def test_spectrum_encoding1_droplet_golden(rot, chi):
+    """examples/test_examples.py test_e03 (31 states within dE < 1 of droplet instance 1), encoding 1."""
+    import golden_inputs as gi
+    from spectrum_ref import SpectrumRef
+    g = np.load(os.path.join(gi.GOLDEN_DIR, 'g10_spectrum.npz'))
+    s = SpectrumRef(mode='Ising', Nx=4, Ny=4, Nc=8, J=gi.droplet_J(128, 1), beta=3.0)
+    if rot:
+        s.rotate_graph(rot)
+    s.search_low_energy_spectrum(excitations_encoding=1, M=1024, relative_P_cutoff=1e-8, Dmax=chi, max_dEng=1.0, lim_hd=0)
+    tag = 'L128_i1_r%d_chi%d' % (rot, chi)
+    assert [len(s.d), len(s.el)] == list(g[tag + '_n_shapes'])
+    s.decode_low_energy_states(max_dEng=1.0)
+    assert len(s.energy) == 31
+    _spectrum_check(s, g, tag)
+    from oracle import solver_ref as sr
+    E = sr.energy_Jij(gi.droplet_J(128, 1), s.binary_states())
+    assert np.abs(E - s.energy).max() < 1e-6                  # every decoded state really has the energy it is listed with
+
+
+def test_spectrum_hamming_limit_and_rmf_golden():
+    import golden_inputs as gi
+    from spectrum_ref import SpectrumRef
+    g = np.load(os.path.join(gi.GOLDEN_DIR, 'g10_spectrum.npz'))
+    s = SpectrumRef(mode='Ising', Nx=4, Ny=4, Nc=8, J=gi.droplet_J(128, 2), beta=3.0)
+    s.search_low_energy_spectrum(excitations_encoding=1, M=1024, relative_P_cutoff=1e-8, Dmax=16, max_dEng=0.8, lim_hd=3)
+    s.decode_low_energy_states(max_dEng=0.8, max_states=20)
+    _spectrum_check(s, g, 'L128_i2_r0_chi16_hd3')
+    J = gi.e05_rmf()                                           # test_e05: 26 states within dE < 3.1
+    for rot in (0, 1):
+        s = SpectrumRef(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=4)
+        if rot:
+            s.rotate_graph(rot)
+        s.search_low_energy_spectrum(excitations_encoding=1, M=1024, relative_P_cutoff=1e-12, Dmax=32, max_dEng=3.1, lim_hd=0)
+        s.decode_low_energy_states(max_dEng=3.1, max_states=100)
+        assert len(s.energy) == 26
+        _spectrum_check(s, g, 'RMF_r%d' % rot, bits=False)
+
+
+def test_unpack_snake_small_forest():
+    """Hand-made forest: two droplets that do not overlap along the snake combine, a nested one needs its parent."""
+    from tnac4o_amd import droplets
+    a = ((0.5, 1, 6, 7, 0.0), ())                  # cells 6..7
+    inner = ((0.2, 3, 2, 2, 0.0), ())              # cell 2, only valid inside b
+    b = ((0.3, 2, 1, 3, 0.0), (inner,))            # cells 1..3
+    E, flips = droplets.unpack_snake([b, a], 8, max_dEng=10.0)
+    got = sorted((round(float(e), 6), tuple(sorted(f))) for e, f in zip(E, flips))
+    assert got == sorted([(0.0, ()), (0.5, (1,)), (0.3, (2,)), (0.5, (2, 3)), (0.8, (1, 2)), (1.0, (1, 2, 3))])
+    E, _ = droplets.unpack_snake([b, a], 8, max_dEng=0.55)
+    assert sorted(np.round(E, 6)) == [0.0, 0.3, 0.5, 0.5]
+    E, _ = droplets.unpack_snake([b, a], 8, max_dEng=10.0, max_states=3)
+    assert len(E) <= 3 and 0.0 in E

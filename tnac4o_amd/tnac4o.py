@@ -90,7 +90,7 @@ def _merge_groups(inv, Eng, prob, deg, min_dEng):
         hi = starts[k + 1] if k + 1 < n_grp else E.size
         same = order[lo:hi][near[lo:hi]]
         probn[k] = np.mean(prob[same])
-    return indn, degn, probn
+    return indn, degn, probn, order, starts
 
 
 def load(file_name):
@@ -526,10 +526,44 @@ class tnac4o:
                 self.rhoT.append(m)
             self.rhoT_overlap, self.rhoT_discarded = diag
 
+    def search_low_energy_spectrum(self, excitations_encoding=1, M=2 ** 10, relative_P_cutoff=1e-6, max_dEng=0., lim_hd=0,
+                                   min_dEng=1e-12, graduate_truncation=True, Dmax=32, tolS=1e-16, tolV=1e-10,
+                                   max_sweeps=20):
+        """Branch-and-bound search that also records the droplets of the branches it merges away, from which the
+        low-energy spectrum up to max_dEng is rebuilt by `decode_low_energy_states` (tnac4o.py:652-915, encoding 1:
+        droplet independence from the row-major order of the cells).  Returns the lowest energies found; stores the
+        same result attributes as search_ground_state plus the excitation forest `el` and the shape table `d`."""
+        from . import droplets
+        if excitations_encoding != 1:
+            raise NotImplementedError('excitations_encoding 2 and 3 (adjacency-based elementary droplets) are not built; '
+                                      'use excitations_encoding=1')
+        self.excitations_encoding = excitations_encoding
+        rec = droplets.ExcitationRecorder(max_dEng, lim_hd, self.mode)
+        Eng = self.search_ground_state(M=M, relative_P_cutoff=relative_P_cutoff, min_dEng=min_dEng,
+                                       graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV,
+                                       max_sweeps=max_sweeps, recorder=rec)
+        self.el, self.d = rec.finish(self.order_i)
+        self.invd = rec.shapes.semi_hash_index()
+        self.free_d = rec.shapes.next_id
+        return Eng
+
+    def decode_low_energy_states(self, max_dEng=0., max_states=1024):
+        """Turn the recorded excitation forest into explicit states, lowest energies first (tnac4o.py:1360-1389).
+        Replaces energy / states by the decoded spectrum; returns the lowest excitation energy (0)."""
+        from . import droplets
+        if getattr(self, 'excitations_encoding', 1) != 1:
+            raise NotImplementedError('only excitations_encoding=1 results can be decoded')
+        E, st = droplets.decode_states(self.states[0], self.el, self.d, self.Nx_model * self.Ny_model, max_dEng, max_states,
+                                       self.indtype)
+        self.energy = E + self.energy[0]
+        self.states = st
+        return E[0]
+
     def search_ground_state(self, M=2 ** 10, relative_P_cutoff=1e-6, min_dEng=1e-12, graduate_truncation=True,
-                            Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20, trace=None, beam_group=None):
+                            Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20, trace=None, beam_group=None, recorder=None):
         """Row-major branch-and-bound for the most probable configuration (tnac4o.py:381-551).  Results are stored in
         energy, degeneracy, states, probability (log2), discarded_probability, negative_probability.
+        ``recorder`` (droplets.ExcitationRecorder): told about every merge (search_low_energy_spectrum).
         ``trace`` (a list) receives (ny, nx, Pn table, minPn, vind) of every site-step when given (parity tests).
         ``beam_group`` (a torch.distributed group): the ranks of the group work on this one solve together -- the first
         computes the sweep, every site-step's branches are split between them (parallel.gather_branch_tables) and each
@@ -600,15 +634,19 @@ class tnac4o:
                 Eng += self._update_Eng(states, ny, nx)
 
                 vindn, inv = _unique_rows(vind)                              # merge equal boundaries (:481-515)
-                indn, degn, probn = _merge_groups(inv, Eng, prob, deg, min_dEng)
+                indn, degn, probn, gorder, gstarts = _merge_groups(inv, Eng, prob, deg, min_dEng)
+                sel = None
+                if probn.size > M:                                           # keep the M most probable (:518-526)
+                    sel = probn.argpartition(-M - 1)
+                    pd_max = max(pd_max, probn[sel[-M - 1]])
+                    sel = sel[-M:]
+                if recorder is not None:                                     # droplets of the merged-away branches
+                    recorder.merge_step(ny * Nx + nx, inds, gorder, gstarts, Eng, prob, states, indn, probn,
+                                        np.arange(probn.size) if sel is None else sel)
                 vind, prob, deg = vindn, probn, degn
                 states, Eng = states[indn], Eng[indn]
-
-                if prob.size > M:                                            # keep the M most probable (:518-526)
-                    order = prob.argpartition(-M - 1)
-                    pd_max = max(pd_max, prob[order[-M - 1]])
-                    order = order[-M:]
-                    vind, states, prob, Eng, deg = vind[order], states[order], prob[order], Eng[order], deg[order]
+                if sel is not None:
+                    vind, states, prob, Eng, deg = vind[sel], states[sel], prob[sel], Eng[sel], deg[sel]
 
                 # left environments of the new distinct prefixes: rows of T1 (tnac4o.py:528-535)
                 nkeys, _ = _unique_rows(vind[:, :nx + 1])

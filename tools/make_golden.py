@@ -276,8 +276,43 @@ def g9():
     print('saved', s.energy[0], len(s.energy))
 
 
+def g10():
+    """Low-energy spectrum, encoding 1 (tnac4o.py:652-915 + decode :1360-1389; examples e03 / e05, test_examples.py:59-138)."""
+    import pickle
+    out = {}
+    for rot, chi in ((0, 16), (1, 16), (3, 8)):
+        s = solver(128, 1, rot)
+        s.search_low_energy_spectrum(excitations_encoding=1, M=1024, relative_P_cutoff=1e-8, Dmax=chi, max_dEng=1.0, lim_hd=0)
+        tag = 'L128_i1_r%d_chi%d' % (rot, chi)
+        out[tag + '_n_shapes'] = np.array([len(s.d), len(s.el)])
+        s.decode_low_energy_states(max_dEng=1.0)
+        out[tag + '_energy'] = np.asarray(s.energy)
+        out[tag + '_states'] = np.asarray(s.states).astype(np.int16)
+        out[tag + '_bits'] = np.asarray(s.binary_states()).astype(np.int8)
+        print(tag, len(s.energy))
+    # a second instance with a Hamming-distance limit
+    s = solver(128, 2, 0)
+    s.search_low_energy_spectrum(excitations_encoding=1, M=1024, relative_P_cutoff=1e-8, Dmax=16, max_dEng=0.8, lim_hd=3)
+    s.decode_low_energy_states(max_dEng=0.8, max_states=20)
+    out['L128_i2_r0_chi16_hd3_energy'] = np.asarray(s.energy)
+    out['L128_i2_r0_chi16_hd3_bits'] = np.asarray(s.binary_states()).astype(np.int8)
+    print('hd3', len(s.energy))
+    # RMF minimal example (examples/e05_minimal_RMF.py)
+    J = gi.e05_rmf()
+    for rot in (0, 1):
+        s = ref.tnac4o(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=4)
+        if rot:
+            s.rotate_graph(rot)
+        s.search_low_energy_spectrum(excitations_encoding=1, M=1024, relative_P_cutoff=1e-12, Dmax=32, max_dEng=3.1, lim_hd=0)
+        s.decode_low_energy_states(max_dEng=3.1, max_states=100)
+        out['RMF_r%d_energy' % rot] = np.asarray(s.energy)
+        out['RMF_r%d_states' % rot] = np.asarray(s.states).astype(np.int16)
+        print('RMF', rot, len(s.energy))
+    save('g10_spectrum.npz', **out)
+
+
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
     for name in todo:
         t = time.time()
         globals()[name]()
