@@ -17,8 +17,20 @@ def timed(obj, name, label=None):
         torch.cuda.synchronize(); acc[label or name] += time.perf_counter() - t; cnt[label or name] += 1
         return r
     setattr(obj, name, g)
-for nm in ['qr_into', 'svd_trunc', 'svdvals', 'mm', 'absorb']:
+for nm in ['svd_trunc', 'svdvals', 'mm', 'absorb']:
     timed(ops, nm, 'ops.' + nm)
+shape_acc = collections.defaultdict(float); shape_cnt = collections.defaultdict(int)
+_qr = ops.qr_into
+def qr_timed(T, *a, **k):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    r = _qr(T, *a, **k)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    acc['ops.qr_into'] += dt; cnt['ops.qr_into'] += 1
+    m, n_ = T.shape
+    key = (1 << (max(m, 1) - 1).bit_length(), 1 << (max(n_, 1) - 1).bit_length())    # rounded up to powers of two
+    shape_acc[key] += dt; shape_cnt[key] += 1
+    return r
+ops.qr_into = qr_timed
 s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=synthetic_chimera(n, n, 20260004), beta=3.0)
 orig = mps.MPS.compress_mps
 def compress(self, Dmax, tolS, tolV, max_sweeps, graduate_truncation=True, verbose=False):
@@ -39,3 +51,6 @@ torch.cuda.synchronize(); tot = time.perf_counter() - t0
 print('total %.2f s (with per-call syncs)' % tot)
 for k in sorted(acc, key=lambda k: -acc[k]):
     print('%-26s %8.3f s  %6d calls' % (k, acc[k], cnt[k]))
+print('QR time by shape (rows, cols rounded up to powers of two):')
+for k in sorted(shape_acc, key=lambda k: -shape_acc[k])[:14]:
+    print('  %6d x %5d  %8.3f s  %5d calls  %7.2f ms each' % (k[0], k[1], shape_acc[k], shape_cnt[k], 1e3 * shape_acc[k] / shape_cnt[k]))
