@@ -417,13 +417,14 @@ class RefSolver:
 
     def search_ground_state(self, M=2 ** 10, relative_P_cutoff=1e-6, min_dEng=1e-12, graduate_truncation=True,
                             Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20, trace=None, sweep_hook=None,
-                            pn_gather=None, merge_hook=None):
+                            pn_gather=None, merge_hook=None, row_hook=None):
         """Row-major branch-and-bound (tnac4o.py:381-551).  ``trace`` (a list) receives the
         (ny, nx, newprob, minprob) tables of every site-step when given (for golden checks).
         ``sweep_hook(solver, run_sweep)`` / ``pn_gather(compute, nb, q)``: optional injection points used by the CPU
         multi-rank tests to wrap the sweep and the per-branch table in the product's sharding helpers; with both None
         this is the plain reference algorithm.  ``merge_hook(site, parents, order, starts, Eng, prob, states, rep, probn,
-        selected)`` is told about every merge (the droplet bookkeeping of tnac4o.py:843-873 plugs in here in the tests)."""
+        selected)`` is told about every merge (the droplet bookkeeping of tnac4o.py:843-873 plugs in here in the tests),
+        ``row_hook()`` is called after each row."""
         M_ = M
         kw_sweep = dict(graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps)
         if sweep_hook is None:
@@ -530,6 +531,8 @@ class RefSolver:
                 RLl = RLnew
                 globalmin = min(globalmin, minprob)
 
+            if row_hook is not None:
+                row_hook()
             vind[:, 1:] = vind[:, :-1]                                      # :540-542
             vind[:, 0] = 0
 

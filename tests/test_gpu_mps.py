@@ -431,5 +431,43 @@ def test_low_energy_spectrum_rmf_golden():
         s.decode_low_energy_states(max_dEng=3.1, max_states=100)
         assert len(s.energy) == 26
         _spectrum_same(s, g, 'RMF_r%d' % rot, bits=False)
-    with pytest.raises(NotImplementedError):
-        s.search_low_energy_spectrum(excitations_encoding=2)
+    with pytest.raises(ValueError):
+        s.search_low_energy_spectrum(excitations_encoding=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('enc,rot,hd,n', [(2, 2, 0, 31), (3, 3, 0, 31), (2, 0, 0, 31), (3, 1, 2, 6)])
+def test_low_energy_spectrum_adjacency_encodings_golden(enc, rot, hd, n, tmp_path):
+    """Encodings 2 / 3 on the HIP path with the reference's seeded add_noise (test_examples.py test_e03)."""
+    import tnac4o_amd
+    g = load('g11_spectrum_adjacency.npz')
+    s = gpu_solver(rot=rot)
+    np.random.seed(100 + enc)
+    s.add_noise(amplitude=1e-7)
+    s.search_low_energy_spectrum(excitations_encoding=enc, M=1024, relative_P_cutoff=1e-8, Dmax=16, max_dEng=1.0, lim_hd=hd)
+    tag = 'L128_i1_e%d_r%d_hd%d' % (enc, rot, hd)
+    assert [len(s.d), len(s.el)] == list(g[tag + '_n_shapes'])
+    f = str(tmp_path / 'spectrum.npy')
+    s.save(f)
+    s.decode_low_energy_states(max_dEng=1.0)
+    assert len(s.energy) == n
+    _spectrum_same(s, g, tag)
+    t = tnac4o_amd.load(f)
+    t.decode_low_energy_states(max_dEng=1.0)
+    assert np.array_equal(t.energy, s.energy) and np.array_equal(t.states, s.states)
+
+
+@pytest.mark.gpu
+def test_low_energy_spectrum_adjacency_rmf_golden():
+    import tnac4o_amd
+    g = load('g11_spectrum_adjacency.npz')
+    J = gi.e05_rmf()
+    for enc, rot in ((2, 2), (3, 3)):
+        s = tnac4o_amd.tnac4o(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=4)
+        s.rotate_graph(rot)
+        np.random.seed(200 + enc)
+        s.add_noise(amplitude=1e-7)
+        s.search_low_energy_spectrum(excitations_encoding=enc, M=1024, relative_P_cutoff=1e-12, Dmax=32, max_dEng=3.1, lim_hd=0)
+        s.decode_low_energy_states(max_dEng=3.1, max_states=100)
+        assert len(s.energy) == 26
+        _spectrum_same(s, g, 'RMF_e%d_r%d' % (enc, rot), bits=False)

@@ -219,3 +219,78 @@ def test_unpack_snake_small_forest():
     assert sorted(np.round(E, 6)) == [0.0, 0.3, 0.5, 0.5]
     E, _ = droplets.unpack_snake([b, a], 8, max_dEng=10.0, max_states=3)
     assert len(E) <= 3 and 0.0 in E
+
+
+def _adjacency_case(enc, rot, hd):
+    import golden_inputs as gi
+    from spectrum_ref import SpectrumRef
+    g = np.load(os.path.join(gi.GOLDEN_DIR, 'g11_spectrum_adjacency.npz'))
+    s = SpectrumRef(mode='Ising', Nx=4, Ny=4, Nc=8, J=gi.droplet_J(128, 1), beta=3.0)
+    if rot:
+        s.rotate_graph(rot)
+    np.random.seed(100 + enc)
+    s.add_noise(amplitude=1e-7)
+    s.search_low_energy_spectrum(excitations_encoding=enc, M=1024, relative_P_cutoff=1e-8, Dmax=16, max_dEng=1.0, lim_hd=hd)
+    tag = 'L128_i1_e%d_r%d_hd%d' % (enc, rot, hd)
+    assert [len(s.d), len(s.el)] == list(g[tag + '_n_shapes'])
+    s.decode_low_energy_states(max_dEng=1.0)
+    return s, g, tag
+
+
+@pytest.mark.parametrize('enc,rot,hd,n', [(2, 2, 0, 31), (3, 3, 0, 31), (3, 1, 2, 6)])
+def test_spectrum_adjacency_encodings_golden(enc, rot, hd, n):
+    """Encodings 2 and 3 (elementary droplets from the coupling graph) with the reference's seeded noise: same number of
+    shapes, same decoded states (test_examples.py test_e03: 31 states within dE < 1)."""
+    s, g, tag = _adjacency_case(enc, rot, hd)
+    assert len(s.energy) == n
+    np.testing.assert_allclose(s.energy, g[tag + '_energy'], rtol=0, atol=1e-9)
+    assert sorted(map(bytes, np.asarray(s.binary_states(), dtype=np.int16))) == \
+        sorted(map(bytes, np.asarray(g[tag + '_bits'], dtype=np.int16)))
+
+
+def test_spectrum_adjacency_rmf_golden():
+    import golden_inputs as gi
+    from spectrum_ref import SpectrumRef
+    g = np.load(os.path.join(gi.GOLDEN_DIR, 'g11_spectrum_adjacency.npz'))
+    J = gi.e05_rmf()
+    for enc, rot in ((2, 2), (3, 3)):
+        s = SpectrumRef(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=4)
+        s.rotate_graph(rot)
+        np.random.seed(200 + enc)
+        s.add_noise(amplitude=1e-7)
+        s.search_low_energy_spectrum(excitations_encoding=enc, M=1024, relative_P_cutoff=1e-12, Dmax=32, max_dEng=3.1, lim_hd=0)
+        s.decode_low_energy_states(max_dEng=3.1, max_states=100)
+        assert len(s.energy) == 26
+        np.testing.assert_allclose(s.energy, g['RMF_e%d_r%d_energy' % (enc, rot)], rtol=0, atol=1e-9)
+        assert sorted(map(bytes, np.asarray(s.states, dtype=np.int16))) == \
+            sorted(map(bytes, np.asarray(g['RMF_e%d_r%d_states' % (enc, rot)], dtype=np.int16)))
+
+
+def test_droplet_shape_algebra():
+    from tnac4o_amd import droplets
+    a = (np.array([1, 4, 7]), np.array([3, 5, 1]))
+    b = (np.array([4, 7, 9]), np.array([5, 2, 8]))
+    c = droplets.combine_shapes(a, b)
+    assert list(c[0]) == [1, 7, 9] and list(c[1]) == [3, 3, 8]                 # cell 4 cancels, cell 7 xors
+    assert droplets.shape_distance(a, b, 'Ising') == 2 + 0 + 2 + 1             # bits of 3 | 5^5 | 1^2 | 8
+    assert droplets.shape_distance(a, b, 'RMF') == 3                           # cells 1, 7, 9 differ
+    conn = droplets.Connectivity('RMF', 5)
+    assert conn.elementary((np.array([0, 1, 6]), np.array([1, 1, 1])))         # (0,0)-(0,1)-(1,1) connected
+    assert not conn.elementary((np.array([0, 7]), np.array([1, 1])))
+    assert conn.touch((np.array([0]), np.array([1])), (np.array([5]), np.array([2])))      # vertical neighbours
+    assert not conn.touch((np.array([0]), np.array([1])), (np.array([7]), np.array([2])))
+
+
+def test_decode_spectrum_file_saved_by_reference():
+    """A result file of an encoding-2 search written by the reference's `save` (forest, shape table, adjacency as CSR):
+    our `load` + `decode_low_energy_states` rebuild the reference's 31 states from it."""
+    import tnac4o_amd
+    import golden_inputs as gi
+    g = np.load(os.path.join(gi.GOLDEN_DIR, 'g11_spectrum_adjacency.npz'))
+    ins = tnac4o_amd.load(os.path.join(gi.GOLDEN_DIR, 'g11_saved_by_reference_e2.npy'))
+    assert ins.excitations_encoding == 2
+    ins.decode_low_energy_states(max_dEng=1.0)
+    tag = 'L128_i1_e2_r2_hd0'
+    np.testing.assert_allclose(ins.energy, g[tag + '_energy'], rtol=0, atol=1e-12)
+    assert sorted(map(bytes, np.asarray(ins.binary_states(), dtype=np.int16))) == \
+        sorted(map(bytes, np.asarray(g[tag + '_bits'], dtype=np.int16)))

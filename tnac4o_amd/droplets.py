@@ -15,7 +15,12 @@ tnac4o.py:727-915, 2051-2079, 2249-2335, 1360-1389) with its own data structures
 A forest node is the tuple ((dE, shape_id, first_cell, last_cell, dlog2P), (children...)) -- the layout the reference
 stores in its result files (`el`), so files written by either side decode on the other.
 
-Encodings 2 and 3 of the reference (adjacency-based elementary droplets) are not built.
+Encodings 2 and 3 decide independence from the interaction graph instead (tnac4o.py:943-1358, 2081-2247, 2337-2377):
+only single-connected ("elementary") droplets are recorded, a droplet's sub-droplets are the loser's excitations that
+touch it, and two excitations may be combined when they do not touch.  `Connectivity` answers the graph questions,
+`AdjacencyRecorder` (encoding 2, nested) and `FlatRecorder` (encoding 3, one layer: every combination with the touching
+sub-droplets is stored as its own merged shape) build the forests, `unpack_adjacent` enumerates them.  Nodes of these
+encodings are ((dE, shape_id), (children...)).
 """
 import numpy as np
 
@@ -168,6 +173,225 @@ def decode_states(ground, forest, shapes, ncells, max_dEng, max_states, dtype):
     """Explicit low-energy states: the ground configuration with the droplets of each unpacked combination flipped
     (tnac4o.py:1360-1389).  Returns (excitation energies sorted ascending, states)."""
     E, flips = unpack_snake(forest, ncells, max_dEng=max_dEng, max_states=max_states)
+    order = E.argsort()
+    E = E[order]
+    n = min(max_states, len(E))
+    out = np.zeros((n, len(ground)), dtype=dtype)
+    for i in range(n):
+        st = ground.copy()
+        for sid in flips[order[i]]:
+            cells, xors = shapes[sid]
+            st[cells] = np.bitwise_xor(st[cells], xors)
+        out[i] = st
+    return E, out
+
+
+# ------------------------------------------------------------------------------------------------ encodings 2 and 3
+class Connectivity:
+    """Which droplets touch.  Ising: through the coupling graph of the spins they flip (adjacency from the nonzero
+    off-diagonal couplings; a cell's xor value selects the flipped spins of that cell).  RMF: cells are nearest
+    neighbours on the Nx-wide grid (tnac4o.py:2021-2041, 2081-2141)."""
+
+    def __init__(self, mode, Nx, J=None, ind=None, adj=None):
+        self.mode, self.Nx = mode, Nx
+        if mode == 'Ising':
+            if adj is None:
+                up = np.triu(np.asarray(J), 1) != 0
+                adj = up | up.T
+            self.adj = np.asarray(adj, dtype=bool)
+            self.flipped = []                      # per cell: xor value -> global spin indices
+            for row in ind:
+                for cell_spins in row:
+                    cell_spins = np.asarray(cell_spins)
+                    n = len(cell_spins)
+                    masks = ((np.arange(2 ** n)[:, None] >> np.arange(n)[None, :]) & 1).astype(bool)
+                    self.flipped.append([cell_spins[m] for m in masks])
+
+    def spins(self, shape):
+        cells, xors = shape
+        return np.hstack([self.flipped[c][int(x) % len(self.flipped[c])] for c, x in zip(cells, xors)])
+
+    def _grid_distance(self, a, b):
+        ax, ay, bx, by = np.mod(a, self.Nx), a // self.Nx, np.mod(b, self.Nx), b // self.Nx
+        return np.abs(ax[:, None] - bx[None, :]) + np.abs(ay[:, None] - by[None, :])
+
+    def elementary(self, shape):
+        """Single-connected?  Grown breadth-first from the first flipped spin / cell (tnac4o.py:2087-2114)."""
+        if self.mode == 'Ising':
+            nodes = self.spins(shape)
+            front, rest = nodes[:1], nodes[1:]
+            while front.size and rest.size:
+                hit = np.any(self.adj[front][:, rest], axis=0)
+                front, rest = rest[hit], rest[~hit]
+            return rest.size == 0
+        cells = np.asarray(shape[0])
+        front, rest = cells[:1], cells[1:]
+        while front.size and rest.size:
+            hit = np.any(self._grid_distance(front, rest) == 1, axis=0)
+            front, rest = rest[hit], rest[~hit]
+        return rest.size == 0
+
+    def touch(self, s1, s2):
+        """tnac4o.py:2116-2141: coupled spins (Ising); same or neighbouring cells (RMF)."""
+        if self.mode == 'Ising':
+            return bool(np.any(self.adj[self.spins(s1)][:, self.spins(s2)]))
+        return bool(np.any(self._grid_distance(np.asarray(s1[0]), np.asarray(s2[0])) <= 1))
+
+
+def combine_shapes(s1, s2):
+    """Composition of two droplets: xor on shared cells (cells that cancel drop out), union elsewhere (tnac4o.py:2198-2247)."""
+    acc = {}
+    for cells, xors in (s1, s2):
+        for c, x in zip(cells, xors):
+            c, x = int(c), int(x)
+            acc[c] = acc[c] ^ x if c in acc else x
+    cells = np.array(sorted(c for c, x in acc.items() if x != 0), dtype=np.int64)
+    return cells, np.array([acc[c] for c in cells], dtype=np.int64)
+
+
+def shape_distance(s1, s2, mode):
+    """Hamming distance between the states two droplets lead to (tnac4o.py:2152-2196): Ising counts spins (bits of the
+    xor), RMF counts cells."""
+    a = {int(c): int(x) for c, x in zip(*s1)}
+    b = {int(c): int(x) for c, x in zip(*s2)}
+    hd = 0
+    for c in set(a) | set(b):
+        if mode == 'Ising':
+            x = (a.get(c, 0) ^ b.get(c, 0)) if (c in a and c in b) else a.get(c, b.get(c))
+            hd += bin(x).count('1')
+        else:
+            hd += 0 if (c in a and c in b and a[c] == b[c]) else 1
+    return hd
+
+
+def unpack_adjacent(forest, shapes, conn, max_dEng=0.0, max_states=np.inf, one_layer=False):
+    """States encoded by a forest of encoding 2 (nested) or 3 (one_layer): (energies, shape-id lists).
+
+    Every partial state owns a work list; taking its last excitation spawns a new state whose work list keeps only the
+    excitations that do not touch the taken one, plus (nested encoding) the taken one's children.  The sweep over the
+    states repeats while the previous one spawned something -- the reference's termination rule, kept as it is because
+    it decides which states are listed (tnac4o.py:2337-2377)."""
+    energies, flips, work = [0.0], [[]], [list(forest)]
+    again = True
+    while again:
+        again = False
+        k = 0
+        while k < len(energies):
+            if work[k]:
+                node = work[k].pop()
+                (dE, sid), children = node[0][:2], node[1]
+                if energies[k] + dE <= max_dEng:
+                    energies.append(energies[k] + dE)
+                    flips.append(flips[k] + [sid])
+                    left = [x for x in work[k] if not conn.touch(_shape(shapes, x[0][1]), _shape(shapes, sid))]
+                    work.append(left)
+                    if not one_layer:
+                        left.extend(children)
+                    if (not again) or left or work[k]:
+                        again = True
+            k += 1
+        if len(energies) > max_states:
+            keep = np.array(energies).argpartition(max_states)[:max_states]
+            energies = [energies[i] for i in keep]
+            flips = [flips[i] for i in keep]
+            work = [work[i] for i in keep]
+    return np.array(energies), flips
+
+
+def _shape(shapes, ref):
+    return shapes[ref] if isinstance(ref, (int, np.integer)) else ref
+
+
+class AdjacencyRecorder(ExcitationRecorder):
+    """Encoding 2: nested forests of elementary droplets, sub-droplets chosen by contact (tnac4o.py:1062-1088)."""
+
+    def __init__(self, max_dEng, lim_hd, mode, conn):
+        super().__init__(max_dEng, lim_hd, mode)
+        self.conn = conn
+
+    def _losers(self, g, order, starts, ends, Eng, states, rep):
+        r = rep[g]
+        for i in order[starts[g]:ends[g]]:
+            dE = Eng[i] - Eng[r]
+            if i == r or not (dE <= self.max_dEng):
+                continue
+            diff = np.bitwise_xor(states[r], states[i])
+            cells = diff.nonzero()[0]
+            yield i, dE, (cells, diff[cells])
+
+    def merge_step(self, site, parents, order, starts, Eng, prob, states, rep, probn, selected):
+        ends = np.r_[starts[1:], len(order)]
+        new = []
+        by_id = self.shapes.by_id
+        for g in selected:
+            forest = list(self.forests[parents[rep[g]]])
+            for i, dE, shape in self._losers(g, order, starts, ends, Eng, states, rep):
+                if self.lim_hd > 1 and hamming_weight(shape[1], self.mode) < self.lim_hd:
+                    continue
+                if not self.conn.elementary(shape):
+                    continue
+                sid = self.shapes.intern(*shape)
+                inner = tuple(prune(e, self.max_dEng - (e[0][0] + dE)) for e in self.forests[parents[i]]
+                              if e[0][0] + dE <= self.max_dEng and self.conn.touch(by_id[sid], by_id[e[0][1]]))
+                forest.append(((dE, sid), inner))
+            new.append(forest)
+        self.forests = new
+        self._drop_unused()
+
+    def _drop_unused(self):
+        used = set()
+        for f in self.forests:
+            shape_ids(f, used)
+        self.shapes.keep_only(used)
+
+
+class FlatRecorder(AdjacencyRecorder):
+    """Encoding 3: one layer.  A loser's droplet is stored once per combination with its touching sub-droplets, each
+    combination as its own merged elementary shape with the summed energy (tnac4o.py:1261-1285); the shape table is
+    cleaned once per row, and near-duplicates (Hamming distance < lim_hd) are removed greedily at the end (:1324-1339)."""
+
+    def merge_step(self, site, parents, order, starts, Eng, prob, states, rep, probn, selected):
+        ends = np.r_[starts[1:], len(order)]
+        new = []
+        by_id = self.shapes.by_id
+        for g in selected:
+            forest = list(self.forests[parents[rep[g]]])
+            fresh = []
+            for i, dE, shape in self._losers(g, order, starts, ends, Eng, states, rep):
+                near = [e for e in self.forests[parents[i]]
+                        if e[0][0] + dE <= self.max_dEng and self.conn.touch(shape, by_id[e[0][1]])]
+                sE, sflip = unpack_adjacent(near, by_id, self.conn, self.max_dEng - dE, one_layer=True)
+                for e_sub, ids in zip(sE, sflip):
+                    merged = shape
+                    for sid in ids:
+                        merged = combine_shapes(merged, by_id[sid])
+                    if (self.lim_hd <= 1 or hamming_weight(merged[1], self.mode) >= self.lim_hd) and self.conn.elementary(merged):
+                        fresh.append(((e_sub + dE, self.shapes.intern(*merged)), ()))
+            fresh.sort(key=lambda node: node[0][0])
+            forest.extend(fresh)
+            new.append(forest)
+        self.forests = new
+
+    def end_row(self):
+        self._drop_unused()
+
+    def finish(self, order_i):
+        best = sorted(self.forests[0], key=lambda node: node[0][0])
+        if self.lim_hd > 1:
+            kept = []
+            for node in best:
+                if all(shape_distance(self.shapes.by_id[node[0][1]], self.shapes.by_id[o[0][1]], self.mode) >= self.lim_hd
+                       for o in kept):
+                    kept.append(node)
+            best = kept
+        self.forests[0] = best
+        self._drop_unused()
+        return super().finish(order_i)
+
+
+def decode_states_adjacent(ground, forest, shapes, conn, max_dEng, max_states, dtype, one_layer):
+    """decode_states for encodings 2 / 3."""
+    E, flips = unpack_adjacent(forest, shapes, conn, max_dEng=max_dEng, max_states=max_states, one_layer=one_layer)
     order = E.argsort()
     E = E[order]
     n = min(max_states, len(E))

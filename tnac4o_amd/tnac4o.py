@@ -111,8 +111,14 @@ def load(file_name):
     if d.get('excitations_encoding') is not None:          # droplet bookkeeping of the reference (:64-74): carried over
         for k in ('excitations_encoding', 'd', 'invd', 'el', 'free_d'):
             setattr(ins, k, d.get(k))
-        if ins.excitations_encoding > 1 and ins.mode == 'Ising':
-            ins.adj = d.get('adj')
+        if ins.excitations_encoding > 1:
+            from . import droplets
+            if ins.mode == 'Ising':
+                adj = d.get('adj')
+                ins.adj = np.asarray(adj.toarray() if hasattr(adj, 'toarray') else adj) != 0
+                ins._conn = droplets.Connectivity('Ising', ins.Nx, ind=ins.ind0, adj=ins.adj | ins.adj.T)
+            else:
+                ins._conn = droplets.Connectivity('RMF', ins.Nx)
     return ins
 
 
@@ -152,6 +158,7 @@ class tnac4o:
                     a, b = (i, j) if i <= j else (j, i)
                     Jd[a, b] += v
                 self.J = Jd
+                self.J0 = Jd.copy()
                 self.ind0 = [[self._active(ny, nx) for nx in range(Nx)] for ny in range(Ny)]
                 self.active = sum(len(self.ind0[ny][nx]) for ny in range(Ny) for nx in range(Nx))
             else:
@@ -534,27 +541,56 @@ class tnac4o:
         droplet independence from the row-major order of the cells).  Returns the lowest energies found; stores the
         same result attributes as search_ground_state plus the excitation forest `el` and the shape table `d`."""
         from . import droplets
-        if excitations_encoding != 1:
-            raise NotImplementedError('excitations_encoding 2 and 3 (adjacency-based elementary droplets) are not built; '
-                                      'use excitations_encoding=1')
+        if excitations_encoding not in (1, 2, 3):
+            raise ValueError('Available droplets handling strategies are excitations_encoding = 1,2,3.')
         self.excitations_encoding = excitations_encoding
-        rec = droplets.ExcitationRecorder(max_dEng, lim_hd, self.mode)
+        if excitations_encoding == 1:
+            rec = droplets.ExcitationRecorder(max_dEng, lim_hd, self.mode)
+        else:                                       # independence from the interaction graph of the (rotated) lattice
+            conn = droplets.Connectivity(self.mode, self.Nx, J=self.J if self.mode == 'Ising' else None,
+                                         ind=self.ind if self.mode == 'Ising' else None)
+            cls = droplets.AdjacencyRecorder if excitations_encoding == 2 else droplets.FlatRecorder
+            rec = cls(max_dEng, lim_hd, self.mode, conn)
         Eng = self.search_ground_state(M=M, relative_P_cutoff=relative_P_cutoff, min_dEng=min_dEng,
                                        graduate_truncation=graduate_truncation, Dmax=Dmax, tolS=tolS, tolV=tolV,
                                        max_sweeps=max_sweeps, recorder=rec)
         self.el, self.d = rec.finish(self.order_i)
         self.invd = rec.shapes.semi_hash_index()
         self.free_d = rec.shapes.next_id
+        if excitations_encoding > 1:                # decoding works in the unrotated cell order (tnac4o.py:1130, 1357)
+            self._conn = droplets.Connectivity(self.mode, self.Nx_model, J=self.J0 if self.mode == 'Ising' else None,
+                                               ind=self.ind0 if self.mode == 'Ising' else None)
+            self.adj = self._conn.adj if self.mode == 'Ising' else []
         return Eng
+
+    def add_noise(self, amplitude=1e-7):
+        """Small random perturbation of the couplings (numpy's global generator, like the reference) that removes
+        accidental degeneracies before a search with excitations_encoding 2 or 3 (tnac4o.py:917-941)."""
+        self.logger.info('Adding noise to the coupling with ampliture %.2e', amplitude)
+        if self.mode == 'Ising':
+            rows, cols = self.J.nonzero()
+            self.J[rows, cols] += (np.random.rand(len(rows)) * 2 - 1) * amplitude
+            self._divide_couplings()
+        else:
+            fun = {}
+            for key, val in self.J['fun'].items():
+                fun[key] = np.array(val, dtype=float, copy=True)
+                if fun[key].ndim == 1:
+                    fun[key] += (np.random.rand(fun[key].shape[0]) * 2 - 1) * amplitude
+            self.J['fun'] = fun
+            self._divide_couplings()
 
     def decode_low_energy_states(self, max_dEng=0., max_states=1024):
         """Turn the recorded excitation forest into explicit states, lowest energies first (tnac4o.py:1360-1389).
         Replaces energy / states by the decoded spectrum; returns the lowest excitation energy (0)."""
         from . import droplets
-        if getattr(self, 'excitations_encoding', 1) != 1:
-            raise NotImplementedError('only excitations_encoding=1 results can be decoded')
-        E, st = droplets.decode_states(self.states[0], self.el, self.d, self.Nx_model * self.Ny_model, max_dEng, max_states,
-                                       self.indtype)
+        enc = getattr(self, 'excitations_encoding', 1)
+        if enc == 1:
+            E, st = droplets.decode_states(self.states[0], self.el, self.d, self.Nx_model * self.Ny_model, max_dEng,
+                                           max_states, self.indtype)
+        else:
+            E, st = droplets.decode_states_adjacent(self.states[0], self.el, self.d, self._conn, max_dEng, max_states,
+                                                    self.indtype, one_layer=(enc == 3))
         self.energy = E + self.energy[0]
         self.states = st
         return E[0]
@@ -657,6 +693,8 @@ class tnac4o:
                 pkeys = nkeys
                 globalmin = min(globalmin, minprob)
 
+            if recorder is not None and hasattr(recorder, 'end_row'):
+                recorder.end_row()
             vind[:, 1:] = vind[:, :-1]                                       # tnac4o.py:540-542
             vind[:, 0] = 0
 

@@ -311,8 +311,40 @@ def g10():
     save('g10_spectrum.npz', **out)
 
 
+def g11():
+    """Low-energy spectrum with the adjacency-based encodings 2 and 3 (tnac4o.py:943-1358), as in test_examples.py test_e03 /
+    test_e05: seeded add_noise(1e-7), droplet L=128 #1 (31 states) and the minimal RMF model (26 states)."""
+    np.int = int                     # the reference's _exc_merge still spells the removed alias (tnac4o.py:2214-2215)
+    out = {}
+    for enc, rot, hd in ((2, 2, 0), (3, 3, 0), (2, 0, 0), (3, 1, 2)):
+        s = solver(128, 1, rot)
+        np.random.seed(100 + enc)
+        s.add_noise(amplitude=1e-7)
+        s.search_low_energy_spectrum(excitations_encoding=enc, M=1024, relative_P_cutoff=1e-8, Dmax=16, max_dEng=1.0, lim_hd=hd)
+        tag = 'L128_i1_e%d_r%d_hd%d' % (enc, rot, hd)
+        out[tag + '_n_shapes'] = np.array([len(s.d), len(s.el)])
+        if enc == 2 and rot == 2:
+            s.save(os.path.join(OUT, 'g11_saved_by_reference_e2.npy'))
+        s.decode_low_energy_states(max_dEng=1.0)
+        out[tag + '_energy'] = np.asarray(s.energy)
+        out[tag + '_bits'] = np.asarray(s.binary_states()).astype(np.int8)
+        print(tag, len(s.energy))
+    J = gi.e05_rmf()
+    for enc, rot in ((2, 2), (3, 3)):
+        s = ref.tnac4o(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=4)
+        s.rotate_graph(rot)
+        np.random.seed(200 + enc)
+        s.add_noise(amplitude=1e-7)
+        s.search_low_energy_spectrum(excitations_encoding=enc, M=1024, relative_P_cutoff=1e-12, Dmax=32, max_dEng=3.1, lim_hd=0)
+        s.decode_low_energy_states(max_dEng=3.1, max_states=100)
+        out['RMF_e%d_r%d_energy' % (enc, rot)] = np.asarray(s.energy)
+        out['RMF_e%d_r%d_states' % (enc, rot)] = np.asarray(s.states).astype(np.int16)
+        print('RMF', enc, rot, len(s.energy))
+    save('g11_spectrum_adjacency.npz', **out)
+
+
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
+    todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
     for name in todo:
         t = time.time()
         globals()[name]()
