@@ -38,8 +38,8 @@ struct GemmP {
 
 constexpr int BK = 16;
 
-template <int BM, int BN, bool AKFAST, bool BKFAST>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
+template <int BM, int BN, bool AKFAST, bool BKFAST, bool MAPPED>
+__global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 1) void gemm_kernel(GemmP g) {
     constexpr int PA = BM + 16, PB = BN + 16;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     constexpr int EA = BM * BK / 256, EB = BN * BK / 256;     // elements per thread per tile
@@ -59,45 +59,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
     const int zb = blockIdx.z / nsk, zs = blockIdx.z % nsk;
     if (g.skip && g.skip[zb] == 0) return;
     int blk0 = 0, blk1 = 0;
-    if (g.pairs) { blk0 = g.pairs[2 * zb]; blk1 = g.pairs[2 * zb + 1]; }
+    if (MAPPED && g.pairs) { blk0 = g.pairs[2 * zb]; blk1 = g.pairs[2 * zb + 1]; }
     auto remap = [&](int64_t v) -> int64_t { return v < g.pw ? (int64_t)blk0 * g.pw + v : (int64_t)blk1 * g.pw + (v - g.pw); };
     const double* A = g.A + zb * g.bsa;
     const double* B = g.B + zb * g.bsb;
     const int64_t k_lo = zs * g.kchunk;
     const int64_t k_hi = (k_lo + g.kchunk < g.K) ? k_lo + g.kchunk : g.K;
 
+    // Element e of this thread's share of a tile sits at (m0 + e DM, kA0 + e DKA) of the A tile and (n0 + e DN,
+    // kB0 + e DKB) of the B tile (the fast index of the thread id follows the operand's unit stride, so the loads
+    // coalesce).  Without block-pair indirection the global element offsets are affine in e and in the K position:
+    // one 64-bit offset per operand is kept and advanced, instead of re-deriving 16 addresses per K step.
+    constexpr int DM = AKFAST ? 256 / BK : 0, DKA = AKFAST ? 0 : 256 / BM;
+    constexpr int DN = BKFAST ? 256 / BK : 0, DKB = BKFAST ? 0 : 256 / BN;
+    const int m0 = AKFAST ? tid / BK : tid % BM, kA0 = AKFAST ? tid % BK : tid / BM;
+    const int n0 = BKFAST ? tid / BK : tid % BN, kB0 = BKFAST ? tid % BK : tid / BN;
+    const int64_t offA0 = (int64_t)(tm0 + m0) * g.rsa + (int64_t)kA0 * g.csa, stepA = (int64_t)DM * g.rsa + (int64_t)DKA * g.csa;
+    const int64_t offB0 = (int64_t)(tn0 + n0) * g.csb + (int64_t)kB0 * g.rsb, stepB = (int64_t)DN * g.csb + (int64_t)DKB * g.rsb;
+
     double ra[EA], rb[EB];
     auto load_tiles = [&](int64_t k0) {
+        if constexpr (!MAPPED) {
+            const double* Ak = A + k0 * g.csa + offA0;
+            const double* Bk = B + k0 * g.rsb + offB0;
 #pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            const int idx = tid + 256 * e;
-            const int m = AKFAST ? idx / BK : idx % BM;
-            const int k = AKFAST ? idx % BK : idx / BM;
-            const int64_t gm = tm0 + m, gk = k0 + k;
-            ra[e] = (gm < g.M && gk < k_hi) ? A[(g.mapA ? remap(gm) : gm) * g.rsa + gk * g.csa] : 0.0;
-        }
+            for (int e = 0; e < EA; ++e)
+                ra[e] = (tm0 + m0 + e * DM < g.M && k0 + kA0 + e * DKA < k_hi) ? Ak[e * stepA] : 0.0;
 #pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            const int idx = tid + 256 * e;
-            const int n = BKFAST ? idx / BK : idx % BN;
-            const int k = BKFAST ? idx % BK : idx / BN;
-            const int64_t gn = tn0 + n, gk = k0 + k;
-            rb[e] = (gn < g.N && gk < k_hi) ? B[(g.mapB == 1 ? remap(gk) : gk) * g.rsb + (g.mapB == 2 ? remap(gn) : gn) * g.csb] : 0.0;
+            for (int e = 0; e < EB; ++e)
+                rb[e] = (tn0 + n0 + e * DN < g.N && k0 + kB0 + e * DKB < k_hi) ? Bk[e * stepB] : 0.0;
+        } else {
+#pragma unroll
+            for (int e = 0; e < EA; ++e) {
+                const int64_t gm = tm0 + m0 + e * DM, gk = k0 + kA0 + e * DKA;
+                ra[e] = (gm < g.M && gk < k_hi) ? A[(g.mapA ? remap(gm) : gm) * g.rsa + gk * g.csa] : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const int64_t gn = tn0 + n0 + e * DN, gk = k0 + kB0 + e * DKB;
+                rb[e] = (gn < g.N && gk < k_hi) ? B[(g.mapB == 1 ? remap(gk) : gk) * g.rsb + (g.mapB == 2 ? remap(gn) : gn) * g.csb] : 0.0;
+            }
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
-            const int idx = tid + 256 * e;
-            const int m = AKFAST ? idx / BK : idx % BM;
-            const int k = AKFAST ? idx % BK : idx / BM;
+            const int m = m0 + e * DM, k = kA0 + e * DKA;
             As[k * PA + (m ^ k)] = ra[e];
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
-            const int idx = tid + 256 * e;
-            const int n = BKFAST ? idx / BK : idx % BN;
-            const int k = BKFAST ? idx % BK : idx / BN;
+            const int n = n0 + e * DN, k = kB0 + e * DKB;
             Bs[k * PB + (n ^ k)] = rb[e];
         }
     };
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP g) {
                 for (int r = 0; r < 4; ++r) {
                     const int64_t row = tm0 + wm * WM + i * 16 + lk + 4 * r, col = tn0 + wn * WN + j * 16 + lr;
                     if (row < g.M && col < g.N) {
-                        double* c = C + (g.mapC ? remap(row) : row) * g.rsc + col * g.csc;
+                        double* c = C + ((MAPPED && g.mapC) ? remap(row) : row) * g.rsc + col * g.csc;
                         double v = g.alpha * acc[i][j][r];
                         if (g.beta != 0.0) v += g.beta * *c;
                         *c = v;
@@ -178,10 +190,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP g) {
 
 template <int BM, int BN>
 static void launch_tile(hipStream_t st, const GemmP& g, dim3 grid, bool ak, bool bk) {
-    if (ak && bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, dim3(256), 0, st, g);
-    else if (ak) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false>), grid, dim3(256), 0, st, g);
-    else if (bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, dim3(256), 0, st, g);
+    if constexpr (BM == 64 && BN == 64) {          // the block-pair indirection of the Jacobi SVD only ever uses this tile
+        if (g.pairs) {
+            if (ak && bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, true>), grid, dim3(256), 0, st, g);
+            else if (ak) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, true>), grid, dim3(256), 0, st, g);
+            else if (bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, true>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, true>), grid, dim3(256), 0, st, g);
+            return;
+        }
+    }
+    if (ak && bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, false>), grid, dim3(256), 0, st, g);
+    else if (ak) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, false>), grid, dim3(256), 0, st, g);
+    else if (bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, false>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, false>), grid, dim3(256), 0, st, g);
 }
 
 static void pick_tile(int64_t M, int64_t N, int& bm, int& bn) {
@@ -227,6 +248,7 @@ int gemm_ex(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const
     g.pw = x ? x->pw : 0; g.mapA = x ? x->mapA : 0; g.mapB = x ? x->mapB : 0; g.mapC = x ? x->mapC : 0;
     int bm, bn;
     pick_tile(M, N, bm, bn);
+    TN_CHECK_ARG(g.pairs == nullptr || (bm == 64 && bn == 64), "block-pair indirection is built for the 64 x 64 tile only");
     g.tiles_m = (int)cdiv(M, bm); g.tiles_n = (int)cdiv(N, bn);
     int s = (x && x->force_splitk > 0) ? x->force_splitk : pick_splitk(M, N, K, batch);
     if (s > 1 && (ws == nullptr || ws_bytes < (int64_t)s * batch * M * N * 8)) s = 1;
