@@ -46,7 +46,7 @@ def build(verbose=False):
     """Compile libtnpeps.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB_PATH] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+          os.environ.get('TN_EXTRA_HIPCC_FLAGS', '').split() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

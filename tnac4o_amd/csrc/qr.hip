@@ -71,9 +71,18 @@ __global__ __launch_bounds__(256) void lu_reconstruct_kernel(double* __restrict_
     __shared__ double Tm[NB * P];
     __shared__ double sg[NB];
     const int tid = threadIdx.x;
-    for (int e = tid; e < b * b; e += 256) {
-        const int i = e / b, j = e % b;
-        B[i * P + j] = Ytop[i * rs + j * cs];
+    {
+        double yv[NB * NB / 256];
+#pragma unroll
+        for (int t = 0; t < NB * NB / 256; ++t) {            // one memory round trip
+            const int e = tid + 256 * t, i = e / NB, j = e % NB;
+            yv[t] = (i < b && j < b) ? Ytop[i * rs + j * cs] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < NB * NB / 256; ++t) {
+            const int e = tid + 256 * t;
+            B[(e / NB) * P + e % NB] = yv[t];
+        }
     }
     for (int e = tid; e < NB * P; e += 256) { Li[e] = 0.0; Ui[e] = 0.0; }
     __syncthreads();
@@ -238,20 +247,37 @@ __global__ __launch_bounds__(256) void rows_times_small3_mfma_kernel(double* __r
     __shared__ double Ss[3][NB * NB];
     __shared__ double tile[256 * P];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, j = e % NB;
-        const bool in = (i < b && j < b);
-        Ss[0][e] = in ? S0[i * b + j] : 0.0;
-        Ss[1][e] = in ? S1[i * b + j] : 0.0;
-        Ss[2][e] = (in && S2) ? S2[i * b + j] : 0.0;
-    }
+    // every global load of the prologue is issued before the first one is consumed (one memory round trip)
     const int64_t r0 = (int64_t)blockIdx.x * 256;
     const int nr = (int)((nrows - r0 < 256) ? nrows - r0 : 256);
-    // coalesced load of the (nr x b) block: the fast index of e follows the operand's unit stride
     const bool xrow = (cs == 1);
-    for (int e = tid; e < 256 * NB; e += 256) {
+    double sv[3][NB * NB / 256], xv[NB];
+#pragma unroll
+    for (int t = 0; t < NB * NB / 256; ++t) {
+        const int e = tid + 256 * t, i = e / NB, j = e % NB;
+        const bool in = (i < b && j < b);
+        sv[0][t] = in ? S0[i * b + j] : 0.0;
+        sv[1][t] = in ? S1[i * b + j] : 0.0;
+        sv[2][t] = (in && S2) ? S2[i * b + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int e = tid + 256 * u;
         const int i = xrow ? e / NB : e % 256, j = xrow ? e % NB : e / 256;
-        tile[i * P + j] = (i < nr && j < b) ? X[(r0 + i) * rs + j * cs] : 0.0;
+        xv[u] = (i < nr && j < b) ? X[(r0 + i) * rs + j * cs] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < NB * NB / 256; ++t) {
+        const int e = tid + 256 * t;
+        Ss[0][e] = sv[0][t];
+        Ss[1][e] = sv[1][t];
+        Ss[2][e] = sv[2][t];
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int e = tid + 256 * u;
+        const int i = xrow ? e / NB : e % 256, j = xrow ? e % NB : e / 256;
+        tile[i * P + j] = xv[u];
     }
     __syncthreads();
     const int li = lane & 15, lk = lane >> 4;

@@ -112,15 +112,33 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
     const int n = (nvec + 1) & ~1;          // even working size (a padding index never rotates)
     const double* pg = part + (int64_t)grp * nchunk * nvec * nvec;
 
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, j = e % NB;
-        double s = 0.0;
-        if (i < nvec && j < nvec)
-            for (int c = 0; c < nchunk; ++c) s += pg[(int64_t)c * nvec * nvec + i * nvec + j];
-        else if (i == j)
-            s = 1.0;
-        G[i * P + j] = s;
-        J[i * P + j] = (i == j) ? 1.0 : 0.0;
+    {   // Gram = sum of the split-K partials.  All of a thread's loads of one chunk are issued together (a loop that
+        // loads, adds and moves on would wait a full memory round trip per element: 128 dependent trips here).
+        constexpr int EPT = NB * NB / 256;
+        double acc[EPT];
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) acc[t] = 0.0;
+        for (int c = 0; c < nchunk; c += 2) {
+            double v0[EPT], v1[EPT];
+            const bool two = (c + 1 < nchunk);
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) {
+                const int e = tid + 256 * t, i = e / NB, j = e % NB;
+                const bool in = (i < nvec && j < nvec);
+                const int64_t o = (int64_t)c * nvec * nvec + i * nvec + j;
+                v0[t] = in ? pg[o] : 0.0;
+                v1[t] = (in && two) ? pg[o + (int64_t)nvec * nvec] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) acc[t] = (acc[t] + v0[t]) + v1[t];
+        }
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            const int e = tid + 256 * t, i = e / NB, j = e % NB;
+            const bool in = (i < nvec && j < nvec);
+            G[i * P + j] = in ? acc[t] : (i == j ? 1.0 : 0.0);
+            J[i * P + j] = (i == j) ? 1.0 : 0.0;
+        }
     }
     if (tid == 0) total = 0;
     __syncthreads();

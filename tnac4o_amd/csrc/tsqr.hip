@@ -8,6 +8,17 @@
 // Compared with the Gram/Jacobi panel step this needs 2 launches per level instead of ~19 per panel and no iteration.
 #include "common.h"
 
+// -DTN_CLOCKS: block 0 / thread 0 of the TSQR kernels records s_memtime at phase boundaries (diagnostics build only)
+#ifdef TN_CLOCKS
+__device__ long long tn_ts_clk[64];
+#define TN_CLK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) tn_ts_clk[k] = clock64(); } while (0)
+extern "C" int tn_debug_clocks(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tn_ts_clk), sizeof(long long) * (n < 64 ? n : 64));
+}
+#else
+#define TN_CLK(k) do {} while (0)
+#endif
+
 namespace tn {
 
 constexpr int TS_RB = 256;
@@ -72,18 +83,29 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
     int nr;
     block_rows(nrows, nblk, blk, r0, nr);
     const bool colfast = (cs == 1);
-    for (int e = tid; e < TS_RB * P; e += 256) T[e] = 0.0;
+    TN_CLK(0);
     if (tid < 32) dinv[tid] = 0.0;
-    __syncthreads();
+    T[tid * P + 32] = 0.0;                               // the pad column
     double amax = 0.0;
-    for (int e = tid; e < nr * b; e += 256) {
-        const int i = colfast ? e / b : e % nr, j = colfast ? e % b : e / nr;
-        const double x = X[(r0 + i) * rs + j * cs];
-        T[i * P + j] = x;
-        amax = fmax(amax, fabs(x));
+    {   // the whole 256 x 32 tile in one memory round trip: all 32 loads of a thread are issued before any is used
+        double xv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = tid + 256 * u;
+            const int i = colfast ? e >> 5 : e & 255, j = colfast ? e & 31 : e >> 8;
+            xv[u] = (i < nr && j < b) ? X[(r0 + i) * rs + j * cs] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = tid + 256 * u;
+            const int i = colfast ? e >> 5 : e & 255, j = colfast ? e & 31 : e >> 8;
+            T[i * P + j] = xv[u];
+            amax = fmax(amax, fabs(xv[u]));
+        }
     }
     part[tid] = amax;
     __syncthreads();
+    TN_CLK(1);
     for (int k = 128; k > 0; k >>= 1) {
         if (tid < k) part[tid] = fmax(part[tid], part[tid + k]);
         __syncthreads();
@@ -103,6 +125,7 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
 #pragma unroll
         for (int k = 0; k < TS_BODY; ++k) vbuf[rb + k] = y[k];
     }
+    TN_CLK(2);
     for (int j = 0; j < kmax; ++j) {
         __syncthreads();                                    // head updated, body of column j published, part[] free
         double v[TS_BODY];
@@ -157,6 +180,7 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
             for (int k = 0; k < TS_BODY; ++k) vbuf[rb + k] = y[k];
         }
     }
+    TN_CLK(3);
     for (int j = kmax + tid; j < 32; j += 256) taus[blk * 32 + j] = 0.0;
     __syncthreads();
     // assemble the LAPACK-style tile: triangle (with its power-of-two scale) on and above the diagonal, reflectors
@@ -173,14 +197,27 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
     }
     __syncthreads();
     const bool ofast = (ocs == 1);
-    for (int e = tid; e < nr * b; e += 256) {
-        const int i = ofast ? e / b : e % nr, j = ofast ? e % b : e / nr;
-        Vout[(r0 + i) * ors + j * ocs] = T[i * P + j];
+#pragma unroll
+    for (int u0 = 0; u0 < 32; u0 += 8) {
+        double ov[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * (u0 + u);
+            const int i = ofast ? e >> 5 : e & 255, j = ofast ? e & 31 : e >> 8;
+            ov[u] = T[i * P + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * (u0 + u);
+            const int i = ofast ? e >> 5 : e & 255, j = ofast ? e & 31 : e >> 8;
+            if (i < nr && j < b) Vout[(r0 + i) * ors + j * ocs] = ov[u];
+        }
     }
     for (int e = tid; e < b * b; e += 256) {
         const int i = e / b, j = e % b;
         Rout[((int64_t)blk * b + i) * b + j] = (i <= j && i < kmax) ? T[i * P + j] : 0.0;
     }
+    TN_CLK(4);
 }
 
 // Qout block = H_0 ... H_{kmax-1} [Qin block; 0]   (Qin == nullptr: identity, used at the single-block top level)
@@ -241,10 +278,212 @@ __global__ __launch_bounds__(256) void tsqr_apply_kernel(const double* V, int64_
 #pragma unroll
     for (int k = 0; k < 32; ++k) Tv[(rb + k) * P + c] = y[k];
     __syncthreads();
-    for (int e = tid; e < nr * b; e += 256) {
-        const int i = qfast ? e / b : e % nr, j = qfast ? e % b : e / nr;
-        Qout[(r0 + i) * qrs + j * qcs] = Tv[i * P + j];
+    TN_CLK(13);
+#pragma unroll
+    for (int u0 = 0; u0 < 32; u0 += 8) {             // 8 LDS reads, then 8 stores
+        double ov[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * (u0 + u);
+            const int i = qfast ? e >> 5 : e & 255, j = qfast ? e & 31 : e >> 8;
+            ov[u] = Tv[i * P + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * (u0 + u);
+            const int i = qfast ? e >> 5 : e & 255, j = qfast ? e & 31 : e >> 8;
+            if (i < nr && j < b) Qout[(r0 + i) * qrs + j * qcs] = ov[u];
+        }
     }
+    TN_CLK(14);
+}
+
+// Compact-WY form of tsqr_apply_kernel (the default): the block's 32 reflectors are not applied one after the other
+// (32 dependent LDS round trips) but as  Q_blk = [Qin; 0] - V (T (V_top^T Qin))  with  T = (diag(1/tau) + striu(V^T V))^-1
+// (the dlarft identity; reflectors with tau = 0 are decoupled and get a zero row / column of T):
+//   V^T V on the matrix cores (each wave its 64 rows, partial sums through LDS), the 32 x 32 triangular inverse by back
+//   substitution in one half-wave (one column per lane), two 32^3 products on the vector ALUs, V G on the matrix cores.
+typedef double d4t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void tsqr_apply_wy_kernel(const double* V, int64_t vrs, int64_t vcs, int64_t nrows, int b,
+                                                            int nblk, const double* __restrict__ taus,
+                                                            const double* __restrict__ Qin, double* Qout, int64_t qrs,
+                                                            int64_t qcs) {
+    constexpr int P = 33, Q = 33;
+    __shared__ double Tv[TS_RB * P];         // reflectors (unit lower trapezoidal); later the output tile
+    __shared__ double Sp[4][32 * Q];         // per-wave partial Gram matrices
+    __shared__ double Mt[32 * Q];            // diag(1/tau) + striu(V^T V), then T
+    __shared__ double Qs[32 * Q];            // Qin (zero padded)
+    __shared__ double Z1[32 * Q];            // V_top^T Qin, then G = T Z1
+    __shared__ double tl[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+    int64_t r0;
+    int nr;
+    block_rows(nrows, nblk, blk, r0, nr);
+    const bool vfast = (vcs == 1), qfast = (qcs == 1);
+    TN_CLK(8);
+    {   // all global loads of the prologue in one round trip
+        double vv[32], qv[4];
+        const double tq = (tid < 32) ? taus[blk * 32 + tid] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = tid + 256 * t, i = e >> 5, c = e & 31;
+            qv[t] = (i < b && i < nr && c < b) ? (Qin ? Qin[((int64_t)blk * b + i) * b + c] : (i == c ? 1.0 : 0.0)) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = tid + 256 * u;
+            const int i = vfast ? e >> 5 : e & 255, j = vfast ? e & 31 : e >> 8;
+            vv[u] = (i < nr && j < b && i > j) ? V[(r0 + i) * vrs + j * vcs] : ((i == j && i < nr && j < b) ? 1.0 : 0.0);
+        }
+        if (tid < 32) tl[tid] = tq;
+        Tv[tid * P + 32] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = tid + 256 * t;
+            Qs[(e >> 5) * Q + (e & 31)] = qv[t];
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = tid + 256 * u;
+            const int i = vfast ? e >> 5 : e & 255, j = vfast ? e & 31 : e >> 8;
+            Tv[i * P + j] = vv[u];
+        }
+    }
+    __syncthreads();
+    TN_CLK(9);
+    const int li = lane & 15, lk = lane >> 4;
+    {   // partial Gram of this wave's 64 rows: tiles (0,0), (0,1), (1,1) of V^T V
+        d4t g00 = d4t{0, 0, 0, 0}, g01 = g00, g11 = g00;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int row = wave * 64 + ks * 4 + lk;
+            const double f0 = Tv[row * P + li], f1 = Tv[row * P + 16 + li];
+            g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, g00, 0, 0, 0);
+            g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, g01, 0, 0, 0);
+            g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, g11, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = lk + 4 * r;
+            Sp[wave][i * Q + li] = g00[r];
+            Sp[wave][i * Q + 16 + li] = g01[r];
+            Sp[wave][(16 + i) * Q + 16 + li] = g11[r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int i = e >> 5, j = e & 31;
+        const bool di = (tl[i] == 0.0), dj = (tl[j] == 0.0);
+        double v = 0.0;
+        if (i == j) v = di ? 1.0 : fast_rcp(tl[i]);
+        else if (i < j && !di && !dj) v = (Sp[0][i * Q + j] + Sp[1][i * Q + j]) + (Sp[2][i * Q + j] + Sp[3][i * Q + j]);
+        Mt[i * Q + j] = v;
+    }
+    __syncthreads();
+    TN_CLK(10);
+    double x[32];
+    if (tid < 32) {           // column c of the inverse of the upper triangular Mt, bottom-up
+        const int c = tid;
+        double rdiag[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) rdiag[i] = fast_rcp(Mt[i * Q + i]);       // off the dependent chain
+#pragma unroll
+        for (int i = 31; i >= 0; --i) {
+            double sa[4] = {0.0, 0.0, 0.0, 0.0};                                // four short chains instead of one long one
+#pragma unroll
+            for (int k = i + 1; k < 32; ++k) sa[k & 3] += Mt[i * Q + k] * x[k];
+            const double sacc = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+            x[i] = (i > c) ? 0.0 : ((i == c) ? rdiag[i] : -sacc * rdiag[i]);
+        }
+    }
+    __syncthreads();          // every read of Mt happened
+    if (tid < 32) {
+        const int c = tid;
+        const bool dc = (tl[c] == 0.0);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) Mt[i * Q + c] = (dc && i == c) ? 0.0 : x[i];
+    }
+    __syncthreads();
+    TN_CLK(11);
+    // Z1 = V_top^T Qin and G = T Z1: the triangular factors carry explicit zeros, so both run over the full index range with
+    // compile-time trip counts (all LDS reads of an entry in flight together, two accumulation chains)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e = tid + 256 * t, a = e >> 5, c = e & 31;
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; i += 2) {
+            z0 += Tv[i * P + a] * Qs[i * Q + c];
+            z1 += Tv[(i + 1) * P + a] * Qs[(i + 1) * Q + c];
+        }
+        Z1[a * Q + c] = z0 + z1;
+    }
+    __syncthreads();
+    double gv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                   // kept in registers until Z1 is free
+        const int e = tid + 256 * t, a = e >> 5, c = e & 31;
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
+            z0 += Mt[a * Q + k] * Z1[k * Q + c];
+            z1 += Mt[a * Q + k + 1] * Z1[(k + 1) * Q + c];
+        }
+        gv[t] = z0 + z1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e = tid + 256 * t;
+        Z1[(e >> 5) * Q + (e & 31)] = gv[t];
+    }
+    __syncthreads();
+    TN_CLK(12);
+    {   // rows 64 wave .. 64 wave + 63:  out = [Qin; 0] - V G
+        double fa[4][8], fb[2][8];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) fa[mt][ks] = Tv[(wave * 64 + mt * 16 + li) * P + ks * 4 + lk];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) fb[nt][ks] = Z1[(ks * 4 + lk) * Q + nt * 16 + li];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                d4t acc = d4t{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[mt][ks], fb[nt][ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wave * 64 + mt * 16 + lk + 4 * r, col = nt * 16 + li;
+                    const double top = (row < 32) ? Qs[row * Q + col] : 0.0;
+                    Tv[row * P + col] = top - acc[r];
+                }
+            }
+    }
+    __syncthreads();
+    TN_CLK(13);
+#pragma unroll
+    for (int u0 = 0; u0 < 32; u0 += 8) {             // 8 LDS reads, then 8 stores
+        double ov[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * (u0 + u);
+            const int i = qfast ? e >> 5 : e & 255, j = qfast ? e & 31 : e >> 8;
+            ov[u] = Tv[i * P + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * (u0 + u);
+            const int i = qfast ? e >> 5 : e & 255, j = qfast ? e & 31 : e >> 8;
+            if (i < nr && j < b) Qout[(r0 + i) * qrs + j * qcs] = ov[u];
+        }
+    }
+    TN_CLK(14);
 }
 
 // ---- host driver -----------------------------------------------------------------------------------------------
@@ -299,8 +538,13 @@ int tsqr_orthonormalize(hipStream_t st, const double* Xin, int64_t irs, int64_t 
         double* Qout = (l == 0) ? X : L.Q;              // level l's output rows are level l-1's Qin blocks
         const int64_t qrs = (l == 0) ? rs : b, qcs = (l == 0) ? cs : 1;
         prof_begin(st, PROF_TSQR);
-        hipLaunchKernelGGL(tsqr_apply_kernel, dim3(L.nblk), dim3(256), 0, st, L.V, L.rs, L.cs, L.nrows, b, L.nblk, L.taus, Qin,
-                           Qout, qrs, qcs);
+        static const bool serial_apply = [] { const char* e = getenv("TN_TSQR_SERIAL_APPLY"); return e && e[0] == '1'; }();
+        if (serial_apply)       // reflector-by-reflector form, kept for cross-checking
+            hipLaunchKernelGGL(tsqr_apply_kernel, dim3(L.nblk), dim3(256), 0, st, L.V, L.rs, L.cs, L.nrows, b, L.nblk, L.taus, Qin,
+                               Qout, qrs, qcs);
+        else
+            hipLaunchKernelGGL(tsqr_apply_wy_kernel, dim3(L.nblk), dim3(256), 0, st, L.V, L.rs, L.cs, L.nrows, b, L.nblk, L.taus,
+                               Qin, Qout, qrs, qcs);
         TN_CHECK_LAUNCH("tsqr_apply_kernel");
         prof_end(st, PROF_TSQR, 2.0 * L.nrows * b * b, 16.0 * L.nrows * b);
     }
