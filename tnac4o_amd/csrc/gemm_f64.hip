@@ -180,7 +180,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP g) {
     if (e >= mn) return;
     const double* W = g.ws + (int64_t)zb * g.splitk * mn + e;
     double s = 0.0;
-    for (int k = 0; k < g.splitk; ++k) s += W[(int64_t)k * mn];
+    int k = 0;
+    for (; k + 8 <= g.splitk; k += 8) {              // eight partials in flight per round trip, summed in a fixed order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = W[(int64_t)(k + u) * mn];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < g.splitk; ++k) s += W[(int64_t)k * mn];
     const int64_t row = e / g.N, col = e % g.N;
     double* c = g.C + zb * g.bsc + row * g.rsc + col * g.csc;
     double v = g.alpha * s;

@@ -57,7 +57,43 @@ __global__ __launch_bounds__(256) void refill_dead_kernel(double* __restrict__ W
 
 // ------------------------------------------------------------------------------------------ reconstruction
 // One workgroup.  In: top b x b block of the orthonormal panel (strided).  Out: Y1 (unit lower triangular, written
-// back in place with explicit zeros/ones), Uinv (b x b), T (b x b upper).
+// back in place with explicit zeros/ones), Uinv (b x b), T (b x b upper), and the products that fold T into the tall
+// factors so that a block reflector is applied with two GEMMs instead of three:
+//   W = Y T^T (trailing update A -= W (Y^T A)),  Wq = Y T (Q accumulation Q -= Wq (Y^T Q)),  Y = [Y1; Q1_below Uinv]:
+//   rows below the top block use UT = Uinv T^T and UTq = Uinv T, the top block (Wtop, Wqtop) is produced here.
+// Steps: (1) sign-choosing LU of Q1_top - S = L U (Ballard et al.), one barrier per pivot: every thread derives the pivot
+// and its multipliers itself, the multipliers go to a separate array; (2) U^-1 and L^-1 by substitution, one column per
+// lane with the column in registers (wave 0: U^-1, wave 1: L^-1); (3) T = -U S L^-T and (4) the four 32^3 products on the
+// matrix cores, one product per wave.
+typedef double d4l __attribute__((ext_vector_type(4)));
+
+template <int NB>
+__device__ __forceinline__ void small_mm(const double* __restrict__ Am, bool at, const double* __restrict__ Bm_, bool bt, int P,
+                                         int lane, d4l (&acc)[NB / 16][NB / 16]) {
+    // acc = op(A) op(B) for NB x NB matrices in LDS (pitch P); at / bt: use the transpose.  One wave.
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ti = 0; ti < NB / 16; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NB / 16; ++tj) acc[ti][tj] = d4l{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < NB / 4; ++ks) {
+        const int k = ks * 4 + lk;
+        double fa[NB / 16], fb[NB / 16];
+#pragma unroll
+        for (int t = 0; t < NB / 16; ++t) {
+            const int i = t * 16 + li;
+            fa[t] = at ? Am[k * P + i] : Am[i * P + k];
+            fb[t] = bt ? Bm_[i * P + k] : Bm_[k * P + i];
+        }
+#pragma unroll
+        for (int ti = 0; ti < NB / 16; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NB / 16; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fb[tj], acc[ti][tj], 0, 0, 0);
+    }
+}
+
 template <int NB>
 __global__ __launch_bounds__(256) void lu_reconstruct_kernel(double* __restrict__ Ytop, int64_t rs, int64_t cs, int b,
                                                              double* __restrict__ Uinv, double* __restrict__ T,
@@ -65,105 +101,121 @@ __global__ __launch_bounds__(256) void lu_reconstruct_kernel(double* __restrict_
                                                              double* __restrict__ Wtop, int64_t wrs, int64_t wcs,
                                                              double* __restrict__ Wqtop) {
     constexpr int P = NB + 1;
-    __shared__ double B[NB * P];
-    __shared__ double Li[NB * P];
-    __shared__ double Ui[NB * P];
-    __shared__ double Tm[NB * P];
+    __shared__ double Um[NB * P];      // work matrix, then U (zeros below the diagonal), then U S, then T
+    __shared__ double Lm[NB * P];      // L (unit lower, zeros above)
+    __shared__ double Ui[NB * P];      // U^-1
+    __shared__ double Li[NB * P];      // L^-1
     __shared__ double sg[NB];
-    const int tid = threadIdx.x;
+    double* const Tm = Um;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         double yv[NB * NB / 256];
 #pragma unroll
         for (int t = 0; t < NB * NB / 256; ++t) {            // one memory round trip
             const int e = tid + 256 * t, i = e / NB, j = e % NB;
-            yv[t] = (i < b && j < b) ? Ytop[i * rs + j * cs] : 0.0;
+            yv[t] = (i < b && j < b) ? Ytop[i * rs + j * cs] : ((i == j) ? 0.0 : 0.0);
         }
 #pragma unroll
         for (int t = 0; t < NB * NB / 256; ++t) {
-            const int e = tid + 256 * t;
-            B[(e / NB) * P + e % NB] = yv[t];
+            const int e = tid + 256 * t, i = e / NB, j = e % NB;
+            Um[i * P + j] = yv[t];
+            Lm[i * P + j] = (i == j) ? 1.0 : 0.0;
+            Ui[i * P + j] = 0.0;
+            Li[i * P + j] = 0.0;
         }
     }
-    for (int e = tid; e < NB * P; e += 256) { Li[e] = 0.0; Ui[e] = 0.0; }
     __syncthreads();
+    // (1) LU with the sign choice  s_i = -sign(u_ii):  u_ii <- u_ii - s_i  (|pivot| >= 1)
     for (int i = 0; i < b; ++i) {
-        if (tid == 0) {
-            const double s = (B[i * P + i] >= 0.0) ? -1.0 : 1.0;
-            sg[i] = s;
-            B[i * P + i] -= s;
-        }
-        __syncthreads();
-        const double piv = B[i * P + i];
-        for (int r = i + 1 + tid; r < b; r += 256) B[r * P + i] /= piv;
-        __syncthreads();
+        const double bii = Um[i * P + i];
+        const double sgn = (bii >= 0.0) ? -1.0 : 1.0, piv = bii - sgn, rp = fast_rcp(piv);
         const int rem = b - i - 1;
         for (int e = tid; e < rem * rem; e += 256) {
             const int r = i + 1 + e / rem, c = i + 1 + e % rem;
-            B[r * P + c] -= B[r * P + i] * B[i * P + c];
+            const double l = Um[r * P + i] * rp;
+            Um[r * P + c] -= l * Um[i * P + c];
+            if (c == i + 1) Lm[r * P + i] = l;
         }
         __syncthreads();
+        if (tid == 0) { sg[i] = sgn; Um[i * P + i] = piv; }
+        if (tid > i && tid < b) Um[tid * P + i] = 0.0;       // column i below the pivot is L's now
     }
-    // U^-1 (rows from the bottom up) and L1^-1 (rows from the top down) by substitution, one row of each per iteration;
-    // column j is shared by 8 threads (k = h mod 8), whose partial sums meet in LDS: 2 barriers per row instead of a
-    // ~500-term dependent chain per column.
-    {
-        __shared__ double redU[8 * NB], redL[8 * NB];
-        const int j = tid & (NB - 1), h = tid / NB;            // NB = 32: 8 parts;  NB = 64: 4 parts
-        constexpr int NH = 256 / NB;
-        for (int it = 0; it < b; ++it) {
-            const int iu = b - 1 - it, il = it;
-            double su = 0.0, sl = 0.0;
-            if (j < b) {
-                for (int k = iu + 1 + h; k <= j; k += NH) su += B[iu * P + k] * Ui[k * P + j];      // needs j >= k > iu
-                for (int k = j + h; k < il; k += NH) sl += B[il * P + k] * Li[k * P + j];            // needs il > k >= j
-            }
-            redU[h * NB + j] = su;
-            redL[h * NB + j] = sl;
-            __syncthreads();
-            if (h == 0 && j < b) {
-                double tu = 0.0, tl = 0.0;
+    if (tid >= b && tid < NB) { sg[tid] = 1.0; Um[tid * P + tid] = 1.0; }      // padding: identity block
+    __syncthreads();
+    // (2) one column per lane, the column held in registers
+    if (wave == 0 && lane < NB) {
+        const int j = lane;
+        double x[NB], rd[NB];
 #pragma unroll
-                for (int q = 0; q < NH; ++q) { tu += redU[q * NB + j]; tl += redL[q * NB + j]; }
-                if (j >= iu) Ui[iu * P + j] = ((j == iu ? 1.0 : 0.0) - tu) / B[iu * P + iu];
-                if (j <= il) Li[il * P + j] = (j == il) ? 1.0 : -tl;
-            }
-            __syncthreads();
+        for (int i = 0; i < NB; ++i) rd[i] = fast_rcp(Um[i * P + i]);
+#pragma unroll
+        for (int i = NB - 1; i >= 0; --i) {
+            double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = i + 1; k < NB; ++k) sa[k & 3] += Um[i * P + k] * x[k];
+            const double t = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+            x[i] = (i > j) ? 0.0 : ((i == j) ? rd[i] : -t * rd[i]);
         }
-    }
-    for (int e = tid; e < b * b; e += 256) {
-        const int i = e / b, j = e % b;
-        double t = 0.0;
-        if (i <= j) {
-            for (int k = i; k <= j; ++k) t += B[i * P + k] * sg[k] * Li[j * P + k];
-            t = -t;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Ui[i * P + j] = x[i];
+    } else if (wave == 1 && lane < NB) {
+        const int j = lane;
+        double x[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < i; ++k) sa[k & 3] += Lm[i * P + k] * x[k];
+            const double t = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+            x[i] = (i < j) ? 0.0 : ((i == j) ? 1.0 : -t);
         }
-        T[e] = t;
-        Tm[i * P + j] = t;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Li[i * P + j] = x[i];
     }
     __syncthreads();
-    // Products that fold T into the tall factors, so that the block reflector is applied with two GEMMs instead of three:
-    //   W  = Y T^T  (trailing update  A -= W (Y^T A)),   Wq = Y T  (Q accumulation  Q -= Wq (Y^T Q)),
-    // where Y = [Y1; Q1_below Uinv]:  rows below the top block use UT = Uinv T^T and UTq = Uinv T, the top block is done here.
+    for (int e = tid; e < NB * NB; e += 256) Um[(e / NB) * P + e % NB] *= sg[e % NB];      // U S, in place (U is done)
+    __syncthreads();
+    // (3) T = -(U S) L^-T, upper triangle
+    const int li = lane & 15, lk = lane >> 4;
+    d4l acc[NB / 16][NB / 16];
+    if (wave == 0) small_mm<NB>(Tm, false, Li, true, P, lane, acc);
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int ti = 0; ti < NB / 16; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NB / 16; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ti * 16 + lk + 4 * r, j = tj * 16 + li;
+                    const double t = (i <= j && j < b) ? -acc[ti][tj][r] : 0.0;
+                    Tm[i * P + j] = t;
+                    if (i < b && j < b) T[i * b + j] = t;
+                }
+    }
+    __syncthreads();
+    // (4) wave 0: UT = Uinv T^T, wave 1: UTq = Uinv T, wave 2: W_top = L T^T, wave 3: Wq_top = L T
+    const double* left = (wave < 2) ? Ui : Lm;
+    small_mm<NB>(left, false, Tm, (wave & 1) == 0, P, lane, acc);
+#pragma unroll
+    for (int ti = 0; ti < NB / 16; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NB / 16; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + lk + 4 * r, j = tj * 16 + li;
+                if (i < b && j < b) {
+                    const double v = acc[ti][tj][r];
+                    if (wave == 0) UT[i * b + j] = v;
+                    else if (wave == 1) UTq[i * b + j] = v;
+                    else if (wave == 2) Wtop[i * wrs + j * wcs] = v;
+                    else Wqtop[i * rs + j * cs] = v;
+                }
+            }
     for (int e = tid; e < b * b; e += 256) {
         const int i = e / b, j = e % b;
-        double ut = 0.0, utq = 0.0;
-        for (int k = i; k < b; ++k) {                       // Uinv is upper triangular
-            const double u = Ui[i * P + k];
-            ut += u * Tm[j * P + k];
-            utq += u * Tm[k * P + j];
-        }
-        double wh = Tm[j * P + i], wqh = Tm[i * P + j];     // Y1 is unit lower triangular
-        for (int k = 0; k < i; ++k) {
-            const double l = B[i * P + k];
-            wh += l * Tm[j * P + k];
-            wqh += l * Tm[k * P + j];
-        }
         Uinv[e] = Ui[i * P + j];
-        UT[e] = ut;
-        UTq[e] = utq;
-        Ytop[i * rs + j * cs] = (i > j) ? B[i * P + j] : (i == j ? 1.0 : 0.0);
-        Wtop[i * wrs + j * wcs] = wh;
-        Wqtop[i * rs + j * cs] = wqh;
+        Ytop[i * rs + j * cs] = Lm[i * P + j];
     }
 }
 
