@@ -199,19 +199,23 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                     rr_pair(NB, s, tid, p, q);
                     const double gpq = G[p * P + q], gpp = G[p * P + p], gqq = G[q * P + q];
                     double c = 1.0, sn = 0.0;
-                    if (gpq != 0.0 && fabs(gpq) > tol * sqrt(fabs(gpp * gqq))) {
-                        const double tau = (gqq - gpp) * 0.5 * fast_rcp(gpq);
-                        double t;
-                        if (!(fabs(tau) < 1e150)) t = 0.5 * fast_rcp(tau);
-                        else {
-                            const double h = 1.0 + tau * tau;
-                            t = copysign(fast_rcp(fabs(tau) + h * fast_rsqrt(h)), tau);
+                    // rotate iff |g_pq| > tol sqrt(g_pp g_qq), tested on the squares (no square root on the critical path)
+                    const double g2 = gpq * gpq;
+                    if (g2 > tol * tol * fabs(gpp * gqq)) {
+                        // smaller-angle rotation from the double angle: cos 2t = |d| / hyp, d = g_qq - g_pp,
+                        // hyp^2 = d^2 + 4 g_pq^2;  c^2 = (1 + cos 2t) / 2,  s = g_pq / (hyp c) with the sign of d g_pq
+                        // (two reciprocal square roots in sequence instead of rcp - rsqrt - rcp - rsqrt)
+                        const double d = gqq - gpp;
+                        const double rh = fast_rsqrt(d * d + 4.0 * g2);
+                        const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+                        const double rcv = fast_rsqrt(c2);
+                        const double sabs = fabs(gpq) * rh * rcv;
+                        if (sabs <= 1.0 && c2 <= 1.0000000000000002) {     // (fails for non-finite intermediates: no rotation)
+                            c = c2 * rcv;
+                            sn = ((d >= 0.0) == (gpq >= 0.0)) ? sabs : -sabs;
+                            atomicAdd(&cnt, 1);
+                            stepflag[s] = 1;
                         }
-                        if (!(fabs(t) <= 1.0)) t = 0.0;            // non-finite intermediates (subnormal g_pq): no rotation
-                        c = fast_rsqrt(1.0 + t * t);
-                        sn = t * c;
-                        atomicAdd(&cnt, 1);
-                        stepflag[s] = 1;
                     }
                     rc[tid] = c; rsn[tid] = sn; rp[tid] = p; rq[tid] = q;
                 }
@@ -264,31 +268,51 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
         // One Newton-Schulz step J <- J (3I - J^T J)/2: the accumulated product of ~n*sweeps plane rotations drifts
         // from orthogonality by ~sqrt(n*sweeps) eps; this squares the defect, so repeated application of J over many
         // Jacobi rounds does not inflate vector norms (singular values) beyond rounding.
+        // Both products run on the matrix cores, each wave owning a strip of 16 x 16 output tiles.
         __shared__ double eigdiag[NB];
+        typedef double d4e __attribute__((ext_vector_type(4)));
+        constexpr int NT = NB / 16, TPW = NT * NT / 4;          // tiles per wave: 4 (NB = 64) or 1 (NB = 32)
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+        const int ti = (NB == 64) ? wave : (wave >> 1), tj0 = (NB == 64) ? 0 : (wave & 1);
         if (tid < NB) eigdiag[tid] = G[tid * P + tid];          // rotated diagonal = eigenvalues (needed below)
         __syncthreads();
-        for (int e = tid; e < NB * NB; e += 256) {              // G <- J^T J
-            const int k = e / NB, j = e % NB;
-            double s = 0.0;
-            for (int i = 0; i < NB; ++i) s += J[i * P + k] * J[i * P + j];
-            G[k * P + j] = s;
-        }
-        __syncthreads();
-        constexpr int EPT = NB * NB / 256;
-        double nv[EPT];
+        d4e acc[TPW];
 #pragma unroll
-        for (int r = 0; r < EPT; ++r) {
-            const int e = tid + 256 * r, i = e / NB, j = e % NB;
-            double s = 0.0;
-            for (int k = 0; k < NB; ++k) s += J[i * P + k] * G[k * P + j];
-            nv[r] = 1.5 * J[i * P + j] - 0.5 * s;
+        for (int t = 0; t < TPW; ++t) acc[t] = d4e{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {                   // S = J^T J
+            const int k = ks * 4 + lk;
+            const double fa = J[k * P + ti * 16 + li];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, J[k * P + (tj0 + t) * 16 + li], acc[t], 0, 0, 0);
         }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) G[(ti * 16 + lk + 4 * r) * P + (tj0 + t) * 16 + li] = acc[t][r];
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < EPT; ++r) {
-            const int e = tid + 256 * r;
-            J[(e / NB) * P + e % NB] = nv[r];
+        for (int t = 0; t < TPW; ++t) acc[t] = d4e{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {                   // N = J S
+            const int k = ks * 4 + lk;
+            const double fa = J[(ti * 16 + li) * P + k];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, G[k * P + (tj0 + t) * 16 + li], acc[t], 0, 0, 0);
         }
+        double nv[TPW][4];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                nv[t][r] = 1.5 * J[(ti * 16 + lk + 4 * r) * P + (tj0 + t) * 16 + li] - 0.5 * acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) J[(ti * 16 + lk + 4 * r) * P + (tj0 + t) * 16 + li] = nv[t][r];
         if (tid < NB) G[tid * P + tid] = eigdiag[tid];
         __syncthreads();
     }
