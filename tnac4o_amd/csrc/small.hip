@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
         for (int sweep = 0; sweep < max_sweeps; ++sweep) {
             if (tid == 0) cnt = 0;
             if (tid < NB) stepflag[tid] = 0;
+            int mine = 0;                                  // rotations decided by this thread in this sweep
             __syncthreads();
             for (int s = 0; s < NB - 1; ++s) {
                 if (tid < HP) {
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                         if (sabs <= 1.0 && c2 <= 1.0000000000000002) {     // (fails for non-finite intermediates: no rotation)
                             c = c2 * rcv;
                             sn = ((d >= 0.0) == (gpq >= 0.0)) ? sabs : -sabs;
-                            atomicAdd(&cnt, 1);
+                            ++mine;
                             stepflag[s] = 1;
                         }
                     }
@@ -257,6 +258,8 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                 }
                 __syncthreads();
             }
+            if (mine) atomicAdd(&cnt, mine);               // once per sweep, off the per-step critical path
+            __syncthreads();
             if (tid == 0) total += cnt;
             const int done = (cnt == 0);
             __syncthreads();
