@@ -361,9 +361,21 @@ __global__ __launch_bounds__(256) void rows_times_small3_mfma_kernel(double* __r
         }
         __syncthreads();
         const bool drow = (dcs == 1);
-        for (int e = tid; e < 256 * NB; e += 256) {
-            const int i = drow ? e / NB : e % 256, j = drow ? e % NB : e / 256;
-            if (i < nr && j < b) dst[(r0 + i) * drs + j * dcs] = tile[i * P + j];
+#pragma unroll
+        for (int u0 = 0; u0 < NB; u0 += 8) {             // 8 LDS reads, then 8 stores
+            double ov[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * (u0 + u);
+                const int i = drow ? e / NB : e % 256, j = drow ? e % NB : e / 256;
+                ov[u] = tile[i * P + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * (u0 + u);
+                const int i = drow ? e / NB : e % 256, j = drow ? e % NB : e / 256;
+                if (i < nr && j < b) dst[(r0 + i) * drs + j * dcs] = ov[u];
+            }
         }
         __syncthreads();
     }

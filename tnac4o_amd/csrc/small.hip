@@ -156,31 +156,38 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
             const double di = dsc[i], dj = dsc[j];
             double g;
             if (di == 0.0 || dj == 0.0) g = (i == j) ? 1.0 : 0.0;
-            else g = (i == j) ? 1.0 : G[i * P + j] / (di * dj);
+            else g = (i == j) ? 1.0 : G[i * P + j] * fast_rcp(di * dj);
             G[i * P + j] = g;
         }
         __syncthreads();
     }
-    // largest relative off-diagonal before rotating (diagnostic / convergence measure)
+    // largest relative off-diagonal before rotating (diagnostic / convergence measure): max of g_ij^2 / (g_ii g_jj) with the
+    // reciprocal diagonal prepared once, one square root at the end, wave-level reduction
     {
-        double m = 0.0;
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int i = e / NB, j = e % NB;
-            if (i < j && j < nvec) {
-                const double dd = fabs(G[i * P + i] * G[j * P + j]);
-                if (dd > 0.0) {
-                    const double r = fabs(G[i * P + j]) / sqrt(dd);
-                    m = r > m ? r : m;
-                }
-            }
+        __shared__ double rdg[NB];
+        if (tid < NB) {
+            const double gii = fabs(G[tid * P + tid]);
+            rdg[tid] = (gii > 0.0 && tid < nvec) ? fast_rcp(gii) : 0.0;
         }
-        red[tid] = m;
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s) red[tid] = red[tid] > red[tid + s] ? red[tid] : red[tid + s];
-            __syncthreads();
+        double m = 0.0;
+#pragma unroll
+        for (int t = 0; t < NB * NB / 256; ++t) {
+            const int e = tid + 256 * t, i = e / NB, j = e % NB;
+            const double g = G[i * P + j];
+            const double r2 = (i < j) ? g * g * rdg[i] * rdg[j] : 0.0;
+            m = r2 > m ? r2 : m;
         }
-        if (tid == 0 && maxoff_out) maxoff_out[grp] = red[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+            const double mm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            red[0] = sqrt(mm);
+            if (maxoff_out) maxoff_out[grp] = red[0];
+        }
+        __syncthreads();
     }
 
     // Parallel-order Jacobi on the full NB x NB arrays (indices >= nvec are isolated: unit diagonal, zero coupling,

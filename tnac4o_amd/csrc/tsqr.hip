@@ -103,14 +103,12 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
             amax = fmax(amax, fabs(xv[u]));
         }
     }
-    part[tid] = amax;
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) part[tid >> 6] = amax;
     __syncthreads();
     TN_CLK(1);
-    for (int k = 128; k > 0; k >>= 1) {
-        if (tid < k) part[tid] = fmax(part[tid], part[tid + k]);
-        __syncthreads();
-    }
-    amax = part[0];
+    amax = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
+    __syncthreads();                                     // part[] is reused by the column loop
     int ex = 0;
     if (amax > 0.0 && amax < 1.7e308) frexp(amax, &ex);
     const double scl = ldexp(1.0, -ex), iscl = ldexp(1.0, ex);
@@ -127,7 +125,9 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
     }
     TN_CLK(2);
     for (int j = 0; j < kmax; ++j) {
+        if (j == 5) TN_CLK(16);
         __syncthreads();                                    // head updated, body of column j published, part[] free
+        if (j == 5) TN_CLK(17);
         double v[TS_BODY];
 #pragma unroll
         for (int k = 0; k < TS_BODY; ++k) v[k] = vbuf[rb + k];
@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
         }
         const double alpha = T[j * P + j], ajc = T[j * P + c];
         part[tid] = (s0 + s1) + (s2 + s3);
+        if (j == 5) TN_CLK(18);
         __syncthreads();
+        if (j == 5) TN_CLK(19);
         double sc = 0.0, sj = 0.0;                          // sums over the rows below the diagonal
 #pragma unroll
         for (int k = 0; k < 8; ++k) { sc += part[k * 32 + c]; sj += part[k * 32 + j]; }
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
             }
             if (g == 0 && c == j) { T[j * P + j] = beta; dinv[j] = invd; }
         }
+        if (j == 5) TN_CLK(20);
         if (tid == 0) taus[blk * 32 + j] = tau;
         // every read of vbuf for this column happened before the barrier above, so the next column may be published now
         if (c == j + 1) {
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
         }
     }
     TN_CLK(3);
+    TN_CLK(21);
     for (int j = kmax + tid; j < 32; j += 256) taus[blk * 32 + j] = 0.0;
     __syncthreads();
     // assemble the LAPACK-style tile: triangle (with its power-of-two scale) on and above the diagonal, reflectors

@@ -13,4 +13,5 @@ for rep in range(3):
     L.tn_debug_clocks(buf, 64)
     c = list(buf)
     print('factor: load %d  amax %d  prep %d  columns %d  store %d   (total %d)' % (c[1]-c[0], 0, c[2]-c[1], c[3]-c[2], c[4]-c[3], c[4]-c[0]))
+    print('factor column 5: barrier1 %d  dots %d  barrier2 %d  scalar+update %d  (column %d)' % (c[17]-c[16], c[18]-c[17], c[19]-c[18], c[20]-c[19], c[20]-c[16]))
     print('apply : load %d  gram %d  inverse %d  small %d  mfma %d  store %d   (total %d)' % (c[9]-c[8], c[10]-c[9], c[11]-c[10], c[12]-c[11], c[13]-c[12], c[14]-c[13], c[14]-c[8]))
