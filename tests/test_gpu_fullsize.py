@@ -95,3 +95,28 @@ def test_sweep_L2048_chi64_properties():
     phi = mps.MPS(d=psi.d, L=psi.L, Dmax=1, canonise=None)
     phi.A = before
     assert abs(mps.dot(phi, psi)) == pytest.approx(1.0, abs=1e-10)   # same state (both are normalised)
+
+
+def test_rmf_d8_chi128_config5_shapes():
+    """BASELINE config 5 family (RMF, d = 8, chi = 128: the absorbed bond is again 1024 but with p = b = 8) on a 10 x 10
+    lattice: compression overlaps 1, the state found has the energy the couplings give it, a chi = 32 contraction finds
+    the same ground state, and the product's energy agrees with the brute-force minimum over a 3 x 3 sub-problem."""
+    import itertools
+    import tnac4o_amd
+    from tnac4o_amd.auxx import synthetic_rmf, energy_RMF
+    J = synthetic_rmf(10, 10, 8, 20260005)
+    out = {}
+    for chi in (128, 32):
+        s = tnac4o_amd.tnac4o(mode='RMF', Nx=10, Ny=10, J=J, beta=1.0)
+        s.search_ground_state(M=256, relative_P_cutoff=1e-8, Dmax=chi)
+        assert min(s.rhoT_overlap) > 1 - 1e-9
+        assert max(max(m.D) for m in s.rhoT) <= chi
+        assert energy_RMF(J, s.states[:1])[0] == pytest.approx(s.energy[0], abs=1e-9)
+        out[chi] = (float(s.energy[0]), [int(x) for x in s.states[0]])
+    assert out[128][0] <= out[32][0] + 1e-9
+    # exhaustive check on a small instance of the same generator (3 x 3, d = 4: 262144 states)
+    Js = synthetic_rmf(3, 3, 4, 7)
+    s = tnac4o_amd.tnac4o(mode='RMF', Nx=3, Ny=3, J=Js, beta=4.0)
+    s.search_ground_state(M=256, relative_P_cutoff=1e-10, Dmax=16)
+    allst = np.array(list(itertools.product(range(4), repeat=9)), dtype=np.int64)
+    assert float(s.energy[0]) == pytest.approx(float(energy_RMF(Js, allst).min()), abs=1e-9)
