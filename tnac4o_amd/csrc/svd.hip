@@ -94,6 +94,124 @@ __global__ __launch_bounds__(256) void svd_gather_kernel(const double* __restric
     for (int64_t c = tid; c < nv; c += 256) left[c * lrs + (int64_t)j * lcs] = p[c] * s;
 }
 
+// Values-only SVD of a small centre matrix (both dimensions <= 64: the Schmidt-value checks of the final variational
+// sweeps, mps.py:550-560) in ONE launch: Hestenes one-sided Jacobi on the rows held in LDS.  Round-robin pairing, 32
+// pairs per step, 8 threads per pair (8 consecutive elements of both rows each; the three inner products meet through
+// three xor-shuffles, every lane derives the same rotation).  Rows below 2^-56 of the largest are zeroed first, sweeps
+// repeat until one passes without a rotation above 4e-15 (the block path's criterion).  out: 64 values sorted
+// descending, out[64] = sweeps, out[65] = 1 if converged.
+__device__ __forceinline__ void rr_pair64(int s, int a, int& p, int& q) {
+    if (a == 0) { p = 63; q = s; }
+    else { p = (s + a) % 63; q = (s - a + 63) % 63; }
+    if (p > q) { const int t = p; p = q; q = t; }
+}
+
+__global__ __launch_bounds__(256) void svd_vals_small_kernel(const double* __restrict__ M, int64_t vs, int64_t es, int nv, int L,
+                                                             double* __restrict__ out) {
+    constexpr int NV = 64, P = 66;            // even pitch: 16-byte aligned 8-element segments
+    __shared__ double X[NV * P];
+    __shared__ double nrm[NV];
+    __shared__ int flags[2];                  // [0] rotations this sweep, [1] rotations above the convergence threshold
+    const int tid = threadIdx.x, slot = tid >> 3, sub = tid & 7;
+    {
+        double xv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {        // one memory round trip
+            const int e = tid + 256 * t, r = e >> 6, c = e & 63;
+            xv[t] = (r < nv && c < L) ? M[(int64_t)r * vs + (int64_t)c * es] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int e = tid + 256 * t;
+            X[(e >> 6) * P + (e & 63)] = xv[t];
+        }
+    }
+    __syncthreads();
+    auto seg_dot3 = [&](const double* xp, const double* xq, double& a, double& b, double& g) {
+        a = 0.0; b = 0.0; g = 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a += xp[e] * xp[e]; b += xq[e] * xq[e]; g += xp[e] * xq[e]; }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); g += __shfl_xor(g, o, 64); }
+    };
+    {   // squared norms of rows 2 slot, 2 slot + 1; deflation
+        double xp[8], xq[8], a, b, g;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xp[e] = X[(2 * slot) * P + sub * 8 + e]; xq[e] = X[(2 * slot + 1) * P + sub * 8 + e]; }
+        seg_dot3(xp, xq, a, b, g);
+        if (sub == 0) { nrm[2 * slot] = a; nrm[2 * slot + 1] = b; }
+        __syncthreads();
+        double nmax = 0.0;
+        for (int r = 0; r < NV; ++r) nmax = fmax(nmax, nrm[r]);
+        const double thr = nmax * 1.9259299443872359e-34;       // (2^-56)^2
+        if (!(a > thr)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) X[(2 * slot) * P + sub * 8 + e] = 0.0;
+        }
+        if (!(b > thr)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) X[(2 * slot + 1) * P + sub * 8 + e] = 0.0;
+        }
+    }
+    const double tol2 = 7.888609052210118e-31;                   // (2^-50)^2
+    const double conv2 = 1.6e-29;                                // (4e-15)^2
+    int sweeps = 0, converged = 0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        if (tid < 2) flags[tid] = 0;
+        __syncthreads();
+        int any = 0, big = 0;
+        for (int s = 0; s < NV - 1; ++s) {
+            int p, q;
+            rr_pair64(s, slot, p, q);
+            double xp[8], xq[8], a, b, g;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xp[e] = X[p * P + sub * 8 + e]; xq[e] = X[q * P + sub * 8 + e]; }
+            seg_dot3(xp, xq, a, b, g);
+            const double g2 = g * g, ab = a * b;
+            if (g2 > tol2 * ab) {
+                const double d = b - a;
+                const double rh = fast_rsqrt(d * d + 4.0 * g2);
+                const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+                const double rcv = fast_rsqrt(c2);
+                const double sabs = fabs(g) * rh * rcv;
+                if (sabs <= 1.0 && c2 <= 1.0000000000000002) {
+                    const double c = c2 * rcv, sn = ((d >= 0.0) == (g >= 0.0)) ? sabs : -sabs;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        X[p * P + sub * 8 + e] = c * xp[e] - sn * xq[e];
+                        X[q * P + sub * 8 + e] = sn * xp[e] + c * xq[e];
+                    }
+                    any = 1;
+                    if (g2 > conv2 * ab) big = 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (any && sub == 0) atomicOr(&flags[0], 1);
+        if (big && sub == 0) atomicOr(&flags[1], 1);
+        __syncthreads();
+        ++sweeps;
+        const int f0 = flags[0], f1 = flags[1];
+        __syncthreads();
+        if (!f1) { converged = 1; if (!f0) break; break; }
+    }
+    {   // singular values = row norms; sorted descending by rank counting
+        double xp[8], xq[8], a, b, g;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xp[e] = X[(2 * slot) * P + sub * 8 + e]; xq[e] = X[(2 * slot + 1) * P + sub * 8 + e]; }
+        seg_dot3(xp, xq, a, b, g);
+        if (sub == 0) { nrm[2 * slot] = a; nrm[2 * slot + 1] = b; }
+        __syncthreads();
+        if (tid < NV) {
+            const double mine = nrm[tid];
+            int rank = 0;
+            for (int r = 0; r < NV; ++r) rank += (nrm[r] > mine || (nrm[r] == mine && r < tid)) ? 1 : 0;
+            out[rank] = sqrt(mine);
+        }
+        if (tid == 0) { out[64] = (double)sweeps; out[65] = (double)converged; }
+    }
+}
+
 static void round_robin(int nblk, std::vector<int>& pairs) {     // (nblk-1) rounds x (nblk/2) pairs x 2
     std::vector<int> idx(nblk);
     for (int i = 0; i < nblk; ++i) idx[i] = i;
@@ -279,6 +397,22 @@ int svd_vals(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t 
     const bool rows = k <= n;
     const int64_t nv = rows ? k : n, L = rows ? n : k;
     const int64_t vs = rows ? crs : ccs, es = rows ? ccs : crs;
+    if (L <= 64) {               // small centre matrix: everything in one launch and one read-back
+        double* dout = (double*)ws;
+        TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_vals_small_kernel, dim3(1), dim3(256), 0, st, C, vs, es, (int)nv, (int)L, dout));
+        TN_CHECK_LAUNCH("svd_vals_small_kernel");
+        double h[66];
+        hipError_t e;
+        if ((e = hipMemcpyAsync(h, dout, sizeof(h), hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy S");
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync S");
+        for (int64_t i = 0; i < nv; ++i) {
+            if (!(h[i] == h[i]) || h[i] > 1.7e308) { set_error("svd: non-finite input"); return -2; }
+            hostS[i] = h[i];
+        }
+        if (sweeps_out) *sweeps_out = (int)h[64];
+        if (info) *info = (h[65] != 0.0) ? 0 : 1;
+        return 0;
+    }
     SvdWs w;
     svd_layout(nv, L, false, (char*)ws, &w);
     std::vector<double> hS;
