@@ -17,7 +17,7 @@ def timed(obj, name, label=None):
         torch.cuda.synchronize(); acc[label or name] += time.perf_counter() - t; cnt[label or name] += 1
         return r
     setattr(obj, name, g)
-for nm in ['svd_trunc', 'svdvals', 'mm', 'absorb']:
+for nm in ['mm', 'absorb']:
     timed(ops, nm, 'ops.' + nm)
 shape_acc = collections.defaultdict(float); shape_cnt = collections.defaultdict(int)
 _qr = ops.qr_into
@@ -31,6 +31,20 @@ def qr_timed(T, *a, **k):
     shape_acc[key] += dt; shape_cnt[key] += 1
     return r
 ops.qr_into = qr_timed
+svd_acc = collections.defaultdict(float); svd_cnt = collections.defaultdict(int)
+def shaped(name):
+    f = getattr(ops, name)
+    def g(Cm, *a, **k):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        r = f(Cm, *a, **k)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        acc['ops.' + name] += dt; cnt['ops.' + name] += 1
+        m, n_ = Cm.shape
+        key = (name, 1 << (max(min(m, n_), 1) - 1).bit_length(), 1 << (max(m, n_, 1) - 1).bit_length())
+        svd_acc[key] += dt; svd_cnt[key] += 1
+        return r
+    setattr(ops, name, g)
+shaped('svd_trunc'); shaped('svdvals')
 s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=synthetic_chimera(n, n, 20260004), beta=3.0)
 orig = mps.MPS.compress_mps
 def compress(self, Dmax, tolS, tolV, max_sweeps, graduate_truncation=True, verbose=False):
@@ -54,3 +68,6 @@ for k in sorted(acc, key=lambda k: -acc[k]):
 print('QR time by shape (rows, cols rounded up to powers of two):')
 for k in sorted(shape_acc, key=lambda k: -shape_acc[k])[:14]:
     print('  %6d x %5d  %8.3f s  %5d calls  %7.2f ms each' % (k[0], k[1], shape_acc[k], shape_cnt[k], 1e3 * shape_acc[k] / shape_cnt[k]))
+print('SVD time by shape (min, max dimension rounded up to powers of two):')
+for k in sorted(svd_acc, key=lambda k: -svd_acc[k])[:14]:
+    print('  %-10s %5d x %5d  %8.3f s  %5d calls  %7.2f ms each' % (k[0], k[1], k[2], svd_acc[k], svd_cnt[k], 1e3 * svd_acc[k] / svd_cnt[k]))
