@@ -99,7 +99,7 @@ int calc_pn(hipStream_t st, const double* T1, const double* RR, const double* F,
     TN_CHECK_ARG(q >= 1 && nl >= 1 && nu >= 1 && p >= 1 && Dr >= 1 && br >= 1, "non-positive dimension");
     const int64_t lds = (p * Dr + Dr * br + p * br + q) * 8;
     TN_CHECK_ARG(lds <= 150 * 1024, "site too large for calc_pn");
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)calc_pn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)calc_pn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(calc_pn_kernel, dim3((unsigned)nb), dim3(256), (size_t)lds, st, T1, RR, F, dmap, rmap, pref, suf, lidx,
                        uidx, (int)q, (int)nl, (int)nu, (int)p, (int)Dr, (int)br, P, minP));
     TN_CHECK_LAUNCH("calc_pn_kernel");

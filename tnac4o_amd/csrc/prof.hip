@@ -23,10 +23,10 @@ struct ThreadProf {
     size_t used = 0;
     void drain() {
         if (used == 0) return;
-        hipEventSynchronize(ring[used - 1].b);
+        (void)hipEventSynchronize(ring[used - 1].b);
         for (size_t i = 0; i < used; ++i) {
             float ms = 0.f;
-            hipEventSynchronize(ring[i].b);
+            (void)hipEventSynchronize(ring[i].b);
             if (hipEventElapsedTime(&ms, ring[i].a, ring[i].b) == hipSuccess) fam[ring[i].ph][ring[i].fam].ms += ms;
         }
         used = 0;
@@ -57,12 +57,12 @@ void prof_begin(hipStream_t st, int fam) {
     if (!t.armed) return;
     if (t.ring.empty()) {
         t.ring.resize(8192);
-        for (auto& p : t.ring) { hipEventCreate(&p.a); hipEventCreate(&p.b); }
+        for (auto& p : t.ring) { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
     }
     if (t.used == t.ring.size()) t.drain();
     t.ring[t.used].fam = fam;
     t.ring[t.used].ph = t.phase;
-    hipEventRecord(t.ring[t.used].a, st);
+    (void)hipEventRecord(t.ring[t.used].a, st);
 }
 
 void prof_end(hipStream_t st, int fam, double flops, double bytes) {
@@ -70,7 +70,7 @@ void prof_end(hipStream_t st, int fam, double flops, double bytes) {
     ThreadProf& t = mine();
     if (!t.armed) return;
     t.armed = false;
-    hipEventRecord(t.ring[t.used].b, st);
+    (void)hipEventRecord(t.ring[t.used].b, st);
     ++t.used;
     Fam& f = t.fam[t.phase][fam];
     f.calls += 1;

@@ -539,9 +539,9 @@ static bool dbg_on() { static int v = -1; if (v < 0) { const char* e = getenv("T
 static void dbg_check(hipStream_t st, const double* p, int64_t rs, int64_t cs, int64_t m, int64_t n, const char* what, int panel, int it) {
     if (!dbg_on()) return;
     std::vector<double> h((size_t)(m * n));
-    hipStreamSynchronize(st);
+    (void)hipStreamSynchronize(st);
     for (int64_t i = 0; i < m; ++i)
-        for (int64_t j = 0; j < n; ++j) hipMemcpy(&h[i * n + j], p + i * rs + j * cs, 8, hipMemcpyDeviceToHost);
+        for (int64_t j = 0; j < n; ++j) (void)hipMemcpy(&h[i * n + j], p + i * rs + j * cs, 8, hipMemcpyDeviceToHost);
     double mx = 0, mn = 1e300; int bad = 0;
     for (double v : h) { if (!(v == v) || v > 1e300 || v < -1e300) ++bad; else { double a = v < 0 ? -v : v; if (a > mx) mx = a; if (a < mn) mn = a; } }
     fprintf(stderr, "[tn_qr dbg] panel %d it %d %-10s %lldx%lld nonfinite=%d max=%.3e min|.|=%.3e\n", panel, it, what, (long long)m, (long long)n, bad, mx, mn);
