@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
     constexpr int P = 33;
     __shared__ double T[TS_RB * P];          // staging for coalesced global loads / stores; rows 0..31 double as the head H
     __shared__ double part[256];
-    __shared__ double vbuf[TS_RB];
+    __shared__ __attribute__((aligned(16))) double vbuf[TS_RB];      // accessed as double2 (rb and TS_BODY are even)
     __shared__ double dinv[32];
     const int tid = threadIdx.x, blk = blockIdx.x;
     int64_t r0;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
     const int kmax = b < nr ? b : nr;
     if (c == 0) {
 #pragma unroll
-        for (int k = 0; k < TS_BODY; ++k) vbuf[rb + k] = y[k];
+        for (int k = 0; k < TS_BODY; k += 2) *reinterpret_cast<double2*>(&vbuf[rb + k]) = make_double2(y[k], y[k + 1]);
     }
     TN_CLK(2);
     for (int j = 0; j < kmax; ++j) {
@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
         if (j == 5) TN_CLK(17);
         double v[TS_BODY];
 #pragma unroll
-        for (int k = 0; k < TS_BODY; ++k) v[k] = vbuf[rb + k];
+        for (int k = 0; k < TS_BODY; k += 2) {
+            const double2 t2 = *reinterpret_cast<const double2*>(&vbuf[rb + k]);
+            v[k] = t2.x; v[k + 1] = t2.y;
+        }
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
         for (int k = 0; k < TS_BODY; k += 4) {
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void tsqr_factor_kernel(const double* X, int64
         // every read of vbuf for this column happened before the barrier above, so the next column may be published now
         if (c == j + 1) {
 #pragma unroll
-            for (int k = 0; k < TS_BODY; ++k) vbuf[rb + k] = y[k];
+            for (int k = 0; k < TS_BODY; k += 2) *reinterpret_cast<double2*>(&vbuf[rb + k]) = make_double2(y[k], y[k + 1]);
         }
     }
     TN_CLK(3);
