@@ -283,3 +283,14 @@ def test_peps_factor_and_mpo_builder(ops, rot):
     for ny in range(r.Ny):
         for nx in range(r.Nx):
             np.testing.assert_allclose(host(r._mpo_site_dev(ny, nx)), r._mpo_site(ny, nx), rtol=1e-14, atol=0)
+
+
+def test_linalg_fuzz_against_numpy():
+    """Randomised shapes / structures (plain, graded, rank deficient, zero columns, 1e+-120 scaling, all ones; both memory
+    layouts) through tn_qr, tn_svd_trunc and tn_svdvals: tools/fuzz_linalg.py with a fixed seed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_linalg.py'), '7', '60'], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
