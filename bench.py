@@ -96,15 +96,25 @@ def main():
     ap.add_argument('--sample', type=int, default=8,
                     help='in the timed region bracket every n-th launch of the dominant kernel family with events')
     ap.add_argument('--no-search', action='store_true', help='skip the (untimed) full search_ground_state figure')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise the RCCL process group even with one rank (rehearses the multi-GPU code path on one GPU)')
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line (rank 0): everything the libraries print while we work (RCCL's version banner
+    # goes to stdout) is routed to stderr, and the real stdout is restored just before the line is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        for k, v in (('RANK', '0'), ('WORLD_SIZE', '1'), ('MASTER_PORT', '29533')):
+            os.environ.setdefault(k, v)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
@@ -263,7 +273,10 @@ def main():
             out['full_search_single_chain'] = search_info
         if args.cpu_rows > 0:
             out['cpu_baseline'] = cpu_baseline(J, n, args, solver, kw)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
