@@ -71,6 +71,9 @@ int64_t tn_svd_ws_bytes(int64_t k, int64_t n, int vectors);
 /* ---- K6: out2[0] = 2^floor(log2 max|x|), out2[1] = 1/out2[0] (device).  Replaces mps.nfactor (mps.py:76-85).
  * slot8: 8 bytes of device scratch. */
 int tn_nfactor(const double* x, int64_t n, double* out2, void* slot8, void* stream);
+/* x /= nfactor(x) in place and out2 = [nfactor, 1/nfactor] (the fused form of tn_nfactor + tn_scale_by used after every QR,
+ * mps.py:781-782, 796-797): two launches, no memset.  scratch: >= 8 KiB of device memory owned by the caller. */
+int tn_normalize_pow2(double* x, int64_t n, double* out2, void* scratch, int64_t scratch_bytes, void* stream);
 /* x[i] *= scalar_dev[0]  (used with out2+1 of tn_nfactor: mps.py:782, 797; tnac4o.py:533, 1781) */
 int tn_scale_by(double* x, int64_t n, const double* scalar_dev, void* stream);
 /* A[dl, s, dr] *= diag[s] (inv=0) or /= diag[s] (inv=1).  Replaces MPS.apply_diagonalO (mps.py:361-366). */

@@ -125,8 +125,14 @@ def test_nfactor_probe(ops):
     f = host(ops.nfactor_dev(dev(X)))
     assert f[0] == mr.pow2_floor_max(X)
     d = dev(X)
-    ops.normalize_pow2_(d)
+    f2 = host(ops.normalize_pow2_(d))
     assert np.array_equal(host(d), X / mr.pow2_floor_max(X))
+    assert f2[0] == mr.pow2_floor_max(X) and f2[1] == 1.0 / f2[0]
+    for shape in ((1, 1), (3, 5), (300, 7000), (4096, 1024)):          # one block ... the 1024-block cap of the two-launch form
+        Z = np.random.default_rng(shape[0]).standard_normal(shape) * 10.0 ** np.random.default_rng(shape[1]).uniform(-30, 30)
+        dz = dev(Z)
+        fz = host(ops.normalize_pow2_(dz))
+        assert fz[0] == mr.pow2_floor_max(Z) and np.array_equal(host(dz), Z / mr.pow2_floor_max(Z))
     Y = np.random.default_rng(1).standard_normal((5, 77))
     dY = dev(Y)
     ops.nfactor_batched_(dY)

@@ -29,6 +29,7 @@ SIGNATURES = {
     'tn_svd_ws_bytes': (_i64, [_i64, _i64, _int]),
     'tn_nfactor': (_int, [_ptr, _i64, _ptr, _ptr, _ptr]),
     'tn_scale_by': (_int, [_ptr, _i64, _ptr, _ptr]),
+    'tn_normalize_pow2': (_int, [_ptr, _i64, _ptr, _ptr, _i64, _ptr]),
     'tn_scale_phys': (_int, [_ptr, _i64, _i64, _i64, _ptr, _int, _ptr]),
     'tn_calc_pn': (_int, [_ptr] * 9 + [_i64] * 7 + [_ptr, _ptr, _ptr]),
     'tn_nfactor_batched': (_int, [_ptr, _i64, _i64, _ptr]),

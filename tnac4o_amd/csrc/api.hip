@@ -27,6 +27,7 @@ int svd_vals(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, dou
 int64_t svd_ws_bytes(int64_t, int64_t, int);
 int nfactor(hipStream_t, const double*, int64_t, double*, void*);
 int scale_by(hipStream_t, double*, int64_t, const double*);
+int normalize_pow2(hipStream_t, double*, int64_t, double*, void*, int64_t);
 int scale_phys(hipStream_t, double*, int64_t, int64_t, int64_t, const double*, int);
 int calc_pn(hipStream_t, const double*, const double*, const double*, const int32_t*, const int32_t*, const int32_t*,
             const int32_t*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, double*,
@@ -128,6 +129,10 @@ int64_t tn_svd_ws_bytes(int64_t k, int64_t n, int vectors) { return svd_ws_bytes
 int tn_nfactor(const double* x, int64_t n, double* out2, void* slot8, void* stream) {
     TN_CHECK_ARG(x && out2 && slot8, "null operand");
     return nfactor(ST, x, n, out2, slot8);
+}
+int tn_normalize_pow2(double* x, int64_t n, double* out2, void* scratch, int64_t scratch_bytes, void* stream) {
+    TN_CHECK_ARG(x && out2 && scratch, "null operand");
+    return normalize_pow2(ST, x, n, out2, scratch, scratch_bytes);
 }
 int tn_scale_by(double* x, int64_t n, const double* scalar_dev, void* stream) {
     TN_CHECK_ARG(x && scalar_dev, "null operand");

@@ -50,6 +50,60 @@ int nfactor(hipStream_t st, const double* x, int64_t n, double* out2, void* slot
     return 0;
 }
 
+// x /= nfactor(x) in two launches and without a memset: per-block maxima into `scratch`, then every block of the scaling
+// kernel reduces those (<= 1024 values) itself; block 0 also publishes [nf, 1/nf].
+__global__ __launch_bounds__(256) void absmax_blocks_kernel(const double* __restrict__ x, int64_t n,
+                                                            unsigned long long* __restrict__ scratch) {
+    __shared__ unsigned long long red[4];
+    const int tid = threadIdx.x;
+    unsigned long long m = 0ULL;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(x[i]));
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+        scratch[blockIdx.x] = a > b ? a : b;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_by_blockmax_kernel(double* __restrict__ x, int64_t n,
+                                                                const unsigned long long* __restrict__ scratch, int nparts,
+                                                                double* __restrict__ out2) {
+    __shared__ unsigned long long red[4];
+    const int tid = threadIdx.x;
+    unsigned long long m = 0ULL;
+    for (int i = tid; i < nparts; i += 256) { const unsigned long long b = scratch[i]; m = b > m ? b : m; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    unsigned long long a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+    a = a > b ? a : b;
+    const double f = ldexp(1.0, (int)((long long)(a >> 52) - 1023)), inv = 1.0 / f;
+    if (blockIdx.x == 0 && tid == 0) { out2[0] = f; out2[1] = inv; }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) x[i] *= inv;
+}
+
+int normalize_pow2(hipStream_t st, double* x, int64_t n, double* out2, void* scratch, int64_t scratch_bytes) {
+    TN_CHECK_ARG(n >= 1, "empty input");
+    int64_t nb = cdiv(n, 256 * 8);
+    if (nb > 1024) nb = 1024;
+    TN_CHECK_ARG(scratch_bytes >= nb * 8, "scratch too small (8 KiB always suffices)");
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(absmax_blocks_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, n, (unsigned long long*)scratch));
+    TN_CHECK_LAUNCH("absmax_blocks_kernel");
+    int64_t ns = cdiv(n, 256 * 4);
+    if (ns > 2048) ns = 2048;
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(scale_by_blockmax_kernel, dim3((unsigned)ns), dim3(256), 0, st, x, n,
+                       (const unsigned long long*)scratch, (int)nb, out2));
+    TN_CHECK_LAUNCH("scale_by_blockmax_kernel");
+    return 0;
+}
+
 int scale_by(hipStream_t st, double* x, int64_t n, const double* scalar_dev) {
     if (n <= 0) return 0;
     int64_t nb = cdiv(n, 256 * 4);

@@ -164,10 +164,13 @@ def scale_(T, scalar_dev):
 
 
 def normalize_pow2_(T):
-    """T /= nfactor(T) in place; returns the device pair [nf, 1/nf]."""
-    f = nfactor_dev(T)
-    scale_(T, f[1:2])
-    return f
+    """T /= nfactor(T) in place; returns the device pair [nf, 1/nf] (tn_normalize_pow2)."""
+    _need_gpu(T)
+    assert T.is_contiguous()
+    out = torch.empty(2, dtype=torch.float64, device=T.device)
+    scratch = workspace(8192, 3)
+    check(lib().tn_normalize_pow2(T.data_ptr(), T.numel(), out.data_ptr(), scratch.data_ptr(), 8192, _stream()))
+    return out
 
 
 def scale_phys_(A, diag, inv=False):
