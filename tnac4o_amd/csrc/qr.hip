@@ -15,6 +15,7 @@
 // matrices this path produces (validated against LAPACK on matrices captured from the droplet sweeps).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -516,21 +517,26 @@ __global__ __launch_bounds__(256) void init_Q_kernel(double* __restrict__ Q, int
     Q[i * rs + j * cs] = v;
 }
 
-// max over columns of sum_i A(i,j)^2 for an (m x n) block -> atomicMax on the bit pattern in slot (pre-zeroed)
-__global__ __launch_bounds__(256) void colnorm2_max_kernel(const double* __restrict__ A, int64_t rs, int64_t cs, int64_t m,
-                                                           int64_t n, unsigned long long* __restrict__ slot) {
-    __shared__ double red[256];
+// out[j] = sum_i A(i,j)^2 for the columns of an (m x n) block (the host takes the maximum: no atomics, nothing to pre-zero)
+__global__ __launch_bounds__(256) void colnorm2_kernel(const double* __restrict__ A, int64_t rs, int64_t cs, int64_t m,
+                                                       int64_t n, double* __restrict__ out) {
+    __shared__ double red[4];
     const int tid = threadIdx.x;
     const int64_t j = blockIdx.x;
-    double s = 0.0;
-    for (int64_t i = tid; i < m; i += 256) { const double x = A[i * rs + j * cs]; s += x * x; }
-    red[tid] = s;
-    __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if (tid < k) red[tid] += red[tid + k];
-        __syncthreads();
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t i = tid;
+    for (; i + 768 < m; i += 1024) {                      // four independent loads in flight
+        const double x0 = A[i * rs + j * cs], x1 = A[(i + 256) * rs + j * cs], x2 = A[(i + 512) * rs + j * cs],
+                     x3 = A[(i + 768) * rs + j * cs];
+        s0 += x0 * x0; s1 += x1 * x1; s2 += x2 * x2; s3 += x3 * x3;
     }
-    if (tid == 0) atomicMax(slot, (unsigned long long)__double_as_longlong(red[0]));
+    for (; i < m; i += 256) { const double x = A[i * rs + j * cs]; s0 += x * x; }
+    double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[j] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------------------ driver
@@ -549,7 +555,7 @@ static void dbg_check(hipStream_t st, const double* p, int64_t rs, int64_t cs, i
 
 struct QrWs {
     double *Y, *Wq, *W, *UT, *UTq;
-    double *T, *X, *X2, *part, *Js, *Uinv, *Z, *Tri, *gemm_ws;
+    double *T, *X, *X2, *part, *Js, *Uinv, *Z, *Tri, *gemm_ws, *cn;
     int* dead;
     int64_t gemm_ws_bytes;
     void* tsqr_ws;
@@ -574,6 +580,7 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     double* Z = (double*)take(P * nb * nb * 8);
     double* Tri = (double*)take(P * nb * nb * 8);
     int* dead = (int*)take(nb * 4);
+    double* cn = (double*)take(2 * n * 8);            // column norms^2: [input | current trailing block]
     // split-K scratch for the tall TN products (b x n, K = m)
     int64_t gw = (int64_t)64 * nb * (n > k ? n : k) * 8;      // upper bound of pick_splitk's partial buffers
     double* gws = (double*)take(gw + 256);
@@ -582,7 +589,7 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     if (w) { w->tsqr_ws = tsw; w->tsqr_bytes = tsb; }
     if (w) { w->Wq = Wq; w->W = Wp; w->UT = UT; w->UTq = UTq; }
     if (w) { w->Y = Y; w->T = T; w->X = X; w->X2 = X2; w->part = part; w->Js = Js; w->Uinv = Uinv; w->Z = Z; w->Tri = Tri;
-             w->dead = dead; w->gemm_ws = gws; w->gemm_ws_bytes = gw; }
+             w->dead = dead; w->gemm_ws = gws; w->gemm_ws_bytes = gw; w->cn = cn; }
     return off;
 }
 
@@ -605,14 +612,11 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
     int64_t k = m < n ? m : n;
     int P = (int)cdiv(k, nb);
     const int64_t kfull = k;
-    unsigned long long* slots = (unsigned long long*)w.dead;         // 2 x 8 bytes of scratch (the nb=64 path's flags)
-    double scale2 = 0.0;
+    double scale2 = -1.0;                                            // largest squared column norm of the input (lazily read back)
     const bool reveal = rank_tol > 0.0 && keff_host != nullptr && P > 2 && nb == 32;
     if (reveal) {
-        hipError_t e = hipMemsetAsync(slots, 0, 16, st);
-        if (e != hipSuccess) return hip_fail(e, "memset slots");
-        TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_max_kernel, dim3((unsigned)n), dim3(256), 0, st, A, rs, cs, m, n, slots));
-        TN_CHECK_LAUNCH("colnorm2_max_kernel");
+        TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_kernel, dim3((unsigned)n), dim3(256), 0, st, A, rs, cs, m, n, w.cn));
+        TN_CHECK_LAUNCH("colnorm2_kernel");
     }
     // Y shares A's fast direction so panel kernels coalesce the same way
     const bool rowmajor = (cs == 1 && rs != 1);
@@ -679,15 +683,24 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         if ((rc = gemm(st, mp, ntr, b, -1.0, Wp, Xm, 1.0, Ap))) return rc;
         if (reveal && (p & 1) == 1 && p + 1 < P) {
             const int64_t j1 = j0 + b;
-            hipError_t e = hipMemsetAsync(slots + 1, 0, 8, st);
-            if (e != hipSuccess) return hip_fail(e, "memset slot");
-            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_max_kernel, dim3((unsigned)(n - j1)), dim3(256), 0, st, sub(Am, j1, j1).p, rs, cs, m - j1,
-                               n - j1, slots + 1));
-            TN_CHECK_LAUNCH("colnorm2_max_kernel");
-            double h[2];
-            if ((e = hipMemcpyAsync(h, slots, 16, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy norms");
+            const int64_t nt = n - j1;
+            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_kernel, dim3((unsigned)nt), dim3(256), 0, st, sub(Am, j1, j1).p, rs, cs, m - j1,
+                               nt, w.cn + n));
+            TN_CHECK_LAUNCH("colnorm2_kernel");
+            // one read-back: the trailing norms, and (first check only) the input norms stored in front of them
+            std::vector<double> hcn((size_t)(scale2 < 0.0 ? n + nt : nt));
+            hipError_t e;
+            if ((e = hipMemcpyAsync(hcn.data(), scale2 < 0.0 ? w.cn : w.cn + n, hcn.size() * 8, hipMemcpyDeviceToHost, st)) != hipSuccess)
+                return hip_fail(e, "memcpy norms");
             if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync norms");
-            scale2 = h[0];
+            const double* tr2 = hcn.data();
+            if (scale2 < 0.0) {
+                scale2 = 0.0;
+                for (int64_t j = 0; j < n; ++j) scale2 = std::max(scale2, hcn[j]);
+                tr2 = hcn.data() + n;
+            }
+            double h[2] = {scale2, 0.0};
+            for (int64_t j = 0; j < nt; ++j) h[1] = std::max(h[1], tr2[j]);
             if (h[1] <= rank_tol * rank_tol * scale2) {       // nothing left above the threshold: stop here
                 k = j1;
                 P = p + 1;

@@ -12,6 +12,7 @@
 // one-sided Jacobi accuracy.  Host syncs: one for deflation, one per sweep (convergence), one for the kept rank.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -52,9 +53,9 @@ __global__ __launch_bounds__(256) void svd_init_kernel(const double* __restrict_
 // with the reference's sign gauge: flip when in both vectors the most negative entry outweighs the most positive.
 __global__ __launch_bounds__(256) void svd_gather_kernel(const double* __restrict__ X, int64_t L, const double* __restrict__ P,
                                                          int64_t nv, int64_t pitch, const int* __restrict__ order,
-                                                         const double* __restrict__ Ssorted, double* __restrict__ left,
-                                                         int64_t lrs, int64_t lcs, double* __restrict__ right, int64_t rrs,
-                                                         int64_t rcs) {
+                                                         const double* __restrict__ Ssorted, double* __restrict__ Sout,
+                                                         double* __restrict__ left, int64_t lrs, int64_t lcs,
+                                                         double* __restrict__ right, int64_t rrs, int64_t rcs) {
     __shared__ double rmin[256], rmax[256];
     __shared__ double sgn;
     const int j = blockIdx.x, tid = threadIdx.x;
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void svd_gather_kernel(const double* __restric
     }
     __syncthreads();
     const double s = sgn, sv = Ssorted[j];
+    if (tid == 0) Sout[j] = sv;
     const double inv = sv > 0.0 ? s / sv : 0.0;
     for (int64_t c = tid; c < L; c += 256) right[(int64_t)j * rrs + c * rcs] = x[c] * inv;
     for (int64_t c = tid; c < nv; c += 256) left[c * lrs + (int64_t)j * lcs] = p[c] * s;
@@ -286,16 +288,19 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     const int nvl = (int)live.size();
     const int64_t nvp = align_up(nvl, 2 * SVD_W);
     const int nblk = (int)(nvp / SVD_W), ng = nblk / 2, nr = nblk - 1;
-    if ((e = hipMemcpyAsync(w.live, live.data(), nvl * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy live");
+    // live list and round-robin schedule go up in ONE copy: w.live and w.pairs are neighbours in the workspace; the host
+    // buffer lives until the end of this function, past the first stream synchronisation below
+    std::vector<int> pairs;
+    round_robin(nblk, pairs);
+    const size_t gap = (size_t)((char*)w.pairs - (char*)w.live) / 4;
+    std::vector<int> hinit(gap + pairs.size(), 0);
+    std::copy(live.begin(), live.end(), hinit.begin());
+    std::copy(pairs.begin(), pairs.end(), hinit.begin() + gap);
+    if ((e = hipMemcpyAsync(w.live, hinit.data(), hinit.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy init");
     const int64_t pitch = L + (vectors ? nv : 0);
     TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_init_kernel, dim3((unsigned)nvp), dim3(256), 0, st, M, vs, es, L, nv, w.live, nvl, w.X,
                        vectors ? w.P : nullptr, pitch));
     TN_CHECK_LAUNCH("svd_init_kernel");
-    std::vector<int> pairs;
-    round_robin(nblk, pairs);
-    if ((e = hipMemcpyAsync(w.pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy pairs");
-    // the host vectors above must outlive the async copies
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync init");
 
     const int nchunk = gram_nchunk(L);
     const int nvec = 2 * SVD_W;
@@ -375,15 +380,19 @@ int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t
     if (discarded_out) *discarded_out = std::sqrt(d2) / hS[0];
     if (keep == 0) return 0;
     hipError_t e;
-    if ((e = hipMemcpyAsync(w.order, hO.data(), keep * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy order");
-    if ((e = hipMemcpyAsync(w.Ssorted, hS.data(), keep * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy S");
-    if ((e = hipMemcpyAsync(S, w.Ssorted, keep * 8, hipMemcpyDeviceToDevice, st)) != hipSuccess) return hip_fail(e, "copy S");
+    // kept singular values and their row order go up in one copy into the (now free) norms | Ssorted area: [S | order]
+    std::vector<char> hpack((size_t)keep * 12);
+    std::memcpy(hpack.data(), hS.data(), (size_t)keep * 8);
+    std::memcpy(hpack.data() + (size_t)keep * 8, hO.data(), (size_t)keep * 4);
+    double* dS = w.norms;
+    const int* dO = (const int*)((const char*)w.norms + (size_t)keep * 8);
+    if ((e = hipMemcpyAsync(w.norms, hpack.data(), hpack.size(), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy S/order");
     // rows: left = U (k x keep), right = Vt.  columns (C^T was factored): left = Vt^T, right = U^T.
     if (rows)
-        TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, w.order, w.Ssorted,
+        TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, dO, dS, S,
                            U, urs, ucs, Vt, vrs, vcs));
     else
-        TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, w.order, w.Ssorted,
+        TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, dO, dS, S,
                            Vt, vcs, vrs, U, ucs, urs));
     TN_CHECK_LAUNCH("svd_gather_kernel");
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync gather");   // hS/hO go out of scope
