@@ -30,12 +30,14 @@ def run_concurrent(fns):
     # stream bookkeeping and was not isolated.
     streams = [torch.cuda.Stream() for _ in range(n)]
     out, err = [None] * n, [None] * n
-    cur = torch.cuda.current_stream()
+    # The caller's pending work must be visible to the chains: wait for it on the HOST.  streams[i].wait_stream(current)
+    # would record an event on the (legacy) default stream, after which every launch of the chain pays for a dependency on
+    # it: 1.51 -> 1.62 s/sweep with fresh streams, 1.64 -> 2.36 with reused ones (tools/stream_regime_experiment.py).
+    torch.cuda.current_stream().synchronize()
 
     def work(i):
         try:
             with torch.cuda.stream(streams[i]):
-                streams[i].wait_stream(cur)
                 out[i] = fns[i]()
                 streams[i].synchronize()
         except BaseException as e:      # noqa: BLE001 - re-raised in the caller's thread
