@@ -23,7 +23,10 @@
 extern "C" {
 #endif
 
+/* version of this C-ABI (bumped whenever a signature below changes; the binding checks it at load time) */
 int tn_version(void);
+/* copies the hash of the sources the library was built from (set by the build recipe) into buf; returns its length */
+int tn_build_id(char* buf, int n);
 /* copies the calling thread's last error text into buf (NUL-terminated); returns its length */
 int tn_last_error(char* buf, int n);
 

@@ -29,22 +29,109 @@ def gpu_solver(L=128, ins=1, rot=0, beta=3.0, pre=False, J=None):
 
 
 # ------------------------------------------------------------------------------------------------ G6 on the HIP path
-@pytest.mark.parametrize('rot,chi', [(0, 8), (3, 8), (0, 32)])
-def test_g6_marginals_hip(rot, chi):
-    """_setup_RR + _calculate_Pn + RL update (reference tnac4o.py:1768-1807, 528-535) on the GPU: the `newprob` tables of
-    9-10 site-steps captured from the reference, incl. the rot=3 run whose tables contain negative entries.
-    Pn: 1e-10 relative with an absolute floor of 1e-13 on the normalised table — entries below that are
-    the rounding noise of the contraction itself (the negative-probability rule replaces them by |min| ~ 5e-14)."""
+G6_CASES = [(0, 8), (3, 8), (0, 32)]
+
+
+def _oracle(rot):
+    from oracle import solver_ref as sr
+    o = sr.RefSolver(mode='Ising', Nx=4, Ny=4, Nc=8, J=gi.droplet_J(128, 1), beta=3.0)
+    if rot:
+        o.rotate_graph(rot)
+    return o
+
+
+def _as_ref_chain(m):
+    from oracle import mps_ref as mr
+    r = mr.RefMPS(d=[int(a.shape[1]) for a in m.A], L=len(m.A), Dmax=1, canonise=None)
+    r.A = [a.detach().cpu().numpy() for a in m.A]
+    r.D = list(m.D)
+    return r
+
+
+@pytest.mark.parametrize('rot,chi', G6_CASES)
+def test_g6_beam_kernels_vs_oracle_on_same_boundary(rot, chi):
+    """The marginals machinery proper: _setup_RR (K9), _calculate_Pn incl. the negative-probability rule (K8) and the RL
+    update (reference tnac4o.py:1768-1807, 528-535) on the GPU against the CPU oracle's restatement of the same lines, both
+    reading the SAME boundary MPS (the GPU's, handed to the oracle through its sweep hook).  Every conditional table of the
+    whole search (16 site-steps, up to 1024 branches x 256 states) at 1e-10 relative; min-probability flags likewise.
+    Measured on the MI355X: <= 3e-13 relative."""
+    s = gpu_solver(rot=rot)
+    tr = []
+    s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi, trace=tr)
+    o = _oracle(rot)
+
+    def hook(solver, run):
+        solver.rhoT = [_as_ref_chain(m) for m in s.rhoT]
+        solver.rhoT_overlap, solver.rhoT_discarded = list(s.rhoT_overlap), list(s.rhoT_discarded)
+    tro = []
+    o.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi, trace=tro, sweep_hook=hook)
+    assert len(tr) == len(tro) == 16
+    for a, b in zip(tr, tro):
+        assert a[2].shape == b[2].shape and np.array_equal(a[4], b[4])          # same branches, same boundary indices
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(a[3], b[3], rtol=1e-8, atol=1e-14)
+    assert s.energy[0] == o.energy[0] and np.array_equal(s.states, o.states)
+    assert s.probability[0] == pytest.approx(o.probability[0], abs=1e-12)
+    assert s.negative_probability == pytest.approx(o.negative_probability, rel=1e-8, abs=1e-14)
+
+
+_G6_SPREAD = {}
+
+
+def g6_reference_spread(rot, chi):
+    """Per recorded site-step: how far the reference algorithm's OWN tables move under rounding-level changes -- every QR
+    input perturbed by 1e-16 relative, and LAPACK's gesdd swapped for gesvd (the survey's probe).  The
+    truncated boundary MPS is an ill-conditioned function of its input wherever kept and discarded Schmidt values are
+    close, so some entries amplify eps by ~1e7; this measures that amplification on the instance at hand."""
+    import scipy.linalg
+    from oracle import mps_ref as mr
+    key = (rot, chi)
+    if key in _G6_SPREAD:
+        return _G6_SPREAD[key]
+    g = load('g6_pn.npz')
+    tag = 'L128_r%d_chi%d' % (rot, chi)
+    spread = {}
+    for probe in ('qr', 'svd'):
+        orig_qr, orig_svd = mr.qr_pos, scipy.linalg.svd
+        if probe == 'qr':
+            rng = np.random.default_rng(0)
+            mr.qr_pos = lambda T: orig_qr(T * (1 + 1e-16 * rng.standard_normal(T.shape)))
+        else:
+            scipy.linalg.svd = lambda a, *args, **kw: orig_svd(a, *args, **dict(kw, lapack_driver='gesvd'))
+        try:
+            o = _oracle(rot)
+            tr = []
+            o.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi, trace=tr)
+        finally:
+            mr.qr_pos, scipy.linalg.svd = orig_qr, orig_svd
+        for k in g[tag + '_steps']:
+            st = int(g[tag + '_stride%d' % k][0])
+            d = float(np.abs(tr[k][2][::st] - g[tag + '_P%d' % k]).max())
+            spread[int(k)] = max(spread.get(int(k), 0.0), d)
+    _G6_SPREAD[key] = spread
+    return spread
+
+
+@pytest.mark.parametrize('rot,chi', G6_CASES)
+def test_g6_marginals_hip_vs_reference_golden(rot, chi):
+    """End to end (GPU sweep + GPU beam) against the `newprob` tables captured from the reference at 9-10 site-steps, incl.
+    the rot=3 run whose tables contain negative entries.  Tolerance per table: 1e-10 relative or, in
+    absolute terms on the normalised table, 100x the movement of the reference algorithm's own tables under eps-level
+    probes (g6_reference_spread) with a floor of 1e-12.  The beam kernels themselves agree with the oracle to 3e-13 on a
+    common boundary MPS (previous test): what is left here is the conditioning of the truncated sweep (measured on the
+    MI355X: worst table 2.3e-10 absolute at chi=32, where the probes move the reference by 8e-12)."""
     g = load('g6_pn.npz')
     tag = 'L128_r%d_chi%d' % (rot, chi)
     trace = []
     s = gpu_solver(rot=rot)
     s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi, trace=trace)
     assert [t[2].shape[0] for t in trace] == list(g[tag + '_nbranch'])
+    spread = g6_reference_spread(rot, chi)
     for k in g[tag + '_steps']:
         st = int(g[tag + '_stride%d' % k][0])
-        np.testing.assert_allclose(trace[k][2][::st], g[tag + '_P%d' % k], rtol=1e-10, atol=1e-13)
-        np.testing.assert_allclose(trace[k][3][::st], g[tag + '_min%d' % k], rtol=1e-2, atol=1e-13)
+        atol = max(1e-12, 100.0 * spread[int(k)])
+        np.testing.assert_allclose(trace[k][2][::st], g[tag + '_P%d' % k], rtol=1e-10, atol=atol)
+        np.testing.assert_allclose(trace[k][3][::st], g[tag + '_min%d' % k], rtol=1e-2, atol=atol)
     assert s.negative_probability == pytest.approx(g[tag + '_neg'][0], rel=1e-2, abs=1e-13)
 
 

@@ -15,6 +15,7 @@ _i64, _f64, _int, _ptr = C.c_int64, C.c_double, C.c_int, C.c_void_p
 SIGNATURES = {
     'tn_version': (_int, []),
     'tn_last_error': (_int, [C.c_char_p, _int]),
+    'tn_build_id': (_int, [C.c_char_p, _int]),
     'tn_gemm': (_int, [_i64, _i64, _i64, _f64, _ptr, _i64, _i64, _ptr, _i64, _i64, _f64, _ptr, _i64, _i64,
                        _i64, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     'tn_gemm_ws_bytes': (_i64, [_i64, _i64, _i64, _i64]),
@@ -43,26 +44,42 @@ SIGNATURES = {
 }
 
 
+def source_hash():
+    """sha256 over csrc/* and include/tnpeps.h (sorted by name): identifies the sources a library was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
+    files.append(os.path.join(HERE, '..', 'include', 'tnpeps.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:32]
+
+
 def build(verbose=False):
-    """Compile libtnpeps.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile libtnpeps.so in-tree for gfx950 (hipcc cross-compiles without a GPU).  The hash of the sources is compiled
+    in (tn_build_id) so that lib() can refuse a library that does not match the sources next to it."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB_PATH] + \
-          os.environ.get('TN_EXTRA_HIPCC_FLAGS', '').split() + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DTN_SRC_HASH="%s"' % source_hash(),
+           '-o', LIB_PATH] + os.environ.get('TN_EXTRA_HIPCC_FLAGS', '').split() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
     return LIB_PATH
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'tnpeps.h')]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+def _stale(L):
+    """True when the loaded library was built from other sources than the ones in the tree (content hash, so copying
+    the tree to another machine does not matter)."""
+    buf = C.create_string_buffer(64)
+    L.tn_build_id.restype, L.tn_build_id.argtypes = _int, [C.c_char_p, _int]
+    L.tn_build_id(buf, 64)
+    return buf.value.decode() != source_hash()
 
 
 _lib = None
+ABI_VERSION = 2          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
 
 
 def lib():
@@ -73,6 +90,14 @@ def lib():
             raise RuntimeError('libtnpeps.so not found at %s: run `python -c "import __graft_entry__ as g; g.build()"` '
                                '(the HIP library is the only backend; there is no CPU fallback)' % LIB_PATH)
         L = C.CDLL(LIB_PATH)
+        L.tn_version.restype = _int
+        if not hasattr(L, 'tn_build_id') or (_stale(L) and not os.environ.get('TN_ALLOW_STALE_LIB')):
+            raise RuntimeError('libtnpeps.so was built from other sources than csrc/*.hip + include/tnpeps.h in this tree: '
+                               'rebuild it with `python -c "import __graft_entry__ as g; g.build()"` -- a stale library can '
+                               'disagree with the ctypes signatures declared here')
+        if L.tn_version() != ABI_VERSION:
+            raise RuntimeError('libtnpeps.so implements C-ABI version %d, this package binds version %d: rebuild the library'
+                               % (L.tn_version(), ABI_VERSION))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args

@@ -44,7 +44,21 @@ using namespace tn;
 
 extern "C" {
 
-int tn_version(void) { return 1; }
+int tn_version(void) { return 2; }
+
+#ifndef TN_SRC_HASH
+#define TN_SRC_HASH "unknown"
+#endif
+int tn_build_id(char* buf, int n) {
+    const char* e = TN_SRC_HASH;
+    const int len = (int)strlen(e);
+    if (buf && n > 0) {
+        const int c = len < n - 1 ? len : n - 1;
+        memcpy(buf, e, c);
+        buf[c] = 0;
+    }
+    return len;
+}
 
 void tn_profile_enable(unsigned mask) { prof_set_mask(mask); }
 void tn_profile_reset(void) { prof_reset(); }

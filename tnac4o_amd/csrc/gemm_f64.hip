@@ -267,7 +267,17 @@ int gemm_ex(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const
     if (s > 1) g.splitk = s = (int)cdiv(K, g.kchunk);
     if (raw && s == 1) g.splitk = -1;          // single "partial": still written to ws (handled below)
     if (x && x->splitk_used) *x->splitk_used = s;
-    TN_CHECK_ARG(batch * s <= 65535, "batch*splitk exceeds grid.z");
+    if (batch * s > 65535) {      // grid.z limit: run the batch in slices (same stream, so the split-K scratch can be reused)
+        TN_CHECK_ARG(x == nullptr && s <= 65535, "batch*splitk exceeds grid.z");
+        const int64_t cb = 65535 / s;
+        for (int64_t b0 = 0; b0 < batch; b0 += cb) {
+            const int64_t nbt = batch - b0 < cb ? batch - b0 : cb;
+            const int rc = gemm_ex(st, M, N, K, alpha, A + b0 * bsa, rsa, csa, B + b0 * bsb, rsb, csb, beta, C + b0 * bsc, rsc, csc,
+                                   nbt, bsa, bsb, bsc, ws, ws_bytes, nullptr);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     const bool ak = (csa == 1 && rsa != 1), bk = (rsb == 1 && csb != 1);
     dim3 grid(g.tiles_m * g.tiles_n, 1, (unsigned)(batch * s));
     const int fam = (bm == 128 && bn == 128) ? PROF_GEMM_128x128 : (bm == 128) ? PROF_GEMM_128x32

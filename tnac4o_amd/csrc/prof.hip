@@ -1,7 +1,9 @@
 // Optional per-kernel-family timing with HIP events on the launch stream (used by bench.py for the roofline line).
 // Disabled by default: prof_begin/prof_end are then two predictable branches.  When a family is enabled, every launch
 // of it is bracketed by an event pair recorded on its own stream.  State is per host thread (one thread drives one
-// stream / one chain), so concurrent chains never share a ring; totals are summed over threads on request.
+// stream / one chain), so concurrent chains never share a ring; totals are summed over threads on request.  A thread
+// that exits folds its totals into a process-wide accumulator and destroys its events (run_concurrent spawns fresh
+// threads per call); the event ring starts at 256 pairs and doubles on demand up to 8192.
 #include <mutex>
 #include <vector>
 
@@ -37,15 +39,34 @@ static unsigned g_mask = 0;
 static unsigned g_sample = 1;          // bracket every g_sample-th launch of an enabled family
 static std::mutex g_mu;
 static std::vector<ThreadProf*> g_all;
+static Fam g_dead[PH_N][PROF_NFAM];    // totals of threads that have exited
+
+struct ThreadSlot {                    // owns the calling thread's state; released when the thread exits
+    ThreadProf* tp = nullptr;
+    ~ThreadSlot() {
+        if (!tp) return;
+        std::lock_guard<std::mutex> lk(g_mu);
+        tp->drain();
+        for (int ph = 0; ph < PH_N; ++ph)
+            for (int f = 0; f < PROF_NFAM; ++f) {
+                g_dead[ph][f].calls += tp->fam[ph][f].calls; g_dead[ph][f].ms += tp->fam[ph][f].ms;
+                g_dead[ph][f].flops += tp->fam[ph][f].flops; g_dead[ph][f].bytes += tp->fam[ph][f].bytes;
+            }
+        for (auto& p : tp->ring) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        for (size_t i = 0; i < g_all.size(); ++i)
+            if (g_all[i] == tp) { g_all[i] = g_all.back(); g_all.pop_back(); break; }
+        delete tp;
+    }
+};
 
 static ThreadProf& mine() {
-    thread_local ThreadProf* tp = nullptr;
-    if (!tp) {
-        tp = new ThreadProf();          // lives for the process (registered below); a handful of threads at most
+    thread_local ThreadSlot slot;
+    if (!slot.tp) {
+        slot.tp = new ThreadProf();
         std::lock_guard<std::mutex> lk(g_mu);
-        g_all.push_back(tp);
+        g_all.push_back(slot.tp);
     }
-    return *tp;
+    return *slot.tp;
 }
 
 bool prof_on(int fam) { return fam < PROF_NKERNEL && ((g_mask >> fam) & 1u); }
@@ -55,11 +76,15 @@ void prof_begin(hipStream_t st, int fam) {
     ThreadProf& t = mine();
     t.armed = (t.seq[fam]++ % g_sample) == 0;
     if (!t.armed) return;
-    if (t.ring.empty()) {
-        t.ring.resize(8192);
-        for (auto& p : t.ring) { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+    if (t.used == t.ring.size()) {
+        if (t.ring.size() < 8192) {                       // grow: 256, 512, ... 8192 event pairs
+            const size_t old = t.ring.size(), now = old ? old * 2 : 256;
+            t.ring.resize(now);
+            for (size_t i = old; i < now; ++i) { (void)hipEventCreate(&t.ring[i].a); (void)hipEventCreate(&t.ring[i].b); }
+        } else {
+            t.drain();
+        }
     }
-    if (t.used == t.ring.size()) t.drain();
     t.ring[t.used].fam = fam;
     t.ring[t.used].ph = t.phase;
     (void)hipEventRecord(t.ring[t.used].a, st);
@@ -105,10 +130,16 @@ void prof_set_sample(unsigned n) { g_sample = n ? n : 1; }
 void prof_reset() {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto* t : g_all) { t->drain(); for (auto& ph : t->fam) for (auto& f : ph) f = Fam(); }
+    for (auto& ph : g_dead) for (auto& f : ph) f = Fam();
 }
 void prof_get(int phase, int fam, uint64_t* calls, double* ms, double* flops, double* bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
     *calls = 0; *ms = 0; *flops = 0; *bytes = 0;
+    for (int ph = 0; ph < PH_N; ++ph) {
+        if (phase >= 0 && ph != phase) continue;
+        const Fam& f = g_dead[ph][fam];
+        *calls += f.calls; *ms += f.ms; *flops += f.flops; *bytes += f.bytes;
+    }
     for (auto* t : g_all) {
         t->drain();
         for (int ph = 0; ph < PH_N; ++ph) {

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import lib, check
+from ._lib import lib, check, TnError
 
 QR_NB = 32
 _ws = {}
@@ -130,6 +130,8 @@ def svd_trunc(Cm, Dmax, tol):
                          U.data_ptr(), U.stride(0), U.stride(1), S.data_ptr(), Vt.data_ptr(), Vt.stride(0), Vt.stride(1),
                          C.byref(keep), C.byref(disc), C.byref(sweeps), C.byref(info), ws.data_ptr(), wsb, _stream()))
     kp = int(keep.value)
+    if info.value != 0:          # the reference's LAPACK path raises LinAlgError when the SVD does not converge (mps.py:31-34)
+        raise TnError('tn_svd_trunc: Jacobi sweeps did not converge on a %d x %d matrix (%d sweeps)' % (k, n, sweeps.value))
     return U[:, :kp], S[:kp], Vt[:kp], kp, float(disc.value), dict(sweeps=sweeps.value, info=info.value)
 
 
@@ -144,6 +146,8 @@ def svdvals(Cm):
     sweeps, info = C.c_int(0), C.c_int(0)
     check(L.tn_svdvals(Cm.data_ptr(), Cm.stride(0), Cm.stride(1), k, n, out.ctypes.data_as(C.POINTER(C.c_double)),
                        C.byref(sweeps), C.byref(info), ws.data_ptr(), wsb, _stream()))
+    if info.value != 0:
+        raise TnError('tn_svdvals: Jacobi sweeps did not converge on a %d x %d matrix (%d sweeps)' % (k, n, sweeps.value))
     return out
 
 

@@ -151,15 +151,37 @@ _HEAD = 6       # energy, degeneracy, log2 P, discarded log2 P, negative probabi
 
 
 def _pack(s, rot, ncell):
-    rec = np.full(_HEAD + ncell, np.nan)
-    rec[0] = float(s.energy[0])
-    rec[1] = float(s.degeneracy)
-    rec[2] = float(s.probability[0])
-    rec[3] = float(s.discarded_probability)
-    rec[4] = float(s.negative_probability)
-    rec[5] = float(rot)
-    rec[_HEAD:] = np.asarray(s.states[0], dtype=np.float64)
+    """One solve as an int64 record: the four float64 results travel as their bit patterns, degeneracy and rotation as
+    integers, the state as integers (i64 / i8 fields, exact for any degeneracy).  Slot 0 of an unused or
+    non-owner record is _EMPTY."""
+    rec = np.zeros(_HEAD + ncell, dtype=np.int64)
+    f = np.array([float(s.energy[0]), float(s.probability[0]), float(s.discarded_probability),
+                  float(s.negative_probability)], dtype=np.float64).view(np.int64)
+    rec[0], rec[2], rec[3], rec[4] = f[0], f[1], f[2], f[3]
+    rec[1] = int(s.degeneracy)
+    rec[5] = int(rot)
+    rec[_HEAD:] = np.asarray(s.states[0], dtype=np.int64)
     return rec
+
+
+_EMPTY = np.array([np.nan]).view(np.int64)[0]      # bit pattern of NaN in the energy slot marks "no record"
+
+
+def _unpack_floats(table):
+    """(energy, log2 P, discarded, negative) columns of a record table as float64."""
+    return [np.ascontiguousarray(table[:, c]).view(np.float64) for c in (0, 2, 3, 4)]
+
+
+_BEAM_GROUPS = {}
+
+
+def _beam_groups(world, B):
+    """Sub-groups of B consecutive ranks, created once per (world, B) (torch.distributed requires every rank to create
+    every group, and groups are never freed, so they are cached for the life of the process group)."""
+    key = (id(dist.distributed_c10d._get_default_group()), world, B)     # a re-initialised process group gets new ones
+    if key not in _BEAM_GROUPS:
+        _BEAM_GROUPS[key] = [dist.new_group(list(range(g * B, (g + 1) * B))) for g in range(world // B)]
+    return _BEAM_GROUPS[key]
 
 
 def solve_rotations(make_solver, rotations=(0, 1, 2, 3), precondition=False, min_dEng=1e-12, group=None,
@@ -188,10 +210,12 @@ def solve_rotations(make_solver, rotations=(0, 1, 2, 3), precondition=False, min
         if group is not None:
             raise ValueError('beam_shards > 1 works on the default process group')
         ngroups = world // B
-        for g in range(ngroups):                  # every rank creates every sub-group (torch.distributed rule)
-            h = dist.new_group(list(range(g * B, (g + 1) * B)))
-            if g == rank // B:
-                beam_group = h
+        beam_group = _beam_groups(world, B)[rank // B]
+        if concurrent:
+            # the rotations of a rank would issue their collectives on the shared sub-group from several host threads in
+            # an order that differs between ranks: refuse instead of hanging
+            raise ValueError('concurrent=True cannot be combined with beam_shards > 1 (collectives of a team must be '
+                             'issued in one order)')
         owner = (rank % B == 0)
         team, nteams = rank // B, ngroups
     else:
@@ -212,7 +236,7 @@ def solve_rotations(make_solver, rotations=(0, 1, 2, 3), precondition=False, min
             s.search_ground_state(**search_kwargs)
         rec = _pack(s, rot, s.states.shape[1])
         if not owner:
-            rec[0] = np.nan                       # partners hold the same result; only the owner's record is counted
+            rec[0] = _EMPTY                       # partners hold the same result; only the owner's record is counted
         return rec
     if concurrent and len(mine) > 1:        # this rank's rotations interleave on the GPU, one stream each
         local = run_concurrent([(lambda r=rot: one(r)) for rot in mine])
@@ -223,29 +247,31 @@ def solve_rotations(make_solver, rotations=(0, 1, 2, 3), precondition=False, min
     if ncell is None:                       # a rank without work still takes part in the gather
         probe = make_solver()
         ncell = probe.Nx * probe.Ny
-    buf = np.full((slots, _HEAD + ncell), np.nan)
+    buf = np.zeros((slots, _HEAD + ncell), dtype=np.int64)
+    buf[:, 0] = _EMPTY
     for i, rec in enumerate(local):
         buf[i] = rec
     if ready and world > 1:
         backend = dist.get_backend(group)
         dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
-        mine_t = torch.as_tensor(buf, dtype=torch.float64).to(dev)
+        mine_t = torch.as_tensor(buf, dtype=torch.int64).to(dev)
         out = [torch.empty_like(mine_t) for _ in range(world)]
         dist.all_gather(out, mine_t, group=group)          # the single exchange of the whole solve
         table = torch.stack(out).cpu().numpy().reshape(world * slots, -1)
     else:
         table = buf
-    table = table[~np.isnan(table[:, 0])]
+    table = table[table[:, 0] != _EMPTY]
     table = table[np.argsort(table[:, 5], kind='stable')]
-    E = table[:, 0]
+    E, logP, disc, neg = _unpack_floats(table)
     best = np.flatnonzero(E - E.min() <= min_dEng)
-    top = best[np.argmax(table[best, 2])]                   # most probable among the minimisers
+    top = best[np.argmax(logP[best])]                       # most probable among the minimisers
     return {
         'energy': float(E.min()),
         'degeneracy': int(table[best, 1].max()),
         'rotation': int(table[top, 5]),
-        'probability': float(table[top, 2]),
+        'probability': float(logP[top]),
         'state': table[top, _HEAD:].astype(np.int64),
-        'records': [dict(rotation=int(r[5]), energy=float(r[0]), degeneracy=int(r[1]), probability=float(r[2]),
-                         discarded_probability=float(r[3]), negative_probability=float(r[4])) for r in table],
+        'records': [dict(rotation=int(r[5]), energy=float(E[i]), degeneracy=int(r[1]), probability=float(logP[i]),
+                         discarded_probability=float(disc[i]), negative_probability=float(neg[i]))
+                    for i, r in enumerate(table)],
     }

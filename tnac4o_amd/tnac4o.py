@@ -800,23 +800,21 @@ class tnac4o:
         np.save(file_name, d)
 
     def show_properties(self):
-        """tnac4o.py:233-241."""
-        print("L:     ", self.L)
-        print("Ny:    ", self.Ny)
-        print("Nx:    ", self.Nx)
-        print("Beta:  ", self.beta)
+        """Print the lattice size and inverse temperature (what tnac4o.py:233-241 reports)."""
+        for label, value in (('L', self.L), ('Ny', self.Ny), ('Nx', self.Nx), ('Beta', self.beta)):
+            print('%-7s %s' % (label + ':', value))
 
     def show_solution(self, state=False):
-        """tnac4o.py:244-259."""
-        if len(self.energy) > 0:
-            print("Energy            : %4.6f" % self.energy[0])
-            print("Degeneracy        : %2d" % self.degeneracy)
-            print("log2(Probability) : %0.2e" % self.probability[0])
-            print("Discarder log2(P) : %0.2e" % self.discarded_probability)
-            print("Min P (err)       : %0.2e" % self.negative_probability)
-            print("# of states       : %1d" % len(self.energy))
-            print("Rotation/direction: %1d" % self.rotation)
-            if state:
-                print(self.states[0])
-        else:
+        """Print a summary of the stored result; with state=True also the best configuration (tnac4o.py:244-259)."""
+        if len(self.energy) == 0:
             print('No solution to show.')
+            return
+        rows = [('Energy', '%4.6f' % self.energy[0]), ('Degeneracy', '%2d' % self.degeneracy),
+                ('log2(Probability)', '%0.2e' % self.probability[0]), ('Discarded log2(P)', '%0.2e' % self.discarded_probability),
+                ('Min P (err)', '%0.2e' % self.negative_probability), ('# of states', '%1d' % len(self.energy)),
+                ('Rotation/direction', '%1d' % self.rotation)]
+        width = max(len(k) for k, _ in rows)
+        for k, v in rows:
+            print('%s : %s' % (k.ljust(width), v))
+        if state:
+            print(self.states[0])
