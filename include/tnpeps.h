@@ -106,6 +106,26 @@ int tn_calc_pn(const double* T1, const double* RR, const double* F, const int32_
 /* ---- K9: per-item power-of-two normalisation of a batch of environments (tnac4o.py:533, 1781):
  * each of the `batch` contiguous blocks of `len` doubles is divided by its own nfactor. */
 int tn_nfactor_batched(double* x, int64_t batch, int64_t len, void* stream);
+/* ---- K9: right environments of every distinct boundary suffix of the beam for one site.  Replaces the body of the key loop
+ * of tnac4o._setup_RR (tnac4o.py:1777-1783): gather of the parent environment, both contractions and the nfactor rescale,
+ * one launch for all keys, no (Dl p) x br intermediate.
+ *   A: (Dl, p, Dr) top boundary-MPS site;  RRprev: (nprev, Dr, br) environments of the previous level;
+ *   W: (bl, p, br, pu) row-MPO site (legs left, down, right, up);  parent[k] (row of RRprev), uidx[k] (up index) int32;
+ *   out[k, x, l] = sum_{d, x', r} A[x, d, x'] RRprev[parent[k], x', r] W[l, d, r, uidx[k]]  / nfactor(out[k]).   (nk, Dl, bl)
+ * Limits (argument error otherwise): Dl * bl <= 2048, (Dr*br + bl*p*br + Dr*bl) * 8 <= 150 KiB. */
+int tn_env_rr_batched(const double* A, const double* RRprev, const double* W, const int32_t* parent, const int32_t* uidx,
+                      int64_t nk, int64_t Dl, int64_t p, int64_t Dr, int64_t bl, int64_t br, int64_t pu, double* out,
+                      void* stream);
+/* ---- K9: left environments of the new distinct prefixes (tnac4o.py:528-535).  T1 = RL . A (npref, p, Dr) is the product K8
+ * already uses, so RL'[k] = RL[par] . A[:, d, :] is row (par[k], didx[k]) of it:  out[k, :] = T1[par[k], didx[k], :] / nfactor. */
+int tn_env_rl_batched(const double* T1, const int32_t* par, const int32_t* didx, int64_t nk, int64_t p, int64_t Dr,
+                      double* out, void* stream);
+/* ---- bond balancing of the preconditioner.  Replaces scipy.linalg.matrix_balance(env, permute=False, separate=True) and the
+ * clamp that follows it (tnac4o.py:1845-1847): LAPACK dgebal, job 'S' (radix 2, 2-norms), on the n x n matrix A (n <= 64,
+ * element strides rs/cs).  scale_out[i] (device, n doubles) = min(max(scale[i], 1/max_scale), max_scale); max_scale <= 0
+ * disables the clamp.  iters_out (device int, may be NULL) = passes of the outer loop. */
+int tn_balance(const double* A, int64_t rs, int64_t cs, int64_t n, double max_scale, double* scale_out, int* iters_out,
+               void* stream);
 
 /* ---- measurement: bracket every launch of the selected kernel families with HIP events on the launch stream.
  * family ids: 0-3 gemm_kernel<128,128> / <128,32> / <32,128> / <64,64> (all operand layouts), 4 splitk_reduce,

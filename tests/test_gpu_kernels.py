@@ -300,3 +300,105 @@ def test_linalg_fuzz_against_numpy():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_linalg.py'), '7', '60'], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ K9 environments, balancing
+ENV_SHAPES = [(64, 16, 64, 16, 16, 16, 40), (128, 8, 128, 8, 8, 8, 33), (5, 3, 7, 2, 4, 3, 6), (1, 16, 16, 1, 16, 16, 3),
+              (64, 16, 1, 16, 1, 16, 2)]
+
+
+@pytest.mark.parametrize('Dl,p,Dr,bl,br,pu,nk', ENV_SHAPES)
+def test_env_rr_batched(ops, Dl, p, Dr, bl, br, pu, nk):
+    """tn_env_rr_batched against the reference's two tensordots + nfactor (tnac4o.py:1779-1781), key by key, incl. an
+    all-zero parent environment and strongly graded data (the nfactor must be the exact power of two)."""
+    rng = np.random.default_rng(Dl * 3 + p + nk)
+    nprev = max(2, nk // 3)
+    A = rng.standard_normal((Dl, p, Dr))
+    RRp = rng.standard_normal((nprev, Dr, br)) * np.exp(-40 * rng.uniform(0, 1, (nprev, 1, 1)))
+    RRp[1] = 0.0
+    W = np.exp(-20 * rng.uniform(0, 1, (bl, p, br, pu)))
+    parent = rng.integers(0, nprev, nk).astype(np.int32)
+    parent[0] = 1
+    uidx = rng.integers(0, pu, nk).astype(np.int32)
+    out = host(ops.env_rr(dev(A), dev(RRp), dev(W), torch.as_tensor(parent).cuda(), torch.as_tensor(uidx).cuda()))
+    assert out.shape == (nk, Dl, bl)
+    for k in range(nk):
+        T = np.tensordot(A, RRp[parent[k]], axes=(2, 0))
+        ref = np.tensordot(T, W[:, :, :, uidx[k]], axes=([1, 2], [1, 2]))
+        nf = mr.pow2_floor_max(ref)
+        ref = ref * (1 / nf)
+        assert np.abs(out[k] - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
+        m = np.abs(out[k]).max()
+        assert m == 0.0 or 1.0 <= m < 2.0                     # normalised by a power of two
+
+
+def test_env_rl_batched(ops):
+    rng = np.random.default_rng(11)
+    npref, p, Dr, nk = 9, 16, 64, 50
+    T1 = rng.standard_normal((npref, p, Dr)) * np.exp(-60 * rng.uniform(0, 1, (npref, p, 1)))
+    T1[2, 3] = 0.0
+    par = rng.integers(0, npref, nk).astype(np.int32)
+    d = rng.integers(0, p, nk).astype(np.int32)
+    par[0], d[0] = 2, 3
+    out = host(ops.env_rl(dev(T1), torch.as_tensor(par).cuda(), torch.as_tensor(d).cuda()))
+    for k in range(nk):
+        row = T1[par[k], d[k]]
+        assert np.array_equal(out[k], row * (1 / mr.pow2_floor_max(row)))      # power-of-two scaling: bit-exact
+
+
+@pytest.mark.parametrize('kind', ['normal', 'wide', 'graded', 'sparse'])
+def test_balance_bit_exact_vs_scipy(ops, kind):
+    """tn_balance = LAPACK dgebal (job 'S') as called by the reference (scipy.linalg.matrix_balance(permute=False,
+    separate=True), tnac4o.py:1845) followed by its clamp (:1847): the scale factors are powers of two, so the agreement
+    must be bit-exact."""
+    import scipy.linalg
+    from oracle.gebal_ref import gebal_scale
+    rng = np.random.default_rng({'normal': 1, 'wide': 2, 'graded': 3, 'sparse': 4}[kind])
+    for t in range(40):
+        n = int(rng.integers(1, 33)) if t else 16
+        if kind == 'normal':
+            A = rng.standard_normal((n, n))
+        elif kind == 'wide':
+            A = np.exp(rng.uniform(-40, 40, (n, n)))
+        elif kind == 'graded':
+            dd = np.exp(rng.uniform(-30, 30, n))
+            A = np.abs(rng.standard_normal((n, n))) * dd[:, None] / dd[None, :]
+        else:
+            A = np.exp(rng.uniform(-20, 0, (n, n)))
+            A[rng.random((n, n)) < 0.3] = 0
+        _, sc = scipy.linalg.matrix_balance(A, permute=False, separate=True)
+        assert np.array_equal(sc[0], gebal_scale(A)[0])
+        got = host(ops.balance(dev(A)))
+        assert np.array_equal(got, sc[0]), (kind, t, n)
+        ms = 32.0
+        got = host(ops.balance(dev(A).t().contiguous().t(), ms))               # strided view + clamp
+        assert np.array_equal(got, np.minimum(np.maximum(sc[0], 1 / ms), ms))
+
+
+def test_balance_on_preconditioner_environments():
+    """The bond environments the 'balancing' preconditioner actually meets (droplet L=128 #1, the G7 pre=1 case): every
+    tn_balance result equals scipy's on the same matrix."""
+    import scipy.linalg
+    import tnac4o_amd
+    from tnac4o_amd import ops as o
+    seen = []
+    orig = o.balance
+
+    def spy(env, max_scale=0.0):
+        sc = orig(env, max_scale)
+        seen.append((env.detach().cpu().numpy().copy(), max_scale, sc.detach().cpu().numpy().copy()))
+        return sc
+    o.balance = spy
+    try:
+        s = tnac4o_amd.tnac4o(mode='Ising', Nx=4, Ny=4, Nc=8, J=gi.droplet_J(128, 1), beta=3.0)
+        s.precondition(mode='balancing')
+    finally:
+        o.balance = orig
+    assert len(seen) == 2 * 3 * 4 * 2                         # 2 conditioning passes x 3 bonds rows x 4 columns x 2 directions
+    for env, ms, sc in seen:
+        _, ref = scipy.linalg.matrix_balance(env, permute=False, separate=True)
+        assert np.array_equal(sc, np.minimum(np.maximum(ref[0], 1 / ms), ms))
+    g = load('g4_peps.npz')
+    np.testing.assert_allclose(s.Xu, g['L128_pre1_Xu'], rtol=1e-12)
+    np.testing.assert_allclose(s.Xd, g['L128_pre1_Xd'], rtol=1e-12)
+    np.testing.assert_allclose(s.overlaps_ud, g['L128_pre1_overlaps_ud'], rtol=1e-9)

@@ -240,3 +240,27 @@ def test_g8_gibbs_sampling(rot, chi, M, seed):
     assert s.negative_probability == pytest.approx(float(g[tag + '_neg'][0]), abs=1e-12)
     # the reference's own consistency check (examples/test_examples.py:36-56): energies recomputed from the bit strings
     assert np.abs(sr.energy_Jij(gi.droplet_J(128, 1), s.binary_states()) - E).max() < 1e-6
+
+
+# ---------------------------------------------------------------- dgebal restatement (preconditioner, tnac4o.py:1845)
+def test_gebal_restatement_matches_scipy():
+    """oracle/gebal_ref.py (LAPACK dgebal, job 'S') against scipy.linalg.matrix_balance(permute=False, separate=True), the
+    call the reference makes: identical power-of-two scale factors on random, wide-range, graded and sparse matrices."""
+    import scipy.linalg
+    from oracle.gebal_ref import gebal_scale
+    rng = np.random.default_rng(1)
+    for t in range(400):
+        n = int(rng.integers(1, 33))
+        kind = t % 4
+        if kind == 0:
+            A = rng.standard_normal((n, n))
+        elif kind == 1:
+            A = np.exp(rng.uniform(-40, 40, (n, n)))
+        elif kind == 2:
+            d = np.exp(rng.uniform(-30, 30, n))
+            A = np.abs(rng.standard_normal((n, n))) * d[:, None] / d[None, :]
+        else:
+            A = np.exp(rng.uniform(-20, 0, (n, n)))
+            A[rng.random((n, n)) < 0.3] = 0
+        _, sc = scipy.linalg.matrix_balance(A, permute=False, separate=True)
+        assert np.array_equal(sc[0], gebal_scale(A)[0])

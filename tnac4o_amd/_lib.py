@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libtnpeps.so')
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['api.hip', 'gemm_f64.hip', 'small.hip', 'qr.hip', 'svd.hip', 'absorb.hip', 'misc.hip', 'beam.hip', 'prof.hip', 'tsqr.hip', 'peps.hip']
+SOURCES = ['api.hip', 'gemm_f64.hip', 'small.hip', 'qr.hip', 'svd.hip', 'absorb.hip', 'misc.hip', 'beam.hip', 'prof.hip', 'tsqr.hip', 'peps.hip', 'env.hip']
 
 _i64, _f64, _int, _ptr = C.c_int64, C.c_double, C.c_int, C.c_void_p
 
@@ -34,6 +34,9 @@ SIGNATURES = {
     'tn_scale_phys': (_int, [_ptr, _i64, _i64, _i64, _ptr, _int, _ptr]),
     'tn_calc_pn': (_int, [_ptr] * 9 + [_i64] * 7 + [_ptr, _ptr, _ptr]),
     'tn_nfactor_batched': (_int, [_ptr, _i64, _i64, _ptr]),
+    'tn_env_rr_batched': (_int, [_ptr] * 5 + [_i64] * 7 + [_ptr, _ptr]),
+    'tn_env_rl_batched': (_int, [_ptr] * 3 + [_i64] * 3 + [_ptr, _ptr]),
+    'tn_balance': (_int, [_ptr, _i64, _i64, _i64, _f64, _ptr, _ptr, _ptr]),
     'tn_peps_factor': (_int, [_ptr] * 9 + [_i64] * 3 + [_ptr, _ptr]),
     'tn_mpo_from_factor': (_int, [_ptr] * 3 + [_i64] * 5 + [_ptr, _ptr]),
     'tn_profile_enable': (None, [C.c_uint]),

@@ -36,6 +36,10 @@ int nfactor_batched(hipStream_t, double*, int64_t, int64_t);
 int peps_factor(hipStream_t, const double*, const double*, const double*, const double*, const double*, const double*, const double*,
                 const int32_t*, const int32_t*, int64_t, int64_t, int64_t, double*);
 int mpo_from_factor(hipStream_t, const double*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t, double*);
+int env_rr_batched(hipStream_t, const double*, const double*, const double*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t,
+                   int64_t, int64_t, int64_t, int64_t, double*);
+int env_rl_batched(hipStream_t, const double*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, double*);
+int balance(hipStream_t, const double*, int64_t, int64_t, int64_t, double, double*, int*);
 
 }  // namespace tn
 
@@ -179,6 +183,25 @@ int tn_mpo_from_factor(const double* F, const int32_t* dmap, const int32_t* rmap
 int tn_nfactor_batched(double* x, int64_t batch, int64_t len, void* stream) {
     TN_CHECK_ARG(x, "null operand");
     return nfactor_batched(ST, x, batch, len);
+}
+
+int tn_env_rr_batched(const double* A, const double* RRprev, const double* W, const int32_t* parent, const int32_t* uidx,
+                      int64_t nk, int64_t Dl, int64_t p, int64_t Dr, int64_t bl, int64_t br, int64_t pu, double* out,
+                      void* stream) {
+    TN_CHECK_ARG(nk >= 0, "negative key count");
+    TN_CHECK_ARG(nk == 0 || (A && RRprev && W && parent && uidx && out), "null operand");
+    return env_rr_batched(ST, A, RRprev, W, parent, uidx, nk, Dl, p, Dr, bl, br, pu, out);
+}
+int tn_env_rl_batched(const double* T1, const int32_t* par, const int32_t* didx, int64_t nk, int64_t p, int64_t Dr,
+                      double* out, void* stream) {
+    TN_CHECK_ARG(nk >= 0, "negative key count");
+    TN_CHECK_ARG(nk == 0 || (T1 && par && didx && out), "null operand");
+    return env_rl_batched(ST, T1, par, didx, nk, p, Dr, out);
+}
+int tn_balance(const double* A, int64_t rs, int64_t cs, int64_t n, double max_scale, double* scale_out, int* iters_out,
+               void* stream) {
+    TN_CHECK_ARG(A && scale_out, "null operand");
+    return balance(ST, A, rs, cs, n, max_scale, scale_out, iters_out);
 }
 
 }  // extern "C"

@@ -284,11 +284,12 @@ class MPS:
         c = RL.shape[0]
         return ops.mm(T.view(c * s, a2), RR).view(c, s, RR.shape[1])
 
-    def update_RL_mix(self, phi, n):
-        """mps.py:436-444."""
+    def update_RL_mix(self, phi, n, keep_on_device=False):
+        """mps.py:436-444.  At the last site the overlap goes to R[-1]: as a host float (one synchronisation), or with
+        keep_on_device as the 1 x 1 device tensor (the preconditioner walks over the last site without needing the number)."""
         new = self._mps_RL(self.R[n], phi.A[n], self.A[n])
         if n == self.L - 1:
-            self.R[self.L + 1] = float(new.reshape(-1)[0].item())
+            self.R[self.L + 1] = new if keep_on_device else float(new.reshape(-1)[0].item())
         else:
             self.R[n + 1] = new
 
@@ -320,10 +321,14 @@ class MPS:
         # env[s, s'] = sum_{c,c'} T2[c,s,c'] Ac[c,s',c']
         return ops.mm(T2.permute(1, 0, 2).reshape(s, c * c2), Ac.permute(1, 0, 2).reshape(Ac.shape[1], c * c2).t())
 
+    def expectation_mix_dev(self, phi, n):
+        """<self| ... |phi> at site n given both environments, as a (1, 1) device tensor (no synchronisation)."""
+        T2 = self._mps_RAR(self.R[n], phi.A[n], self.R[n + 1])
+        return ops.mm(T2.reshape(1, -1), self.A[n].reshape(-1, 1))
+
     def expectation_mix(self, phi, n):
         """<self| ... |phi> at site n given both environments (mps.py:587-591, 694-698).  Syncs."""
-        T2 = self._mps_RAR(self.R[n], phi.A[n], self.R[n + 1])
-        return float(ops.mm(T2.reshape(1, -1), self.A[n].reshape(-1, 1)).item())
+        return float(self.expectation_mix_dev(phi, n).item())
 
     # -- variational compression --------------------------------------------------------------------------
     def optimise_site(self, phi, n):

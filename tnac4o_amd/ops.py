@@ -210,6 +210,43 @@ def calc_pn(T1, RR, F, dmap, rmap, pref, suf, lidx, uidx):
     return P, mP
 
 
+def env_rr(A, RRprev, W, parent, uidx):
+    """Right environments of all distinct suffixes of one site (tn_env_rr_batched).  A (Dl,p,Dr), RRprev (nprev,Dr,br),
+    W (bl,p,br,pu), parent / uidx int32 device vectors (nk).  Returns (nk, Dl, bl), each block nfactor-normalised."""
+    Dl, p, Dr = A.shape
+    bl, p2, br, pu = W.shape
+    assert p2 == p and RRprev.shape[1:] == (Dr, br), (A.shape, W.shape, RRprev.shape)
+    for t in (A, RRprev, W, parent, uidx):
+        assert t.is_contiguous() and t.is_cuda
+    nk = parent.numel()
+    out = torch.empty((nk, Dl, bl), dtype=torch.float64, device=A.device)
+    check(lib().tn_env_rr_batched(A.data_ptr(), RRprev.data_ptr(), W.data_ptr(), parent.data_ptr(), uidx.data_ptr(), nk, Dl, p, Dr,
+                                  bl, br, pu, out.data_ptr(), _stream()))
+    return out
+
+
+def env_rl(T1, par, didx):
+    """Left environments of the new distinct prefixes: rows (par[k], didx[k]) of T1 (npref, p, Dr), nfactor-normalised."""
+    _, p, Dr = T1.shape
+    for t in (T1, par, didx):
+        assert t.is_contiguous() and t.is_cuda
+    nk = par.numel()
+    out = torch.empty((nk, Dr), dtype=torch.float64, device=T1.device)
+    check(lib().tn_env_rl_batched(T1.data_ptr(), par.data_ptr(), didx.data_ptr(), nk, p, Dr, out.data_ptr(), _stream()))
+    return out
+
+
+def balance(env, max_scale=0.0):
+    """dgebal (job 'S') scaling of a small square device matrix, clamped to [1/max_scale, max_scale] (tn_balance).
+    Returns the device vector of scale factors (powers of two)."""
+    _need_gpu(env)
+    n = env.shape[0]
+    assert env.shape == (n, n)
+    out = torch.empty(n, dtype=torch.float64, device=env.device)
+    check(lib().tn_balance(env.data_ptr(), env.stride(0), env.stride(1), n, float(max_scale), out.data_ptr(), None, _stream()))
+    return out
+
+
 def peps_factor(Es, E1, E4, Xu, Xl, Xr, Xd, dmap, rmap):
     """F[s,l,u] on the device from the (beta-scaled, min-shifted) energy tables and gauge diagonals (tn_peps_factor)."""
     q, nl = E1.shape

@@ -16,7 +16,6 @@ import itertools
 import logging
 
 import numpy as np
-import scipy.linalg
 import torch
 
 from . import mps, ops
@@ -428,23 +427,36 @@ class tnac4o:
                                       max_sweeps=max_sweeps, max_scale=max_scale)
         self.beta = main_beta
 
-    def _balance_site(self, B, T, ny, nx, max_scale, overlaps):
-        """One balancing step for the vertical bond above cell (ny,nx) (tnac4o.py:1844-1867).  The p x p bond
-        environment comes from the GPU; its dgebal scaling (<= 16 x 16) is computed on the host like the reference."""
-        env = B.bond_env_mix(T, nx).cpu().numpy()
-        _, sc = scipy.linalg.matrix_balance(env, permute=False, separate=True)
-        sc = np.minimum(np.maximum(sc[0], 1 / max_scale), max_scale)
-        nrm = lambda t: float(torch.linalg.vector_norm(t).item())                       # noqa: E731
-        o1 = B.expectation_mix(T, nx) * (1 / (nrm(B.A[nx]) * nrm(T.A[nx])))
-        B.apply_diagonalO(sc, nx)
-        T.apply_diagonalO(1 / sc, nx)
-        o2 = B.expectation_mix(T, nx) * (1 / (nrm(B.A[nx]) * nrm(T.A[nx])))
-        if o1 < overlaps[0, ny - 1]:
-            overlaps[0, ny - 1] = o1
-            overlaps[1, ny - 1] = max(o1, o2)
-        k = self.ld[ny - 1, nx]
-        self.Xd[ny - 1, nx, :k] *= sc
-        self.Xu[ny, nx, :k] *= 1 / sc
+    def _balance_site(self, B, T, ny, nx, max_scale, pending):
+        """One balancing step for the vertical bond above cell (ny,nx) (tnac4o.py:1844-1867), entirely on the GPU: the
+        p x p bond environment, its dgebal scaling clamped to [1/max_scale, max_scale] (tn_balance), the two overlaps.
+        Nothing is read back here: the scale vector and the overlaps are queued in `pending` and folded into the host-side
+        gauge tables Xd / Xu and the diagnostics once per conditioning pass (_flush_balance)."""
+        sc = ops.balance(B.bond_env_mix(T, nx), max_scale)
+        nrm = torch.linalg.vector_norm
+        o1 = B.expectation_mix_dev(T, nx) * torch.reciprocal(nrm(B.A[nx]) * nrm(T.A[nx]))
+        ops.scale_phys_(B.A[nx], sc)
+        ops.scale_phys_(T.A[nx], sc, inv=True)              # powers of two: dividing is exactly multiplying by 1/sc
+        o2 = B.expectation_mix_dev(T, nx) * torch.reciprocal(nrm(B.A[nx]) * nrm(T.A[nx]))
+        pending.append((ny, nx, sc, o1.reshape(1), o2.reshape(1)))
+
+    def _flush_balance(self, pending, overlaps):
+        """One device-to-host copy for a whole conditioning pass, then the reference's bookkeeping in its order
+        (tnac4o.py:1857-1865)."""
+        if not pending:
+            return
+        flat = torch.cat([torch.cat([sc, o1, o2]) for (_, _, sc, o1, o2) in pending]).cpu().numpy()
+        off = 0
+        for (ny, nx, sc, _, _) in pending:
+            k = sc.numel()
+            scale, o1, o2 = flat[off:off + k], float(flat[off + k]), float(flat[off + k + 1])
+            off += k + 2
+            if o1 < overlaps[0, ny - 1]:
+                overlaps[0, ny - 1] = o1
+                overlaps[1, ny - 1] = max(o1, o2)
+            kk = self.ld[ny - 1, nx]
+            self.Xd[ny - 1, nx, :kk] *= scale
+            self.Xu[ny, nx, :kk] *= 1 / scale
 
     def _update_conditioning(self, graduate_truncation=False, Dmax=8, tolS=1e-16, tolV=1e-10, max_sweeps=4,
                              max_scale=1024):
@@ -455,16 +467,17 @@ class tnac4o:
         self._setup_rhoB(**kw)
         overlaps = np.ones((2, self.Ny - 1))
         Nx = self.Nx
+        pending = []
 
-        def renorm(B, k):
-            B.R[k] = B.R[k] * (1.0 / float(torch.linalg.vector_norm(B.R[k]).item()))
+        def renorm(B, k):                      # R *= 1 / ||R||  with the norm kept on the device
+            B.R[k] = B.R[k] * torch.reciprocal(torch.linalg.vector_norm(B.R[k]))
         for ny in range(1, self.Ny):
             B, T = self.rhoB[ny], self.rhoT[ny]
             for nx in range(Nx):
-                B.update_RL_mix(T, nx)
+                B.update_RL_mix(T, nx, keep_on_device=True)
                 renorm(B, nx + 1)            # for nx = Nx-1 this touches the unused 1x1 slot R[Nx], as in the reference
             for nx in range(Nx - 1, -1, -1):
-                self._balance_site(B, T, ny, nx, max_scale, overlaps)
+                self._balance_site(B, T, ny, nx, max_scale, pending)
                 if nx > 0:
                     B.orth_right(nx)
                     B.attach_AC()
@@ -473,7 +486,7 @@ class tnac4o:
                     B.update_RR_mix(T, nx)
                     renorm(B, nx)
             for nx in range(Nx):
-                self._balance_site(B, T, ny, nx, max_scale, overlaps)
+                self._balance_site(B, T, ny, nx, max_scale, pending)
                 if nx < Nx - 1:
                     B.orth_left(nx)
                     B.attach_CA()
@@ -481,6 +494,7 @@ class tnac4o:
                     T.attach_CA()
                     B.update_RL_mix(T, nx)
                     renorm(B, nx + 1)
+        self._flush_balance(pending, overlaps)
         self.overlaps_ud = np.vstack([self.overlaps_ud, overlaps])
         self.rhoB = []
 
@@ -503,12 +517,15 @@ class tnac4o:
             bl, p, br, pu = W.shape
             A = top.A[nx]
             Dl, _, Dr = A.shape
-            RRg = prr[torch.as_tensor(parent, device=dev)]                   # (nk, Dr, br)
-            T = ops.bmm(A.view(1, Dl * p, Dr), RRg)                          # (nk, Dl p, br)
-            Wt = W.permute(3, 1, 2, 0).reshape(pu, p * br, bl).contiguous()
-            Wsel = Wt[torch.as_tensor(keys[:, 0].astype(np.int64), device=dev)]
-            RR = ops.bmm(T.view(-1, Dl, p * br), Wsel)                       # (nk, Dl, bl)
-            ops.nfactor_batched_(RR)
+            if Dl * bl <= 2048:              # K9: gather + both contractions + nfactor in one launch
+                RR = ops.env_rr(A.contiguous(), prr, W, _dev_i32(parent), _dev_i32(keys[:, 0]))
+            else:                            # very wide bonds: the same contraction as two batched GEMMs
+                RRg = prr[torch.as_tensor(parent, device=dev)]                   # (nk, Dr, br)
+                T = ops.bmm(A.view(1, Dl * p, Dr), RRg)                          # (nk, Dl p, br)
+                Wt = W.permute(3, 1, 2, 0).reshape(pu, p * br, bl).contiguous()
+                Wsel = Wt[torch.as_tensor(keys[:, 0].astype(np.int64), device=dev)]
+                RR = ops.bmm(T.view(-1, Dl, p * br), Wsel)                       # (nk, Dl, bl)
+                ops.nfactor_batched_(RR)
             levels.append((keys, RR))
         return levels
 
@@ -688,8 +705,7 @@ class tnac4o:
                 nkeys, _ = _unique_rows(vind[:, :nx + 1])
                 _, par = _unique_rows(np.vstack([pkeys, nkeys[:, :nx]]))
                 par = par[len(pkeys):]
-                RL = T1[torch.as_tensor(par, device=dev), torch.as_tensor(nkeys[:, nx].astype(np.int64), device=dev)].contiguous()
-                ops.nfactor_batched_(RL)
+                RL = ops.env_rl(T1, _dev_i32(par), _dev_i32(nkeys[:, nx]))
                 pkeys = nkeys
                 globalmin = min(globalmin, minprob)
 
@@ -752,8 +768,7 @@ class tnac4o:
                 nkeys, _ = _unique_rows(vind[:, :nx + 1])                    # left environments (:628-636)
                 _, par = _unique_rows(np.vstack([pkeys, nkeys[:, :nx]]))
                 par = par[len(pkeys):]
-                RL = T1[torch.as_tensor(par, device=dev), torch.as_tensor(nkeys[:, nx].astype(np.int64), device=dev)].contiguous()
-                ops.nfactor_batched_(RL)
+                RL = ops.env_rl(T1, _dev_i32(par), _dev_i32(nkeys[:, nx]))
                 pkeys = nkeys
                 globalmin = min(globalmin, minprob)
             vind[:, 1:] = vind[:, :-1]
