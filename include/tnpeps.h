@@ -52,9 +52,14 @@ int tn_absorb(const double* A, const double* W, double* out, int64_t Dl, int64_t
  * back; once it is <= rank_tol x the largest column norm of A the factorisation stops and *keff_host (HOST) receives
  * the number of columns of Q / rows of R produced (A = Q[:, :keff] R[:keff, :] to rank_tol * max column norm).  With
  * rank_tol = 2^-56 this drops exactly the rows the Jacobi SVD (tn_svd_trunc) would deflate.  Synchronises the stream
- * at each check.  *keff_host = min(m, n) otherwise. */
+ * at each check.  *keff_host = min(m, n) otherwise.
+ * aux_stream (a second hipStream_t owned by the caller, or NULL): look-ahead.  The device-filling part of every trailing update
+ * is enqueued on aux_stream while `stream` goes on factoring the next panel (a chain of latency-bound single-workgroup kernels);
+ * the two are ordered by events inside the call, and on return all work the result depends on is ordered before anything
+ * enqueued on `stream` afterwards.  Results are bit-identical with and without it (same kernels on the same data). */
 int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs, int64_t qcs, double* R,
-          int64_t rrs, int64_t rcs, int nb, double rank_tol, int64_t* keff_host, void* ws, int64_t ws_bytes, void* stream);
+          int64_t rrs, int64_t rcs, int nb, double rank_tol, int64_t* keff_host, void* ws, int64_t ws_bytes, void* stream,
+          void* aux_stream);
 int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb);
 
 /* ---- K4: truncated SVD of a centre matrix.  Replaces mps.svd (mps.py:24-40, sign gauge included) +

@@ -402,3 +402,32 @@ def test_balance_on_preconditioner_environments():
     np.testing.assert_allclose(s.Xu, g['L128_pre1_Xu'], rtol=1e-12)
     np.testing.assert_allclose(s.Xd, g['L128_pre1_Xd'], rtol=1e-12)
     np.testing.assert_allclose(s.overlaps_ud, g['L128_pre1_overlaps_ud'], rtol=1e-9)
+
+
+@pytest.mark.parametrize('m,n,tol', [(16384, 1024, 0.0), (4096, 1024, 0.0), (4096, 1024, 1e-12), (16384, 512, 0.0)])
+def test_qr_lookahead_bit_identical(ops, m, n, tol):
+    """tn_qr with its look-ahead stream issues the same kernels on the same data, split over two ordered streams: Q, R and
+    the revealed rank must be bit-identical to the single-stream run (graded low-rank input, so the early exit triggers)."""
+    g = torch.Generator(device='cuda').manual_seed(m + n)
+    r = 300
+    T = (torch.randn((m, r), dtype=torch.float64, device='cuda', generator=g)
+         * torch.exp(-30.0 * torch.rand((1, r), dtype=torch.float64, device='cuda', generator=g))) \
+        @ torch.randn((r, n), dtype=torch.float64, device='cuda', generator=g)
+    k = min(m, n)
+    res = []
+    saved = ops.LOOKAHEAD
+    try:
+        for la in (False, True, True):
+            ops.LOOKAHEAD = la
+            Q = torch.zeros((m, k), dtype=torch.float64, device='cuda')
+            R = torch.zeros((k, n), dtype=torch.float64, device='cuda')
+            _, _, keff = ops.qr_into(T.clone(), Q, R, overwrite=True, rank_tol=tol)
+            torch.cuda.synchronize()
+            res.append((Q, R, keff))
+    finally:
+        ops.LOOKAHEAD = saved
+    for Q, R, keff in res[1:]:
+        assert keff == res[0][2]
+        assert torch.equal(Q[:, :keff], res[0][0][:, :keff]) and torch.equal(R[:keff], res[0][1][:keff])
+    if tol > 0:
+        assert res[0][2] < k

@@ -21,9 +21,9 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().tn_version() >= 1
+    assert _lib.lib().tn_version() == _lib.ABI_VERSION
     # argument errors are reported without touching a GPU
-    rc = _lib.lib().tn_qr(None, 1, 1, 4, 4, None, 1, 1, None, 1, 1, 32, 0.0, None, None, 0, None)
+    rc = _lib.lib().tn_qr(None, 1, 1, 4, 4, None, 1, 1, None, 1, 1, 32, 0.0, None, None, 0, None, None)
     assert rc < 0
     buf = ctypes.create_string_buffer(256)
     _lib.lib().tn_last_error(buf, 256)

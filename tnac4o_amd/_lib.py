@@ -21,7 +21,7 @@ SIGNATURES = {
     'tn_gemm_ws_bytes': (_i64, [_i64, _i64, _i64, _i64]),
     'tn_absorb': (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _ptr]),
     'tn_qr': (_int, [_ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _i64, _i64, _int, _f64, C.POINTER(_i64), _ptr, _i64,
-              _ptr]),
+              _ptr, _ptr]),
     'tn_qr_ws_bytes': (_i64, [_i64, _i64, _int]),
     'tn_svd_trunc': (_int, [_ptr, _i64, _i64, _i64, _i64, _i64, _f64, _ptr, _i64, _i64, _ptr, _ptr, _i64, _i64,
                             C.POINTER(_i64), C.POINTER(_f64), C.POINTER(_int), C.POINTER(_int), _ptr, _i64, _ptr]),

@@ -19,7 +19,7 @@ const char* get_error() { return g_err; }
 // implemented in the other translation units
 int absorb(hipStream_t, const double*, const double*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
 int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
-              void*, int64_t, double, int64_t*);
+              void*, int64_t, double, int64_t*, hipStream_t);
 int64_t qr_ws_bytes(int64_t, int64_t, int);
 int svd_trunc(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double, double*, int64_t, int64_t, double*,
               double*, int64_t, int64_t, int64_t*, double*, int*, int*, void*, int64_t);
@@ -109,13 +109,13 @@ int tn_absorb(const double* A, const double* W, double* out, int64_t Dl, int64_t
 }
 
 int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs, int64_t qcs, double* R, int64_t rrs,
-          int64_t rcs, int nb, double rank_tol, int64_t* keff_host, void* ws, int64_t ws_bytes, void* stream) {
+          int64_t rcs, int nb, double rank_tol, int64_t* keff_host, void* ws, int64_t ws_bytes, void* stream, void* aux_stream) {
     TN_CHECK_ARG(A && Q && R && ws, "null operand");
     TN_CHECK_ARG(rank_tol >= 0.0 && rank_tol < 1.0, "rank_tol out of range");
     ProfPhase ph(PH_QR);
     const double dm = (double)m, dn = (double)(n < m ? n : m);
     prof_note(PROF_QR_NOMINAL, 1, 4.0 * dm * dn * dn - 4.0 / 3.0 * dn * dn * dn, 8.0 * (2.0 * dm * dn + dn * dn));
-    return qr_factor(ST, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host);
+    return qr_factor(ST, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host, (hipStream_t)aux_stream);
 }
 int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_ws_bytes(m, n, nb); }
 

@@ -554,7 +554,7 @@ static void dbg_check(hipStream_t st, const double* p, int64_t rs, int64_t cs, i
 }
 
 struct QrWs {
-    double *Y, *Wq, *W, *UT, *UTq;
+    double *Y, *Wq, *W, *W2, *UT, *UTq, *gemm_ws2;
     double *T, *X, *X2, *part, *Js, *Uinv, *Z, *Tri, *gemm_ws, *cn;
     int* dead;
     int64_t gemm_ws_bytes;
@@ -569,6 +569,7 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     double* Y = (double*)take(m * k * 8);
     double* Wq = (double*)take(m * k * 8);            // Y T of every panel (Q accumulation)
     double* Wp = (double*)take(m * nb * 8);           // Y T^T of the current panel (trailing update)
+    double* Wp2 = (double*)take(m * nb * 8);          // ... of the next one (look-ahead: the wide update of panel p still reads W_p)
     double* UT = (double*)take((int64_t)nb * nb * 8);
     double* UTq = (double*)take((int64_t)nb * nb * 8);
     double* T = (double*)take(P * nb * nb * 8);
@@ -584,10 +585,11 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     // split-K scratch for the tall TN products (b x n, K = m)
     int64_t gw = (int64_t)64 * nb * (n > k ? n : k) * 8;      // upper bound of pick_splitk's partial buffers
     double* gws = (double*)take(gw + 256);
+    double* gws2 = (double*)take(gw + 256);           // split-K scratch of the look-ahead stream
     const int64_t tsb = tsqr_ws_bytes(m, nb < 32 ? nb : 32);
     void* tsw = (void*)take(tsb);
     if (w) { w->tsqr_ws = tsw; w->tsqr_bytes = tsb; }
-    if (w) { w->Wq = Wq; w->W = Wp; w->UT = UT; w->UTq = UTq; }
+    if (w) { w->Wq = Wq; w->W = Wp; w->W2 = Wp2; w->UT = UT; w->UTq = UTq; w->gemm_ws2 = gws2; }
     if (w) { w->Y = Y; w->T = T; w->X = X; w->X2 = X2; w->part = part; w->Js = Js; w->Uinv = Uinv; w->Z = Z; w->Tri = Tri;
              w->dead = dead; w->gemm_ws = gws; w->gemm_ws_bytes = gw; w->cn = cn; }
     return off;
@@ -601,9 +603,31 @@ int64_t qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_layout(m, n, nb, n
 // (A = Q[:, :k_eff] R[:k_eff, :] to rank_tol * max column norm).  Used by the truncating canonisation passes, whose centre
 // matrix is SVD-truncated at eps * S0 right afterwards (the Jacobi SVD deflates rows below 2^-56 anyway); it needs one
 // 16-byte read-back per check.  *keff_host receives the number of columns/rows produced.
+// Look-ahead (aux != nullptr, nb = 32): the trailing update of panel p is split.  The columns of the next panel (and the
+// panel's own) are updated on the caller's stream, which then factors panel p+1 right away -- a chain of latency-bound
+// single-workgroup kernels -- while the device-filling update of everything to the right of it runs on `aux`.  Ordering:
+// aux waits for panel p's reflectors (ev.panel), the caller's stream waits for the wide update of panel p-1 before it touches
+// the columns of panel p+1 (ev.wide); W = Y T^T and the split-K scratch are double-buffered between the two streams.
+struct LookaheadEvents {
+    hipEvent_t panel[2] = {nullptr, nullptr}, wide[2] = {nullptr, nullptr};
+    bool ok = false;
+    bool init() {
+        if (ok) return true;
+        for (int i = 0; i < 2; ++i) {
+            if (hipEventCreateWithFlags(&panel[i], hipEventDisableTiming) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&wide[i], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        return ok = true;
+    }
+    ~LookaheadEvents() {
+        if (!ok) return;
+        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(panel[i]); (void)hipEventDestroy(wide[i]); }
+    }
+};
+
 int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
               int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
-              int64_t* keff_host) {
+              int64_t* keff_host, hipStream_t aux) {
     TN_CHECK_ARG(m >= 1 && n >= 1, "empty matrix");
     TN_CHECK_ARG(nb == 32 || nb == 64, "nb must be 32 or 64");
     TN_CHECK_ARG(ws_bytes >= qr_ws_bytes(m, n, nb), "workspace too small");
@@ -624,6 +648,18 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
     const int64_t wrs = rowmajor ? nb : 1, wcs = rowmajor ? 1 : m;
     Mat Am = mat(A, rs, cs), Ym = mat(w.Y, yrs, ycs), Wqm = mat(w.Wq, yrs, ycs);
     int rc;
+    thread_local LookaheadEvents ev;
+    // worth it only when there is a wide part to overlap with (at least 4 panels) and the panel is tall enough to be slow
+    const bool lookahead = aux != nullptr && aux != st && nb == 32 && P >= 4 && m >= 2048 && ev.init();
+    int wide_pending = -1;                    // parity of the ev.wide event the caller's stream has not waited for yet
+    hipError_t he;
+    auto join_wide = [&]() -> int {           // caller's stream waits for the outstanding wide update
+        if (wide_pending >= 0) {
+            if ((he = hipStreamWaitEvent(st, ev.wide[wide_pending], 0)) != hipSuccess) return hip_fail(he, "wait wide update");
+            wide_pending = -1;
+        }
+        return 0;
+    };
     for (int p = 0; p < P; ++p) {
         const int64_t j0 = (int64_t)p * nb;
         const int b = (int)((k - j0 < nb) ? k - j0 : nb);
@@ -655,7 +691,7 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         }
         // --- Householder reconstruction
         double* Tp = w.T + (int64_t)p * nb * nb;
-        Mat Wqp = sub(Wqm, j0, j0), Wp = mat(w.W, wrs, wcs);
+        Mat Wqp = sub(Wqm, j0, j0), Wp = mat((lookahead && (p & 1)) ? w.W2 : w.W, wrs, wcs);
         if (nb == 32)
             TN_PROF_LAUNCH(st, PROF_LU, hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT, w.UTq,
                                Wp.p, wrs, wcs, Wqp.p));
@@ -678,10 +714,27 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
             prof_end(st, PROF_ROWS_SMALL, 6.0 * (mp - b) * b * b, 32.0 * (mp - b) * b);
         }
         // --- trailing update  A[j0:, j0:] -= (Y T^T) (Y^T A[j0:, j0:])
-        Mat Xm = mat(w.X, ntr, 1);
-        if ((rc = gemm(st, b, ntr, mp, 1.0, tr(Yp), Ap, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
-        if ((rc = gemm(st, mp, ntr, b, -1.0, Wp, Xm, 1.0, Ap))) return rc;
+        const int64_t nnar = lookahead ? std::min<int64_t>(ntr, 2 * (int64_t)nb) : ntr;     // columns updated on this stream
+        if (lookahead && ntr > nnar) {
+            // the wide part goes to the look-ahead stream as soon as this panel's reflectors exist
+            if ((he = hipEventRecord(ev.panel[p & 1], st)) != hipSuccess) return hip_fail(he, "record panel");
+            if ((he = hipStreamWaitEvent(aux, ev.panel[p & 1], 0)) != hipSuccess) return hip_fail(he, "wait panel");
+            const int64_t nw = ntr - nnar;
+            Mat Aw = sub(Ap, 0, nnar), Xw = mat(w.X2, nw, 1);
+            if ((rc = gemm(aux, b, nw, mp, 1.0, tr(Yp), Aw, 0.0, Xw, w.gemm_ws2, w.gemm_ws_bytes))) return rc;
+            if ((rc = gemm(aux, mp, nw, b, -1.0, Wp, Xw, 1.0, Aw))) return rc;
+            // columns j0+nb .. j0+2nb (the next panel) were last written by the previous wide update
+            if ((rc = join_wide())) return rc;
+            if ((he = hipEventRecord(ev.wide[p & 1], aux)) != hipSuccess) return hip_fail(he, "record wide");
+            wide_pending = p & 1;
+        } else if (lookahead) {
+            if ((rc = join_wide())) return rc;
+        }
+        Mat Xm = mat(w.X, nnar, 1);
+        if ((rc = gemm(st, b, nnar, mp, 1.0, tr(Yp), Ap, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+        if ((rc = gemm(st, mp, nnar, b, -1.0, Wp, Xm, 1.0, Ap))) return rc;
         if (reveal && (p & 1) == 1 && p + 1 < P) {
+            if ((rc = join_wide())) return rc;                  // the norms below read the whole trailing block
             const int64_t j1 = j0 + b;
             const int64_t nt = n - j1;
             TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_kernel, dim3((unsigned)nt), dim3(256), 0, st, sub(Am, j1, j1).p, rs, cs, m - j1,
@@ -708,6 +761,7 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
             }
         }
     }
+    if ((rc = join_wide())) return rc;
     if (keff_host) *keff_host = k;
     // --- triangularise the diagonal blocks, assemble R
     if (nb == 32) TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri));

@@ -98,7 +98,8 @@ template <int NB>
 __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict__ part, int nchunk, int nvec, int mode,
                                                         int max_sweeps, double dead_thresh,
                                                         double* __restrict__ out, int* __restrict__ dead,
-                                                        int* __restrict__ nrot_out, double* __restrict__ maxoff_out) {
+                                                        int* __restrict__ nrot_out, double* __restrict__ maxoff_out,
+                                                        double relevant2) {
     constexpr int P = NB + 1;
     __shared__ double G[NB * P];
     __shared__ double J[NB * P];
@@ -167,7 +168,10 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
         __shared__ double rdg[NB];
         if (tid < NB) {
             const double gii = fabs(G[tid * P + tid]);
-            rdg[tid] = (gii > 0.0 && tid < nvec) ? fast_rcp(gii) : 0.0;
+            // vectors whose squared norm is <= relevant2 do not enter the convergence measure (SVD: they lie a factor 4 below
+            // the truncation threshold and are discarded whatever their mutual angles are); a group in which only such
+            // vectors are non-orthogonal is not rotated at all
+            rdg[tid] = (gii > relevant2 && tid < nvec) ? fast_rcp(gii) : 0.0;
         }
         __syncthreads();
         double m = 0.0;
@@ -340,16 +344,16 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
 }
 
 int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngroups, int mode, int max_sweeps,
-              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff) {
+              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2) {
     TN_CHECK_ARG(nvec >= 1 && nvec <= NBMAX, "nvec out of range");
     if (ngroups <= 0) return 0;
     prof_begin(st, PROF_EIG);
     if (nvec <= 32)
         hipLaunchKernelGGL((eig_small_kernel<32>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,
-                           dead_thresh, out, dead, nrot, maxoff);
+                           dead_thresh, out, dead, nrot, maxoff, relevant2);
     else
         hipLaunchKernelGGL((eig_small_kernel<64>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,
-                           dead_thresh, out, dead, nrot, maxoff);
+                           dead_thresh, out, dead, nrot, maxoff, relevant2);
     TN_CHECK_LAUNCH("eig_small_kernel");
     prof_end(st, PROF_EIG, 0.0, 8.0 * ngroups * ((double)nchunk + 1.0) * nvec * nvec);
     return 0;

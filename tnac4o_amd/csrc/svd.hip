@@ -12,6 +12,7 @@
 // one-sided Jacobi accuracy.  Host syncs: one for deflation, one per sweep (convergence), one for the kept rank.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256) void svd_vals_small_kernel(const double* __res
     __shared__ double nrm[NV];
     __shared__ int flags[2];                  // [0] rotations this sweep, [1] rotations above the convergence threshold
     const int tid = threadIdx.x, slot = tid >> 3, sub = tid & 7;
+    double relevant2 = 0.0;
     {
         double xv[16];
 #pragma unroll
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256) void svd_vals_small_kernel(const double* __res
         double nmax = 0.0;
         for (int r = 0; r < NV; ++r) nmax = fmax(nmax, nrm[r]);
         const double thr = nmax * 1.9259299443872359e-34;       // (2^-56)^2
+        relevant2 = nmax * 3.0814879110195774e-33;              // (2^-54)^2: see jacobi_core
         if (!(a > thr)) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) X[(2 * slot) * P + sub * 8 + e] = 0.0;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void svd_vals_small_kernel(const double* __res
                         X[q * P + sub * 8 + e] = sn * xp[e] + c * xq[e];
                     }
                     any = 1;
-                    if (g2 > conv2 * ab) big = 1;
+                    if (g2 > conv2 * ab && fmin(a, b) > relevant2) big = 1;
                 }
             }
             __syncthreads();
@@ -266,8 +269,16 @@ int64_t svd_ws_bytes(int64_t k, int64_t n, int vectors) {
 
 // Core: orthogonalise the rows of M (nv x L, strides vs/es).  On return hostS holds the singular values sorted
 // descending (length nvl), *nvl_out the number of live vectors, order[] (device) the matching row permutation.
+// rel_tol: the relative threshold below which singular values are of no interest to the caller (the truncation rule keeps
+// S > S0 max(eps, tol), mps.py:805-806).  Vectors a factor 4 below it (relative to the largest input row) are still rotated
+// whenever a group needs rotating, but they do not hold up convergence: the rows of a triangular factor beyond its
+// numerical rank are rounding noise of the QR (typically 2/3 of the live rows at 1e-16..1e-17 of the scale), a generic
+// dense cluster on which cyclic Jacobi needs 15-25 sweeps, and every one of them is discarded afterwards.  What is returned
+// for the kept vectors is unaffected: U and V^T stay orthonormal (J is orthogonal, the kept rows are mutually orthogonal),
+// and the discarded weight is the Frobenius norm of the remaining rows, which rotations do not change.
 static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, int64_t nv, int64_t L, bool vectors,
-                       SvdWs& w, std::vector<double>& hostS, std::vector<int>& hostOrder, int* sweeps_out, int* info) {
+                       SvdWs& w, std::vector<double>& hostS, std::vector<int>& hostOrder, int* sweeps_out, int* info,
+                       double rel_tol) {
     hipError_t e;
     int rc;
     TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nv), dim3(256), 0, st, M, vs, es, L, w.norms));
@@ -285,6 +296,11 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     for (int64_t i = 0; i < nv; ++i)
         if (hn[i] > thr) live.push_back((int)i);
     if (live.empty()) live.push_back(0);                      // all-zero input: one (zero) vector
+    // de Rijk ordering: vectors enter the tournament sorted by decreasing norm, so that the blocks are graded (large
+    // vectors meet large ones first) -- the classical remedy for the slow start of Jacobi on strongly graded matrices.
+    // Only the initial order changes (TN_SVD_SORT=0 keeps the input order for A/B measurements).
+    static const bool sort_live = [] { const char* e = getenv("TN_SVD_SORT"); return !(e && e[0] == '0'); }();
+    if (sort_live) std::stable_sort(live.begin(), live.end(), [&](int a, int b) { return hn[a] > hn[b]; });
     const int nvl = (int)live.size();
     const int64_t nvp = align_up(nvl, 2 * SVD_W);
     const int nblk = (int)(nvp / SVD_W), ng = nblk / 2, nr = nblk - 1;
@@ -307,7 +323,11 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     std::vector<double> hoff((size_t)nr * ng);
     // a single block pair is diagonalised completely inside eig_small (one round + one verification round);
     // with several pairs two inner sweeps per visit give the fewest total Jacobi steps
-    const int inner_sweeps = (ng == 1) ? 12 : 2;
+    static const int inner_env = [] { const char* e = getenv("TN_SVD_INNER"); return e ? atoi(e) : 2; }();
+    const int inner_sweeps = (ng == 1) ? 12 : inner_env;
+    static const bool restrict_conv = [] { const char* e = getenv("TN_SVD_RELEVANT"); return !(e && e[0] == '0'); }();
+    const double rel4 = 0.25 * rel_tol;
+    const double relevant2 = restrict_conv ? nmax * rel4 * rel4 : 0.0;
     int sweeps = 0;
     bool converged = false;
     for (int outer = 0; outer < 40 && !converged; ++outer) {
@@ -322,7 +342,8 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
             if ((rc = gemm_ex(st, nvec, nvec, L, 1.0, w.X, pitch, 1, w.X, 1, pitch, 0.0, nullptr, 0, 0, ng, 0, 0, 0, w.part,
                               (int64_t)ng * nchunk * nvec * nvec * 8, &xg)))
                 return rc;
-            if ((rc = eig_small(st, w.part, used, nvec, ng, 2, inner_sweeps, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng))) return rc;
+            if ((rc = eig_small(st, w.part, used, nvec, ng, 2, inner_sweeps, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng, relevant2)))
+                return rc;
             GemmExtra xa;
             xa.pairs = pr; xa.pw = SVD_W; xa.mapB = 1; xa.mapC = 1; xa.skip = w.nrot;
             if ((rc = gemm_ex(st, nvec, pitch, nvec, 1.0, w.Js, 1, nvec, w.X, pitch, 1, 0.0, w.X, pitch, 1, ng, (int64_t)nvec * nvec,
@@ -334,6 +355,8 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync sweep");
         double worst = 0.0;
         for (double v : hoff) worst = std::max(worst, v);
+        static const bool trace = [] { const char* e = getenv("TN_SVD_TRACE"); return e && e[0] == '1'; }();
+        if (trace) fprintf(stderr, "[tn_svd] nv=%lld L=%lld live=%d sweep=%d worst=%.3e\n", (long long)nv, (long long)L, nvl, sweeps, worst);
         converged = worst < 4.0e-15;
     }
     if (sweeps_out) *sweeps_out = sweeps;
@@ -366,11 +389,11 @@ int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t
     svd_layout(nv, L, true, (char*)ws, &w);
     std::vector<double> hS;
     std::vector<int> hO;
-    int rc = jacobi_core(st, C, vs, es, nv, L, true, w, hS, hO, sweeps_out, info);
-    if (rc) return rc;
-    const int nvl = (int)hS.size();
     const double eps = 2.220446049250313e-16;
     const double t = tol > eps ? tol : eps;
+    int rc = jacobi_core(st, C, vs, es, nv, L, true, w, hS, hO, sweeps_out, info, t);
+    if (rc) return rc;
+    const int nvl = (int)hS.size();
     int64_t keep = 0;
     for (int i = 0; i < nvl; ++i) keep += (hS[i] > hS[0] * t) ? 1 : 0;
     if (keep > Dmax) keep = Dmax;
@@ -427,7 +450,7 @@ int svd_vals(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t 
     svd_layout(nv, L, false, (char*)ws, &w);
     std::vector<double> hS;
     std::vector<int> hO;
-    int rc = jacobi_core(st, C, vs, es, nv, L, false, w, hS, hO, sweeps_out, info);
+    int rc = jacobi_core(st, C, vs, es, nv, L, false, w, hS, hO, sweeps_out, info, 2.220446049250313e-16);
     if (rc) return rc;
     for (int64_t i = 0; i < nv; ++i) hostS[i] = i < (int64_t)hS.size() ? hS[i] : 0.0;
     return 0;

@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C-ABI (torch tensors in, torch tensors out).  PyTorch is used for device
 memory and streams only; every contraction/factorisation below runs in libtnpeps."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -9,6 +10,26 @@ from ._lib import lib, check, TnError
 
 QR_NB = 32
 _ws = {}
+_aux = {}
+LOOKAHEAD = os.environ.get('TN_QR_LOOKAHEAD', '0') == '1'      # tn_qr look-ahead on a second stream per chain (off: no gain measured)
+
+
+def register_aux_stream(main, aux):
+    """Pair a chain's stream with the side stream tn_qr may use for its look-ahead (parallel.run_concurrent does this for
+    the streams it creates, so the mapping of chains to hardware queues is deterministic)."""
+    _aux[(main.device.index, main.cuda_stream)] = aux
+
+
+def aux_stream():
+    """The side stream paired with the current stream (created on first use), or None when look-ahead is disabled."""
+    if not LOOKAHEAD:
+        return None
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream)
+    a = _aux.get(key)
+    if a is None:
+        a = _aux[key] = torch.cuda.Stream()
+    return a
 
 
 def _stream():
@@ -100,12 +121,15 @@ def qr_into(T, Q, R, overwrite=False, nb=None, rank_tol=0.0):
     wsb = L.tn_qr_ws_bytes(m, n, nb)
     ws = workspace(wsb, 0)
     keff = C.c_int64(min(m, n))
+    aux = aux_stream() if (nb == 32 and m >= 2048 and min(m, n) >= 128) else None
     check(L.tn_qr(T.data_ptr(), T.stride(0), T.stride(1), m, n, Q.data_ptr(), Q.stride(0), Q.stride(1), R.data_ptr(),
-                  R.stride(0), R.stride(1), nb, float(rank_tol), C.byref(keff), ws.data_ptr(), wsb, _stream()))
+                  R.stride(0), R.stride(1), nb, float(rank_tol), C.byref(keff), ws.data_ptr(), wsb, _stream(),
+                  C.c_void_p(aux.cuda_stream) if aux is not None else None))
     return Q, R, int(keff.value)
 
 
 def qr(T, overwrite=False, nb=None):
+    """Economic QR (Q, R) of a 2-D view; T is preserved unless overwrite is set."""
     m, n = T.shape
     k = min(m, n)
     Q = torch.empty((m, k), dtype=torch.float64, device=T.device)

@@ -27,6 +27,16 @@ def run_concurrent(fns):
     # streams (or a persistent thread pool) fell into a 1.5x slower regime under bench.py (2.45-2.53 vs 1.60-1.70 s/sweep)
     # whenever an event had been recorded on the legacy default stream; this form held 1.70 s/sweep over 11 calls.
     streams = [torch.cuda.Stream() for _ in range(n)]
+    from . import ops
+    if ops.LOOKAHEAD:
+        # side streams for tn_qr's look-ahead, taken right after the chains' own streams so that the pairing with hardware
+        # queues is the same on every call (torch hands out pool streams round-robin, pool stream k sits on hardware queue
+        # k mod 4): chain i's side stream is rotated by AUX_ROT so that it does not share a queue with its own chain
+        import os
+        rot = int(os.environ.get('TN_AUX_ROT', '2'))
+        side = [torch.cuda.Stream() for _ in range(n)]
+        for i in range(n):
+            ops.register_aux_stream(streams[i], side[(i + rot) % n])
     out, err = [None] * n, [None] * n
     # The caller's pending work must be visible to the chains: wait for it on the HOST.  streams[i].wait_stream(current)
     # would record an event on the (legacy) default stream, after which every launch of the chain pays for a dependency on
