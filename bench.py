@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: boundary-MPS PEPS contraction, ms per sweep, chimera L=2048, chi=64 (BASELINE.json).
 
-One step = one sweep = one `_setup_rhoT` (reference tnac4o.py:1674-1695): for each of the 16 rows, build the row
-MPO, absorb it into the boundary MPS and compress back to chi=64 with the defaults of search_ground_state
-(graduate_truncation, tolS=1e-16, tolV=1e-10, max_sweeps=20).  Synthetic chimera couplings (seed 20260004,
-SURVEY.md §8d).  With N GPUs each rank sweeps its own lattice rotation (rank mod 4) of the same couplings — the
-reference's 4-rotation loop (examples/e06:97-109) sharded with no data-path collective ("weak" scaling);
-`value` = wall ms divided by the number of sweeps all ranks completed.  On each GPU the G = 4 lattice rotations of one
-instance run interleaved on 4 HIP streams (the chains are latency-bound), so one step = G sweeps
-per rank; the latency of a single chain is reported as config.single_chain_sweep_latency_ms.
+One sweep = one `_setup_rhoT` (reference tnac4o.py:1674-1695): for each of the 16 rows, build the row MPO, absorb it
+into the boundary MPS and compress back to chi=64 with the defaults of search_ground_state (graduate_truncation,
+tolS=1e-16, tolV=1e-10, max_sweeps=20).  Synthetic chimera couplings (seed 20260004).
 
-Prints ONE JSON line on rank 0.  `roofline` describes the kernel family with the largest summed duration, timed
-with HIP events on its launch stream inside the timed region; `cpu_baseline` times the CPU oracle on a bounded
-sample (the bottom rows of the same sweep) on this box's host cores.
+One step = the sweeps of the 4 lattice rotations of ONE instance (the reference's 4-rotation loop, examples/e06:97-109),
+`value` = wall ms of a step / 4.  N = 1: the 4 chains are interleaved on 4 HIP streams of the one GPU.  N > 1 (`--mode
+sweep`, the default) is the north-star decomposition of the same job: the rotations are dealt to min(N, 4) teams of
+N / teams ranks; a team's first rank sweeps its rotation(s), and when a team has partners (N = 8: 4 rotations x 2 beam
+shards) it broadcasts the boundary MPS of every row to them over RCCL inside the timed step (what the beam shards need
+before the search can start).  Same total work for every N => "scaling": "strong".  `--mode replicas` keeps the round-1
+form (every rank its own instance, no collective, "weak").  After the timed steps one full 4-rotation ground-state
+search (solve_rotations: sweeps + M=1024 beam + RCCL gather at merge time) is timed once as `full_solve`.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the kernel family with the largest summed duration, timed with
+HIP events on its launch stream inside the timed region; `cpu_baseline` times the CPU oracle on a bounded sample of the
+same sweep (bulk sites of the middle row) on this box's host cores.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -37,8 +42,12 @@ FAMILIES = ['gemm_kernel<128,128>', 'gemm_kernel<128,32>', 'gemm_kernel<32,128>'
 COUNTERS = {'qr_nominal': 15, 'svd_nominal': 16, 'svd_stream': 17, 'svdvals_nominal': 18}   # counter-only families
 PHASES = ['gemm_var (attach / projector / environment GEMMs, scaling)', 'absorb', 'qr', 'svd_trunc', 'svdvals', 'mpo_build']
 MFMA_FAM = {0, 1, 2, 3}
+SERIAL_FAM = {7: ('eig_small_kernel', 'Jacobi step (32 plane rotations of a 64 x 64 Gram matrix in LDS)', 126),
+              10: ('tsqr_factor/apply_kernel', 'Householder column of a 256 x 32 block', 32)}
 PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X fp64 matrix peak (vendor figure quoted in SURVEY.md §7; not in the microarch guide)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+WORKLOADS = {'chimera2048': ('Ising', 16, 20260004, 3.0), 'chimera512': ('Ising', 8, 20260003, 3.0),
+             'chimera128': ('Ising', 4, 20260002, 3.0), 'rmf64': ('RMF', 64, 20260005, 1.0)}
 
 
 def _get(lib, phase, f):
@@ -51,7 +60,7 @@ def profile_totals(lib, phase=-1):
     return [dict(kernel=FAMILIES[f], **_get(lib, phase, f)) for f in range(len(FAMILIES))]
 
 
-def phase_report(lib):
+def phase_report(lib, pmc):
     """Sub-timers of SURVEY.md §8(d): summed kernel durations of one single-chain sweep split by the entry point that
     issued the launch, plus the three SVD-step roofline figures and the nominal QR rate."""
     rep = {}
@@ -64,8 +73,12 @@ def phase_report(lib):
     if t_qr > 0:
         rep['qr'].update({'calls': qr['calls'], 'nominal_tflops': qr['flops'] / t_qr / 1e12,
                           'frac_of_f64_mfma_peak': qr['flops'] / t_qr / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                          'compulsory_GBps': qr['bytes'] / t_qr / 1e9})
+                          'compulsory_GBps': qr['bytes'] / t_qr / 1e9,
+                          'note': 'nominal counts use the full (m, n) of every call; the truncating passes stop early (rank_tol)'})
     if t_svd > 0:
+        tert = None
+        if pmc and pmc.get('svd_step'):
+            tert = pmc['svd_step']
         rep['svd_trunc'].update({
             'calls': svd['calls'], 'executed_sweeps': stream['calls'],
             'nominal_tflops': svd['flops'] / t_svd / 1e12,
@@ -73,32 +86,62 @@ def phase_report(lib):
             'hbm_primary_frac': svd['bytes'] / t_svd / 1e9 / PEAK_HBM_GBS,
             'hbm_secondary_jacobi_streaming_model_GBps': stream['bytes'] / t_svd / 1e9,
             'hbm_secondary_frac': stream['bytes'] / t_svd / 1e9 / PEAK_HBM_GBS,
-            'hbm_tertiary_pmc': None,
+            'hbm_tertiary_pmc': tert,
             'note': 'block Jacobi (32-wide blocks): the pair Gram/apply are MFMA GEMMs on L2/Infinity-Cache-resident data, '
                     'so the streaming model of a column-pair Jacobi overstates the bytes actually moved; the step is '
-                    'latency-bound (eig_small), not HBM-bound'})
+                    'latency-bound (eig_small: one workgroup per block pair), not HBM-bound'})
     if sv['calls']:
         rep['svdvals'].update({'calls': sv['calls']})
     return rep
 
 
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def load_pmc():
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            d['file'] = 'profiles/' + name
+            return d
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--L', type=int, default=2048, choices=[128, 512, 2048])
-    ap.add_argument('--chi', type=int, default=64)
-    ap.add_argument('--cpu-rows', type=int, default=2, help='bottom rows timed on the CPU oracle (0 disables)')
+    ap.add_argument('--workload', default='chimera2048', choices=sorted(WORKLOADS))
+    ap.add_argument('--L', type=int, default=None, choices=[128, 512, 2048], help='shorthand for --workload chimera<L>')
+    ap.add_argument('--chi', type=int, default=None, help='bond dimension (default 64; 128 for rmf64)')
+    ap.add_argument('--mode', default='sweep', choices=['sweep', 'replicas'],
+                    help='sweep: one instance, rotations (and beam partners) sharded over the ranks, strong scaling; '
+                         'replicas: every rank its own instance, no collective, weak scaling')
+    ap.add_argument('--cpu-rows', type=int, default=4, help='bulk sites of the middle row timed on the CPU oracle (0 disables)')
     ap.add_argument('--concurrent', type=int, default=4,
-                    help='independent sweeps (lattice rotations of one instance) interleaved per GPU, one stream each')
+                    help='N = 1: lattice rotations of the instance interleaved on the GPU, one stream each (4 = the full step)')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--sample', type=int, default=8,
                     help='in the timed region bracket every n-th launch of the dominant kernel family with events')
-    ap.add_argument('--no-search', action='store_true', help='skip the (untimed) full search_ground_state figure')
+    ap.add_argument('--no-search', action='store_true', help='skip the (untimed) full ground-state search figure')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group even with one rank (rehearses the multi-GPU code path on one GPU)')
     args = ap.parse_args()
+    if args.L:
+        args.workload = 'chimera%d' % args.L
+    kind, n, seed, beta = WORKLOADS[args.workload]
+    chi = args.chi or (128 if kind == 'RMF' else 64)
 
     # stdout carries exactly one JSON line (rank 0): everything the libraries print while we work (RCCL's version banner
     # goes to stdout) is routed to stderr, and the real stdout is restored just before the line is written
@@ -119,18 +162,21 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     import tnac4o_amd
-    from tnac4o_amd import _lib
-    from tnac4o_amd.auxx import synthetic_chimera
+    from tnac4o_amd import _lib, parallel
+    from tnac4o_amd.auxx import synthetic_chimera, synthetic_rmf
     lib = _lib.lib()
-    n = {128: 4, 512: 8, 2048: 16}[args.L]
-    seed = {128: 20260002, 512: 20260003, 2048: 20260004}[args.L]
-    from tnac4o_amd.parallel import run_concurrent
-    G = max(1, args.concurrent)
-    J = synthetic_chimera(n, n, seed + rank)                 # every rank sweeps its own instance (weak scaling)
-    kw = dict(graduate_truncation=True, Dmax=args.chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
+    pmc = load_pmc()
+    replicas = args.mode == 'replicas'
+    inst_seed = seed + (rank if replicas else 0)
+    J = synthetic_chimera(n, n, inst_seed) if kind == 'Ising' else synthetic_rmf(n, n, 8, inst_seed)
+    kw = dict(graduate_truncation=True, Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
+    NROT = 4
 
-    def make(rot):
-        s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=J, beta=3.0)
+    def make(rot=0):
+        if kind == 'Ising':
+            s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=J, beta=beta)
+        else:
+            s = tnac4o_amd.tnac4o(mode='RMF', Nx=n, Ny=n, J=J, beta=beta)
         if rot % 4:
             s.rotate_graph(rot % 4)
         return s
@@ -141,40 +187,72 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    solvers = [make(g) for g in range(G)]
-    solver = solvers[0]
+    # ---- who does what (sweep mode): teams of B = world / nteams consecutive ranks, rotations dealt round-robin to teams
+    if replicas or world == 1:
+        nteams, B, team, owner = 1, 1, 0, True
+        my_rots = list(range(max(1, args.concurrent))) if world == 1 else list(range(NROT))
+        beam_group = None
+    else:
+        nteams = min(world, NROT)
+        if world % nteams:
+            raise SystemExit('--gpus must be 1, 2, 4 or a multiple of 4')
+        B = world // nteams
+        team, owner = rank // B, rank % B == 0
+        my_rots = [r for r in range(NROT) if r % nteams == team]
+        beam_group = parallel._beam_groups(world, B)[team] if B > 1 else None
+    sweeps_per_step = len(my_rots) * (world if replicas else 1) if (replicas or world == 1) else NROT
+    solvers = [make(r) for r in my_rots] if owner else []
+    solver = solvers[0] if solvers else None
 
-    def step():                  # one step = G sweeps (the rotations of this rank's instance), interleaved on G streams
-        run_concurrent([(lambda s=s: s._setup_rhoT(**kw)) for s in solvers])
+    def step():
+        if owner:
+            parallel.run_concurrent([(lambda s=s: s._setup_rhoT(**kw)) for s in solvers])
+        if beam_group is not None or (args.force_dist and world == 1):
+            # the boundary MPS of every row to the beam partners (RCCL broadcast; rehearsed on a group of one with --force-dist)
+            for s in (solvers if owner else [None] * len(my_rots)):
+                parallel.broadcast_site_tensors([m.A for m in s.rhoT] if owner else None, beam_group, rehearse=world == 1)
 
-    # Untimed phase.  (1) one single-chain sweep with events on every kernel family: sweep latency and the per-family
-    # table; (2) the W warm-up steps.  The timed steps then bracket only the dominant family's launches with events, so
-    # the roofline duration is measured inside the timed region at small overhead.
-    warm_prof, single_ms = None, None
+    # Untimed phase.  (1) one single-chain sweep without any instrumentation (latency of one chain), (2) the same with
+    # events on every kernel family (per-family / per-phase tables), (3) the W warm-up steps.  The timed steps then
+    # bracket only the dominant family's launches with events, so the roofline duration is measured inside the timed
+    # region at small overhead.
+    warm_prof, single_ms, single_prof_ms, phases = None, None, None, None
     mask_all = (1 << len(FAMILIES)) - 1
-    phases = None
-    if not args.no_profile and args.warmup > 0:
+    if owner and rank == 0 and not args.no_profile and args.warmup > 0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solver._setup_rhoT(**kw)
+        torch.cuda.synchronize()
+        single_ms = 1e3 * (time.perf_counter() - t0)
         lib.tn_profile_reset()
         lib.tn_profile_enable(mask_all)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         solver._setup_rhoT(**kw)
         torch.cuda.synchronize()
-        single_ms = 1e3 * (time.perf_counter() - t0)
+        single_prof_ms = 1e3 * (time.perf_counter() - t0)
         warm_prof = profile_totals(lib)
-        phases = phase_report(lib)
+        phases = phase_report(lib, pmc)
         lib.tn_profile_enable(0)
     for _ in range(args.warmup):
         step()
     if not args.no_profile:
         dom_mask = mask_all if warm_prof is None else 1 << max(range(len(warm_prof)), key=lambda i: warm_prof[i]['ms'])
+        if dist is not None and world > 1:          # every rank samples the family rank 0 found dominant
+            t = torch.tensor([dom_mask], dtype=torch.int64, device='cuda')
+            dist.broadcast(t, src=0)
+            dom_mask = int(t.item())
         lib.tn_profile_reset()
         lib.tn_profile_sample(max(1, args.sample))
         lib.tn_profile_enable(dom_mask)
+    step_ms = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        step_ms.append(1e3 * (time.perf_counter() - ts))
     barrier()
     dt = time.perf_counter() - t0
     prof = None
@@ -182,40 +260,59 @@ def main():
         prof = profile_totals(lib)
         lib.tn_profile_enable(0)
         lib.tn_profile_sample(1)
-    # second headline, outside the timed region: one full search_ground_state (sweep + 256-site beam,
-    # M = 1024) of rotation 0 on a single chain
-    search_ms = None
-    if rank == 0 and not args.no_search:
-        sv = make(0)
-        torch.cuda.synchronize()
-        t0s = time.perf_counter()
-        sv.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=args.chi)
-        torch.cuda.synchronize()
-        search_ms = 1e3 * (time.perf_counter() - t0s)
-        search_info = {'ms': search_ms, 'energy': float(sv.energy[0]), 'degeneracy': int(sv.degeneracy),
-                       'log2_probability': float(sv.probability[0]), 'negative_probability': float(sv.negative_probability)}
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps
 
+    # second headline, outside the timed region: one full ground-state search of the 4 rotations
+    # (sweeps + beam M=1024, merge of the rotations; with N > 1 sharded exactly like the timed step, one RCCL all-gather)
+    full = None
+    if not args.no_search:
+        M = 1024 if kind == 'Ising' else 64
+        skw = dict(M=M, relative_P_cutoff=1e-8, Dmax=chi)
+        barrier()
+        t0s = time.perf_counter()
+        if world == 1 or replicas:
+            res = parallel.solve_rotations(make, rotations=tuple(my_rots), concurrent=True, **skw) if rank == 0 else None
+        else:
+            res = parallel.solve_rotations(make, rotations=tuple(range(NROT)), concurrent=(B == 1), beam_shards=B, **skw)
+        barrier()
+        if res is not None:
+            full = {'ms': 1e3 * (time.perf_counter() - t0s), 'rotations': len(res['records']), 'M': M,
+                    'energy': res['energy'], 'degeneracy': res['degeneracy'], 'log2_probability': res['probability'],
+                    'best_rotation': res['rotation'],
+                    'what': 'solve_rotations: %d rotation(s), sweeps + beam search + merge%s' %
+                            (len(res['records']), '' if world == 1 else ', one RCCL all-gather of the records')}
+
     if rank == 0:
+        par = ('1 GPU: %d lattice rotations of one instance interleaved on %d HIP streams' % (len(my_rots), len(my_rots))) \
+            if world == 1 else \
+            ('%d ranks, every rank its own instance with 4 interleaved rotations, no collective' % world) if replicas else \
+            ('%d ranks = %d rotation teams x %d rank(s): each team owner sweeps %d rotation(s)%s' %
+             (world, nteams, B, len(my_rots), ', boundary MPS broadcast to its beam partner(s) over RCCL in the timed step'
+              if B > 1 else ''))
         out = {
-            'metric': 'PEPS-contraction ms/sweep, chimera L=%d chi=%d (boundary-MPS sweep _setup_rhoT)' % (args.L, args.chi),
-            'value': ms_per_step / (world * G), 'unit': 'ms/sweep', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'chimera L=%d (Nx=Ny=%d, Nc=8) synthetic couplings seed %d, beta=3, chi=%d, one sweep = %d '
-                                   'rows of MPO absorb + compress_mps' % (args.L, n, seed, args.chi, n),
-                       'sweeps_per_step_all_ranks': world * G,
-                       'parallelism': '%d rank(s) x %d lattice rotations interleaved per GPU (one HIP stream each), one instance per '
-                                      'rank, no data-path collective' % (world, G),
+            'metric': 'PEPS-contraction ms/sweep, %s chi=%d (boundary-MPS sweep _setup_rhoT)' % (
+                'chimera L=%d' % (n * n * 8) if kind == 'Ising' else 'RMF %dx%d d=8' % (n, n), chi),
+            'value': ms_per_step / sweeps_per_step, 'unit': 'ms/sweep', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': False,
+            'scaling': 'weak' if replicas else 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s, synthetic couplings seed %d, beta=%g, chi=%d; one sweep = %d rows of MPO absorb + '
+                                   'compress_mps; one step = the sweeps of the %d lattice rotations of one instance' % (
+                                       ('chimera L=%d (Nx=Ny=%d, Nc=8)' % (n * n * 8, n)) if kind == 'Ising' else
+                                       ('Random Markov Field %d x %d, d=8' % (n, n)), seed, beta, chi, n, sweeps_per_step),
+                       'sweeps_per_step': sweeps_per_step, 'parallelism': par, 'mode': args.mode,
+                       'median_ms_per_sweep': statistics.median(step_ms) / sweeps_per_step,
+                       'step_ms_rank0': [round(x, 1) for x in step_ms],
                        'single_chain_sweep_latency_ms': single_ms,
-                       'rhoT_discarded_max': float(max(solver.rhoT_discarded)),
-                       'rhoT_overlap_min': float(min(solver.rhoT_overlap)),
-                       'bond_dims_mid_row': [int(d) for d in solver.rhoT[n // 2].D]},
+                       'single_chain_sweep_latency_with_events_on_every_launch_ms': single_prof_ms},
         }
+        if solver is not None and getattr(solver, 'rhoT', None):
+            out['config'].update({'rhoT_discarded_max': float(max(solver.rhoT_discarded)),
+                                  'rhoT_overlap_min': float(min(solver.rhoT_overlap)),
+                                  'bond_dims_mid_row': [int(d) for d in solver.rhoT[n // 2].D]})
         if prof is not None:
             dom = max(range(len(prof)), key=lambda i: prof[i]['ms'])
             d = prof[dom]
@@ -232,32 +329,31 @@ def main():
                                             'the timed region' % max(1, args.sample),
                          'avg_launch_ms': avg_ms,
                          'algorithmic_flops_per_launch': d['flops'] / max(1, d['calls']),
-                         'algorithmic_bytes_per_launch': d['bytes'] / max(1, d['calls']),
-                         'note': 'single-workgroup LDS-resident Jacobi step: latency-bound, far from either roofline'
-                                 if d['kernel'].startswith('eig_small') or d['kernel'].startswith('tsqr') else ''})
-            # HBM traffic from the PMC counters: rocprofv3's counter mode crashes on this multi-threaded bench, so the
-            # FETCH_SIZE / WRITE_SIZE passes are taken on tools/pmc_probe.py (the same kernels at the bulk shapes of this
-            # workload) and committed under profiles/; the figure is per launch of the probe, next to the probe's own
-            # algorithmic bytes per launch.
-            try:
-                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['families'].get(d['kernel'])
-            except (OSError, ValueError, KeyError):
-                pm = None
-            if pm:
-                roof['traffic'] = pm['traffic_bytes_per_launch']
+                         'algorithmic_bytes_per_launch': d['bytes'] / max(1, d['calls'])})
+            if dom in SERIAL_FAM:
+                _, what, nser = SERIAL_FAM[dom]
+                roof['limited_by'] = ('latency: a column-serial single-workgroup kernel (its bytes are its algorithmic minimum, '
+                                      'see traffic); figure of merit = time per serial step')
+                roof['us_per_serial_step'] = 1e3 * avg_ms / nser
+                roof['serial_step'] = '%s, %d per launch' % (what, nser)
+            fam = (pmc or {}).get('families', {}).get(d['kernel']) if pmc else None
+            if fam:
+                roof['traffic'] = fam['traffic_bytes_per_launch']
                 roof['traffic_detail'] = {
-                    'unit': 'bytes per launch', 'source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
-                    'separate passes, FETCH_SIZE x2 per the gfx950 correction) on tools/pmc_probe.py: tn_qr 16384 x 1024',
-                    'fetch': pm['fetch_bytes_per_launch'], 'write': pm['write_bytes_per_launch'],
-                    'algorithmic_bytes_per_launch_same_probe': pm.get('algorithmic_bytes_per_launch'),
-                    'traffic_over_algorithmic': pm.get('traffic_over_algorithmic')}
+                    'unit': 'bytes per launch', 'source': '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
+                    'FETCH_SIZE x2 per the gfx950 correction) on tools/pmc_probe.py: the same kernels at the bulk shapes of '
+                    'this workload (tn_qr 16384 x 1024, tn_svd_trunc 1024 x 1024)' % pmc['file'],
+                    'fetch': fam['fetch_bytes_per_launch'], 'write': fam['write_bytes_per_launch'],
+                    'algorithmic_bytes_per_launch_same_probe': fam.get('algorithmic_bytes_per_launch'),
+                    'traffic_over_algorithmic': fam.get('traffic_over_algorithmic')}
             out['roofline'] = roof
             table = warm_prof if warm_prof is not None else prof
-            nsw = 1 if warm_prof is not None else args.steps * G
+            nsw = 1 if warm_prof is not None else args.steps * len(my_rots)
             out['kernel_table_source'] = ('one single-chain sweep before the timed region (events on all families)'
                                           if warm_prof is not None else 'timed sweeps')
             out['kernel_time_ms_per_sweep'] = {p['kernel']: round(p['ms'] / nsw, 3) for p in table}
             out['kernel_launches_per_sweep'] = {p['kernel']: p['calls'] // nsw for p in table}
+            out['launches_per_sweep'] = sum(p['calls'] for p in table) // nsw
             if phases is not None:
                 out['phase_kernel_time_single_chain_sweep'] = phases
             gm = [p for i, p in enumerate(table) if i in MFMA_FAM and p['ms'] > 0]
@@ -265,14 +361,22 @@ def main():
                 fl, ms = sum(p['flops'] for p in gm), sum(p['ms'] for p in gm)
                 out['gemm_mfma'] = {'achieved': fl / (ms * 1e-3) / 1e12, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': fl / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS, 'ms_per_sweep': ms / nsw}
+                if warm_prof is not None:
+                    t_sw = ms_per_step / sweeps_per_step * 1e-3
+                    out['sweep_mfma'] = {
+                        'executed_mfma_gemm_flops_per_sweep': fl, 'unit': 'TFLOP/s', 'peak': PEAK_F64_MFMA_TFLOPS,
+                        'achieved_at_step_rate': fl / t_sw / 1e12, 'frac_at_step_rate': fl / t_sw / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                        'frac_single_chain': (fl / (single_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS) if single_ms else None,
+                        'note': 'all MFMA GEMM flops a sweep executes / wall time of a sweep; SQ MFMA counters: ' +
+                                ((pmc or {}).get('mfma_counters', {}).get('file', 'not collected'))}
             ab = table[5]
             if ab['ms'] > 0:
                 out['absorb_hbm'] = {'achieved': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                      'frac': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS}
-        if search_ms is not None:
-            out['full_search_single_chain'] = search_info
-        if args.cpu_rows > 0:
-            out['cpu_baseline'] = cpu_baseline(J, n, args, solver, kw)
+        if full is not None:
+            out['full_solve'] = full
+        if args.cpu_rows > 0 and world == 1 and kind == 'Ising' and solver is not None:
+            out['cpu_baseline'] = cpu_baseline(n, args, solver, kw, single_ms)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
@@ -282,76 +386,69 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(J, n, args, solver, kw):
-    """CPU oracle ("port" of the reference algorithm, numpy/scipy on OpenBLAS) on the bottom `cpu_rows` rows of the
-    same sweep, and the GPU time for the same rows; the full-sweep CPU figure is the measured GPU ms/sweep scaled by
-    that ratio (a full CPU sweep at L=2048 chi=64 takes tens of minutes)."""
-    from oracle import solver_ref as sr
+def cpu_baseline(n, args, solver, kw, single_ms):
+    """CPU oracle ("port" of the reference algorithm, numpy/scipy on OpenBLAS) on a bounded bulk sample of the same sweep:
+    the middle row's absorbed boundary MPS, first canonisation pass (attach GEMM, QR with the reference's gauge, nfactor;
+    reference mps.py:220-236) over the right edge and `cpu_rows` bulk sites, i.e. the shapes that make up ~40 % of a sweep
+    ((p Dr) x Dl = 16384 x 1024).  The same steps are timed on the GPU; the full-sweep CPU figure is a linear
+    extrapolation by that ratio (a full CPU sweep at L=2048 chi=64 takes the better part of an hour).  One bulk QR is also
+    timed with a single BLAS thread."""
     from oracle import mps_ref as mr
-    rows = min(args.cpu_rows, n)
-    b = sr.RefSolver(mode='Ising', Nx=n, Ny=n, Nc=8, J=J, beta=3.0)
-    t0 = time.perf_counter()
-    psi = mr.RefMPS(d=1, L=n, Dmax=1)
-    for ny in range(n - 1, n - 1 - rows, -1):
-        psi = psi.copy()
-        psi.apply_mpo(b._row_mpo(ny), Hconj=True)
-        psi.compress_mps(Dmax=kw['Dmax'], tolS=kw['tolS'], tolV=kw['tolV'], max_sweeps=kw['max_sweeps'],
-                         graduate_truncation=True)
-    cpu_ms = 1e3 * (time.perf_counter() - t0)
-    # the same rows on the GPU
     from tnac4o_amd import mps
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    phi = mps.MPS(d=1, L=n, Dmax=1, initial='X')
-    for ny in range(n - 1, n - 1 - rows, -1):
-        phi = phi.copy()
-        phi.apply_mpo(solver._row_mpo(ny), Hconj=True)
-        phi.compress_mps(Dmax=kw['Dmax'], tolS=kw['tolS'], tolV=kw['tolV'], max_sweeps=kw['max_sweeps'],
-                         graduate_truncation=True)
-    torch.cuda.synchronize()
-    gpu_ms = 1e3 * (time.perf_counter() - t0)
     try:
         import threadpoolctl
-        threads = max([p['num_threads'] for p in threadpoolctl.threadpool_info()] or [os.cpu_count()])
-    except Exception:
-        threads = os.cpu_count()
-    bulk = bulk_site_sample(solver, n, kw, mr, mps)
-    return {'value': cpu_ms, 'unit': 'ms for the sample', 'cores': int(threads), 'kind': 'port', 'bulk_site': bulk,
-            'sample': 'bottom %d of %d rows of the same sweep (rows %d..%d): MPO absorb + compress_mps, oracle/ numpy+scipy; '
-                      'GPU time for the same rows: %.1f ms' % (rows, n, n - 1, n - rows, gpu_ms),
-            'gpu_same_sample_ms': gpu_ms, 'speedup_on_sample': cpu_ms / gpu_ms if gpu_ms > 0 else None}
-
-
-def bulk_site_sample(solver, n, kw, mr, mps):
-    """Second bounded CPU sample, representative of the bulk of the sweep (the edge rows above are cheap): the
-    right-canonicalisation of ONE absorbed bulk site of the middle row — QR of the (p Dr b) x (Dl b) matrix with the
-    oracle's scipy/LAPACK call (mps.py:787-800) vs tn_qr on the same tensor."""
-    from tnac4o_amd import ops
-    ny, nx = n // 2, n // 2
+    except ImportError:
+        threadpoolctl = None
+    ny = n // 2
     psi = solver.rhoT[ny + 1].copy()
     psi.apply_mpo(solver._row_mpo(ny), Hconj=True)
-    T = psi.A[nx]
-    Dl, p, Dr = T.shape
-    host = T.cpu().numpy()
+    first_bulk = max(0, n - 4)                       # absorbed bonds reach their bulk value 3 sites from the edge
+    nsites = min(n, (n - first_bulk) + args.cpu_rows)
+    sites = list(range(n - 1, n - 1 - nsites, -1))
+    host = {s: psi.A[s].cpu().numpy() for s in sites}
+    o = mr.RefMPS(d=[int(a.shape[1]) for a in psi.A], L=n, Dmax=1, canonise=None)
+    o.A = [host.get(s) for s in range(n)]
+    o.D = list(psi.D)
+    o.C, o.pC = np.ones((1, 1)), n
     t0 = time.perf_counter()
-    Q, C = mr.qr_pos(host.reshape(Dl, p * Dr).T)
-    C = C / mr.pow2_floor_max(C)
+    for s in sites:
+        o.attach_AC()
+        o.orth_right(s)
     cpu_ms = 1e3 * (time.perf_counter() - t0)
-    k = min(p * Dr, Dl)
-    Qt = torch.empty((k, p * Dr), dtype=torch.float64, device='cuda')
-    Ct = torch.empty((Dl, k), dtype=torch.float64, device='cuda')
-    reps = 3
-    work = [T.clone() for _ in range(reps)]
+    shapes = ['%dx%d' % (o.A[s].shape[1] * o.A[s].shape[2], host[s].shape[0]) for s in sites]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for w in work:
-        ops.qr_into(w.view(Dl, p * Dr).t(), Qt.t(), Ct.t(), overwrite=True)
-        ops.normalize_pow2_(Ct)
+    psi.C = torch.ones((1, 1), dtype=torch.float64, device='cuda')
+    psi.pC = n
+    for s in sites:
+        psi.attach_AC()
+        psi.orth_right(s)
     torch.cuda.synchronize()
-    gpu_ms = 1e3 * (time.perf_counter() - t0) / reps
-    return {'what': 'QR (+ nfactor) of one absorbed bulk site, %d x %d, row %d site %d' % (p * Dr, Dl, ny, nx),
-            'cpu_ms': cpu_ms, 'gpu_ms': gpu_ms, 'speedup': cpu_ms / gpu_ms if gpu_ms > 0 else None,
-            'gpu_tflops_nominal': (4.0 * p * Dr * Dl * Dl - 4.0 / 3.0 * Dl ** 3) / (gpu_ms * 1e-3) / 1e12}
+    gpu_ms = 1e3 * (time.perf_counter() - t0)
+    threads = os.cpu_count()
+    if threadpoolctl is not None:
+        threads = max([p['num_threads'] for p in threadpoolctl.threadpool_info()] or [threads])
+    one = None
+    sb = max(sites, key=lambda s: host[s].size)      # the largest site of the sample: its input matrix with one BLAS thread
+    M1 = np.ascontiguousarray(host[sb].reshape(host[sb].shape[0], -1).T)
+    if threadpoolctl is not None:
+        with threadpoolctl.threadpool_limits(limits=1):
+            t0 = time.perf_counter()
+            mr.qr_pos(M1)
+            one = 1e3 * (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    mr.qr_pos(M1)
+    allc = 1e3 * (time.perf_counter() - t0)
+    ratio = cpu_ms / gpu_ms if gpu_ms > 0 else None
+    return {'value': cpu_ms, 'unit': 'ms for the sample', 'cores': int(threads), 'kind': 'port', 'cpu_model': cpu_model(),
+            'sample': 'row %d of %d (bulk), first canonisation pass of compress_mps over sites %d..%d (attach GEMM + QR + nfactor; '
+                      'QR shapes %s), oracle/ numpy+scipy with %d BLAS threads; the same steps on the GPU: %.1f ms'
+                      % (ny, n, sites[0], sites[-1], ', '.join(shapes), threads, gpu_ms),
+            'gpu_same_sample_ms': gpu_ms, 'speedup_on_sample': ratio,
+            'full_sweep_cpu_ms_linear_extrapolation': (ratio * single_ms) if (ratio and single_ms) else None,
+            'extrapolation': 'single-chain GPU sweep latency x (CPU / GPU time on the sample); the sample is QR-dominated like '
+                             'the sweep (QR = 65 % of a sweep\'s kernel time), so this is an order-of-magnitude figure',
+            'bulk_qr_%dx%d_ms' % M1.shape: {'one_thread': one, 'all_threads': allc}}
 
 
 if __name__ == '__main__':

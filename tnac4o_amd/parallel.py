@@ -109,16 +109,17 @@ def gather_branch_tables(compute, nb, q, group):
     return np.ascontiguousarray(full[:, :q]), np.ascontiguousarray(full[:, q])
 
 
-def broadcast_site_tensors(rows, group):
+def broadcast_site_tensors(rows, group, rehearse=False):
     """Broadcast a list (rows) of lists (sites) of float64 arrays from the first rank of `group` to the others.
 
     rows: on the source the tensors (numpy arrays or torch tensors); ignored elsewhere.  Returns the same nested list on
     every rank (numpy arrays for gloo, device tensors for nccl; the source gets its own objects back).  One broadcast of
-    the shapes and one flat buffer per row."""
+    the shapes and one flat buffer per row.  rehearse=True issues the collectives even in a group of one rank (bench.py
+    --force-dist: the RCCL code path on a single GPU)."""
     rank, world = _group_info(group)
-    if world == 1:
+    if world == 1 and not (rehearse and dist.is_available() and dist.is_initialized()):
         return rows
-    src = dist.get_global_rank(group, 0)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
     dev = _comm_device(group)
     meta = [[tuple(int(x) for x in a.shape) for a in row] for row in rows] if rank == 0 else None
     box = [meta]
