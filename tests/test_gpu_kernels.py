@@ -431,3 +431,25 @@ def test_qr_lookahead_bit_identical(ops, m, n, tol):
         assert torch.equal(Q[:, :keff], res[0][0][:, :keff]) and torch.equal(R[:keff], res[0][1][:keff])
     if tol > 0:
         assert res[0][2] < k
+
+
+def test_svd_general_ill_conditioned_uses_qr_preconditioning(ops):
+    """A dense matrix with nearly parallel rows and condition 1e14 (not a triangular factor): the plain Jacobi run hits its
+    sweep cap, ops.svd_trunc then preconditions with two QRs.  Values against LAPACK, orthogonality, reconstruction, the
+    reference's sign gauge, and svdvals on the same input."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    n = 512
+    U0, _ = torch.linalg.qr(torch.randn((n, n), dtype=torch.float64, device='cuda', generator=g))
+    S0 = torch.logspace(0, -14, n, dtype=torch.float64, device='cuda')
+    C = (U0 * S0) @ torch.randn((n, n), dtype=torch.float64, device='cuda', generator=g)
+    U, S, Vt, keep, disc, info = ops.svd_trunc(C, n, 1e-17)
+    Sref = torch.linalg.svdvals(C.cpu()).cuda()
+    assert keep == int((Sref > Sref[0] * 2.220446049250313e-16).sum()) or abs(keep - n) <= 2
+    assert float((S - Sref[:keep]).abs().max()) < 1e-13 * float(Sref[0])
+    I = torch.eye(keep, dtype=torch.float64, device='cuda')
+    assert float((ops.mm(U.t(), U) - I).abs().max()) < 1e-12 and float((ops.mm(Vt, Vt.t()) - I).abs().max()) < 1e-12
+    assert float((ops.mm(U * S, Vt) - C).abs().max()) < 1e-12 * float(Sref[0])
+    flip = (U.min(dim=0).values.abs() > U.max(dim=0).values) & (Vt.min(dim=1).values.abs() > Vt.max(dim=1).values)
+    assert not bool(flip.any())                                   # gauge fixed point (mps.py:35-39)
+    sv = ops.svdvals(C)
+    assert np.abs(sv[:keep] - Sref[:keep].cpu().numpy()).max() < 1e-13 * float(Sref[0])

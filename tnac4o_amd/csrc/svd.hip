@@ -247,7 +247,7 @@ static int64_t svd_layout(int64_t nv, int64_t L, bool vectors, char* base, SvdWs
     // X (nvp x L) and the accumulator P (nvp x nv) share rows of one (nvp x (L + nv)) array, so that one GEMM applies a
     // round's rotations to both
     double* X = (double*)take(nvp * (L + (vectors ? nv : 0)) * 8);
-    double* P = X + L;
+    double* P = X ? X + L : nullptr;        // size queries run the layout with a null base
     double* part = (double*)take(ng * nchunk * 4 * SVD_W * SVD_W * 8);
     double* Js = (double*)take(ng * 4 * SVD_W * SVD_W * 8);
     double* maxoff = (double*)take(nr * ng * 8);

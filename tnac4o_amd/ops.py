@@ -138,9 +138,7 @@ def qr(T, overwrite=False, nb=None):
     return Q, R
 
 
-def svd_trunc(Cm, Dmax, tol):
-    """Truncated SVD of the 2-D view Cm.  Returns (U[:, :keep], S[:keep], Vt[:keep], keep, discarded, info)."""
-    _need_gpu(Cm)
+def _svd_trunc_raw(Cm, Dmax, tol):
     k, n = Cm.shape
     cap = int(min(k, n, Dmax))
     U = torch.empty((k, cap), dtype=torch.float64, device=Cm.device)
@@ -154,13 +152,50 @@ def svd_trunc(Cm, Dmax, tol):
                          U.data_ptr(), U.stride(0), U.stride(1), S.data_ptr(), Vt.data_ptr(), Vt.stride(0), Vt.stride(1),
                          C.byref(keep), C.byref(disc), C.byref(sweeps), C.byref(info), ws.data_ptr(), wsb, _stream()))
     kp = int(keep.value)
-    if info.value != 0:          # the reference's LAPACK path raises LinAlgError when the SVD does not converge (mps.py:31-34)
-        raise TnError('tn_svd_trunc: Jacobi sweeps did not converge on a %d x %d matrix (%d sweeps)' % (k, n, sweeps.value))
     return U[:, :kp], S[:kp], Vt[:kp], kp, float(disc.value), dict(sweeps=sweeps.value, info=info.value)
 
 
-def svdvals(Cm):
-    """Singular values (host numpy array, descending) of the 2-D view Cm."""
+def _sign_gauge_(U, Vt):
+    """The reference's sign convention (mps.py:35-39) on a finished factorisation: flip the pairs (column of U, row of Vt)
+    in which the most negative entry outweighs the most positive one in both."""
+    if U.shape[1] == 0:
+        return
+    flip = (U.min(dim=0).values.abs() > U.max(dim=0).values) & (Vt.min(dim=1).values.abs() > Vt.max(dim=1).values)
+    sg = torch.where(flip, -1.0, 1.0).to(torch.float64)
+    U.mul_(sg[None, :])
+    Vt.mul_(sg[:, None])
+
+
+def svd_trunc(Cm, Dmax, tol):
+    """Truncated SVD of the 2-D view Cm.  Returns (U[:, :keep], S[:keep], Vt[:keep], keep, discarded, info).
+
+    The one-sided Jacobi kernel converges in a handful of sweeps on what the contraction path feeds it (triangular factors
+    of a QR).  On a general ill-conditioned matrix (nearly parallel rows) it can exhaust its sweep cap; then the classical
+    remedy is applied here: factor the tall orientation, A = Q1 R1, R1^T = Q2 R2 (two QRs leave a nearly diagonal
+    triangle), take the Jacobi SVD of R2 and fold the orthogonal factors back.  The reference's LAPACK call raises
+    LinAlgError when it does not converge (mps.py:31-34); this raises TnError if even the preconditioned run fails."""
+    _need_gpu(Cm)
+    out = _svd_trunc_raw(Cm, Dmax, tol)
+    if out[5]['info'] == 0:
+        return out
+    k, n = Cm.shape
+    tall = Cm if k >= n else Cm.t()
+    Q1, R1 = qr(tall)                                     # tall = Q1 R1
+    Q2, R2 = qr(R1.t().contiguous())                      # R1^T = Q2 R2   =>  tall = Q1 R2^T Q2^T
+    U2, S, V2t, kp, disc, info = _svd_trunc_raw(R2, Dmax, tol)     # R2 = U2 S V2t  =>  tall = (Q1 V2) S (Q2 U2)^T
+    if info['info'] != 0:
+        raise TnError('tn_svd_trunc: Jacobi sweeps did not converge on a %d x %d matrix (%d sweeps, after QR preconditioning)'
+                      % (k, n, info['sweeps']))
+    left = mm(Q1, V2t.t())                                # (rows of tall) x keep
+    right = mm(U2.t(), Q2.t())                            # keep x (cols of tall)
+    U, Vt = (left, right) if k >= n else (right.t().contiguous(), left.t().contiguous())
+    _sign_gauge_(U, Vt)
+    info = dict(info, preconditioned=True, first_attempt_sweeps=out[5]['sweeps'])
+    return U, S, Vt, kp, disc, info
+
+
+def svdvals(Cm, _preconditioned=False):
+    """Singular values (host numpy array, descending) of the 2-D view Cm (same fallback as svd_trunc)."""
     _need_gpu(Cm)
     k, n = Cm.shape
     out = np.empty(min(k, n), dtype=np.float64)
@@ -171,7 +206,12 @@ def svdvals(Cm):
     check(L.tn_svdvals(Cm.data_ptr(), Cm.stride(0), Cm.stride(1), k, n, out.ctypes.data_as(C.POINTER(C.c_double)),
                        C.byref(sweeps), C.byref(info), ws.data_ptr(), wsb, _stream()))
     if info.value != 0:
-        raise TnError('tn_svdvals: Jacobi sweeps did not converge on a %d x %d matrix (%d sweeps)' % (k, n, sweeps.value))
+        if _preconditioned:
+            raise TnError('tn_svdvals: Jacobi sweeps did not converge on a %d x %d matrix (%d sweeps, after QR preconditioning)'
+                          % (k, n, sweeps.value))
+        _, R1 = qr(Cm if k >= n else Cm.t())
+        _, R2 = qr(R1.t().contiguous())
+        return svdvals(R2, _preconditioned=True)
     return out
 
 

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Fold the rocprofv3 --pmc summaries of tools/collect_profiles.sh (gpurun_out/prof_r02/) into profiles/r02_pmc_traffic.json:
+HBM-side bytes per launch of our kernels (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, KB -> bytes),
+the whole-call traffic of tn_qr 16384 x 1024 and of tn_svd_trunc 1024 x 1024 against their compulsory bytes, and the raw SQ
+MFMA counters.  Usage: make_pmc_json.py [PROBE_TIMES json string]"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASE = os.path.join(ROOT, 'gpurun_out', 'prof_r02')
+
+
+def load(tag):
+    out = {}
+    with open(os.path.join(BASE, 'pmc_%s_summary.csv' % tag)) as f:
+        for r in csv.DictReader(f):
+            out.setdefault(r['Kernel'], {})[r['Counter']] = (int(r['Dispatches']), float(r['Total']), float(r['MeanPerDispatch']))
+    return out
+
+
+F, W = load('FETCH_SIZE'), load('WRITE_SIZE')
+M1 = load('SQ_INSTS_VALU_MFMA_F64+SQ_VALU_MFMA_BUSY_CYCLES+SQ_BUSY_CYCLES')
+M2 = load('SQ_INSTS_VALU_MFMA_MOPS_F64+SQ_WAVE_CYCLES+SQ_WAIT_INST_LDS')
+times = json.loads(sys.argv[1]) if len(sys.argv) > 1 else {}
+
+
+def bytes_of(k):
+    f = F.get(k, {}).get('FETCH_SIZE', (0, 0, 0))
+    w = W.get(k, {}).get('WRITE_SIZE', (0, 0, 0))
+    return f[0], 2.0 * 1024 * f[1], 1024 * w[1]        # dispatches, fetch bytes (x2), write bytes (totals over the probe)
+
+
+kern = {}
+for k in F:
+    if 'tn::' not in k:
+        continue
+    n, fb, wb = bytes_of(k)
+    kern[k] = {'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
+               'traffic_bytes_per_launch': (fb + wb) / n}
+
+fam = {}
+ts = [k for k in kern if 'tsqr_factor_kernel' in k or 'tsqr_apply_wy_kernel' in k]
+n = sum(kern[k]['dispatches'] for k in ts)
+fb = sum(kern[k]['fetch_bytes_per_launch'] * kern[k]['dispatches'] for k in ts)
+wb = sum(kern[k]['write_bytes_per_launch'] * kern[k]['dispatches'] for k in ts)
+# algorithmic bytes of the TSQR family over one 16384 x 1024 QR: 16 B per panel element per level (read + write), levels shrink 8x
+alg = 0.0
+for p in range(32):
+    rows = 16384 - 32 * p
+    while True:
+        nblk = -(-rows // 256)
+        alg += 2 * 16.0 * rows * 32          # factor + apply of this level
+        if nblk == 1:
+            break
+        rows = nblk * 32
+fam['tsqr_factor/apply_kernel'] = {'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
+                                   'traffic_bytes_per_launch': (fb + wb) / n, 'algorithmic_bytes_per_launch': alg / n,
+                                   'traffic_over_algorithmic': (fb + wb) / alg}
+for name, pat in (('eig_small_kernel', 'eig_small_kernel'), ('absorb_kernel', 'absorb_mfma_kernel')):
+    ks = [k for k in kern if pat in k]
+    if ks:
+        k = ks[0]
+        fam[name] = dict(kern[k])
+
+# whole-call traffic: tn_qr 16384 x 1024 = every kernel of the QR (the probe runs exactly one such QR under the counters;
+# gemm<128,128,true,false> also contains the 3 plain 16384x1024x1024 products of the probe, which are subtracted)
+qr_names = ['tsqr_factor_kernel', 'tsqr_apply_wy_kernel', 'lu_reconstruct_kernel', 'rows_times_small3_mfma_kernel', 'diag_qr_kernel',
+            'assemble_R_kernel', 'init_Q_kernel', 'splitk_reduce_kernel', 'gemm_kernel<32, 128, false, false, false>',
+            'gemm_kernel<128, 32, true, false, false>']
+qr_bytes = 0.0
+for k in kern:
+    if any(q in k for q in qr_names):
+        qr_bytes += kern[k]['traffic_bytes_per_launch'] * kern[k]['dispatches']
+g = [k for k in kern if 'gemm_kernel<128, 128, true, false, false>' in k]
+plain = 8.0 * (16384 * 1024 * 2 + 1024 * 1024)                  # one 16384x1024x1024 product, compulsory
+if g:
+    tot = kern[g[0]]['traffic_bytes_per_launch'] * kern[g[0]]['dispatches']
+    qr_bytes += max(0.0, tot - 3 * 1.94 * plain)                # the 3 plain products at their measured 1.94x (round 1)
+m, nn = 16384, 1024
+qr_comp = 8.0 * (2 * m * nn + nn * nn)
+whole = {'tn_qr_16384x1024': {'hbm_bytes': qr_bytes, 'compulsory_bytes': qr_comp, 'traffic_over_compulsory': qr_bytes / qr_comp,
+                              'ms_unprofiled': times.get('qr_16384x1024_ms')}}
+svd_names = ['gemm_kernel<64, 64, false, false, true>', 'gemm_kernel<64, 64, true, true, true>', 'eig_small_kernel', 'svd_init_kernel',
+             'svd_gather_kernel', 'vec_norm2_kernel']
+svd_bytes = sum(kern[k]['traffic_bytes_per_launch'] * kern[k]['dispatches'] for k in kern if any(q in k for q in svd_names))
+svd_comp = 8.0 * (2 * 320 * 1024 + 320 * 320 + 320)
+svd = {'hbm_bytes': svd_bytes, 'compulsory_bytes': svd_comp, 'traffic_over_compulsory': svd_bytes / svd_comp,
+       'ms_unprofiled': times.get('svd_trunc_320x1024_ms'), 'sweeps': times.get('svd_sweeps')}
+if times.get('svd_trunc_320x1024_ms'):
+    svd['GBps'] = svd_bytes / (times['svd_trunc_320x1024_ms'] * 1e-3) / 1e9
+    svd['frac_of_hbm_peak'] = svd['GBps'] / 8000.0
+whole['tn_svd_trunc_320x1024'] = svd
+
+mfma = {}
+for k in kern:
+    a, b = M1.get(k, {}), M2.get(k, {})
+    if a.get('SQ_INSTS_VALU_MFMA_F64', (0, 0, 0))[1] > 0:
+        mfma[k] = {'SQ_INSTS_VALU_MFMA_F64_per_launch': a['SQ_INSTS_VALU_MFMA_F64'][2],
+                   'SQ_VALU_MFMA_BUSY_CYCLES_per_launch': a['SQ_VALU_MFMA_BUSY_CYCLES'][2],
+                   'SQ_BUSY_CYCLES_per_launch': a['SQ_BUSY_CYCLES'][2],
+                   'SQ_INSTS_VALU_MFMA_MOPS_F64_per_launch': b.get('SQ_INSTS_VALU_MFMA_MOPS_F64', (0, 0, 0))[2],
+                   'SQ_WAVE_CYCLES_per_launch': b.get('SQ_WAVE_CYCLES', (0, 0, 0))[2],
+                   'SQ_WAIT_INST_LDS_per_launch': b.get('SQ_WAIT_INST_LDS', (0, 0, 0))[2],
+                   'mfma_busy_over_wave_cycles': a['SQ_VALU_MFMA_BUSY_CYCLES'][2] / max(1.0, b.get('SQ_WAVE_CYCLES', (0, 0, 1))[2])}
+out = {'source': 'rocprofv3 --pmc (separate passes: FETCH_SIZE; WRITE_SIZE; SQ MFMA counters) over tools/pmc_probe.py on MI355X, '
+                 'round 2; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md); KB -> bytes',
+       'shapes': 'tn_qr 16384 x 1024 (nb=32, 32 panels x 3 TSQR levels), tn_svd_trunc 320 x 1024 (leading rows of the triangular factor of a graded rank-300 matrix), tn_absorb bulk '
+                 'site, tn_gemm 16384 x 1024 x 1024',
+       'families': fam, 'kernels': kern, 'whole_call': whole, 'svd_step': svd,
+       'mfma_counters': {'file': 'profiles/r02_pmc_traffic.json (mfma_counters.kernels)', 'kernels': mfma,
+                         'note': 'raw SQ counters per launch; the derived MfmaUtil of rocprofv3 falls back to gfx94x formulas on '
+                                 'gfx950, so only ratios of raw counters are quoted'}}
+json.dump(out, open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json'), 'w'), indent=1)
+print(json.dumps({'families': fam, 'whole_call': whole}, indent=1))

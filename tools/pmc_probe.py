@@ -1,8 +1,10 @@
-"""Tiny workload for PMC collection: absorb at the bulk shape, one large GEMM, one QR of an absorbed-bulk-site shape
-(16384 x 1024, nb = 32: tsqr_factor / tsqr_apply / lu_reconstruct / rows_times_small3 / trailing GEMMs) and one
-truncated SVD (1024 x 1024: eig_small + pair GEMMs).  Run under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
-separate passes (tools/pmc_summary.py aggregates the counter CSV per kernel)."""
-import os, sys
+"""Tiny workload for PMC collection: absorb at the bulk shape (x5), one large GEMM (x3), ONE QR of an absorbed-bulk-site shape
+(16384 x 1024, nb = 32: tsqr_factor / tsqr_apply / lu_reconstruct / rows_times_small3 / trailing GEMMs) and ONE truncated SVD
+of a centre matrix as the sweep produces them (the leading 320 rows of the triangular factor of a graded rank-300 matrix,
+i.e. what the rank-revealing QR of a truncating pass hands over: eig_small + pair GEMMs).  Inputs are prepared with torch
+(rocSOLVER / rocBLAS kernels, not counted).  Run under rocprofv3 --pmc in separate passes (tools/collect_profiles.sh);
+tools/pmc_summary.py aggregates the counter CSV per kernel.  Prints the un-profiled timings of the QR and the SVD."""
+import json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import torch
 from tnac4o_amd import ops
@@ -13,11 +15,22 @@ for _ in range(5):
 X = torch.randn(16384, 1024, dtype=torch.float64, device='cuda'); Y = torch.randn(1024, 1024, dtype=torch.float64, device='cuda')
 for _ in range(3):
     Z = ops.mm(X, Y)
-Q, Rr = ops.qr(X.clone())
-# graded spectrum like a centre matrix of the sweep
-U0, _ = torch.linalg.qr(torch.randn(1024, 1024, dtype=torch.float64, device='cuda'))
-S0 = torch.logspace(0, -14, 1024, dtype=torch.float64, device='cuda')
-C = (U0 * S0) @ Y
-out = ops.svd_trunc(C, 256, 1e-16)
+k = 1024
+Q = torch.empty((16384, k), dtype=torch.float64, device='cuda'); Rr = torch.empty((k, 1024), dtype=torch.float64, device='cuda')
+Xq = X.clone()
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+ops.qr_into(Xq, Q, Rr, overwrite=True)
+torch.cuda.synchronize()
+t_qr = time.perf_counter() - t0
+G0 = torch.randn(4096, 300, dtype=torch.float64, device='cuda') * (10.0 ** (-torch.arange(300, dtype=torch.float64, device='cuda') / 20.0))
+_, Rfull = torch.linalg.qr(G0 @ torch.randn(300, 1024, dtype=torch.float64, device='cuda'))
+C = Rfull[:320].contiguous()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+out = ops.svd_trunc(C, 256, 1e-17)
+torch.cuda.synchronize()
+t_svd = time.perf_counter() - t0
 print('done', float(T.sum()), float(Z.sum()), float(Rr.abs().sum()), out[1][:2])
+print('PROBE_TIMES ' + json.dumps({'svd_trunc_320x1024_ms': 1e3 * t_svd, 'svd_sweeps': out[5]['sweeps'], 'svd_keep': out[3],
+                                   'svd_preconditioned': bool(out[5].get('preconditioned')), 'qr_16384x1024_ms': 1e3 * t_qr}))
