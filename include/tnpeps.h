@@ -41,9 +41,12 @@ int64_t tn_gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch);
 
 /* ---- K1: MPO.MPS absorption of one site.  Replaces MPS.apply_mpo (mps.py:353-359) -> _mps_HA (:753-763).
  * A: (Dl, pold, Dr) C-order.  W: (ba, po, bb, pi) C-order, legs (left, out, right, in).
- * hconj=1: out (Dl*ba, pi, Dr*bb), MPS index major;  hconj=0: out (ba*Dl, po, bb*Dr), MPO index major. */
+ * hconj=1: out (Dl*ba, pi, Dr*bb), MPS index major;  hconj=0: out (ba*Dl, po, bb*Dr), MPO index major.
+ * batch >= 1 equally shaped sites in one launch (item i at A + i*bsA, W + i*bsW, out + i*bsOut; a stride of 0 shares the
+ * operand between the items, e.g. one MPO site absorbed into the same site of several boundary MPS). */
 int tn_absorb(const double* A, const double* W, double* out, int64_t Dl, int64_t pold, int64_t Dr, int64_t ba,
-              int64_t po, int64_t bb, int64_t pi, int hconj, void* stream);
+              int64_t po, int64_t bb, int64_t pi, int hconj, int64_t batch, int64_t bsA, int64_t bsW, int64_t bsOut,
+              void* stream);
 
 /* ---- K3: economic QR, diag(R) >= 0.  Replaces mps.qr (mps.py:43-59) as used by _mps_decompose_AC/CA (:772-800).
  * A (m x n) is DESTROYED.  Q: m x min(m,n), R: min(m,n) x n.  nb in {32, 64} is the panel width.
@@ -61,6 +64,14 @@ int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, in
           int64_t rrs, int64_t rcs, int nb, double rank_tol, int64_t* keff_host, void* ws, int64_t ws_bytes, void* stream,
           void* aux_stream);
 int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb);
+/* Strided batch of `batch` equally shaped QR problems (the rotations of examples/e06:97-109 at one site): item i
+ * at A + i*bsA, Q + i*bsQ, R + i*bsR, keff_host[i].  ws_bytes >= batch * roundup(tn_qr_ws_bytes(m,n,nb), 256).  A factorisation
+ * is a chain of latency-bound single-workgroup kernels, so the items are made CONCURRENT rather than fused: item i is enqueued on
+ * side_streams[i % nside] (hipStream_t owned by the caller, nside <= 8), forked from and joined back into `stream` with events;
+ * nside = 0 runs them one after the other on `stream`.  Per-item results are bit-identical to tn_qr. */
+int tn_qr_batched(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs, int64_t qcs, double* R,
+                  int64_t rrs, int64_t rcs, int nb, double rank_tol, int64_t* keff_host, int64_t batch, int64_t bsA, int64_t bsQ,
+                  int64_t bsR, void* ws, int64_t ws_bytes, void* stream, void* const* side_streams, int nside);
 
 /* ---- K4: truncated SVD of a centre matrix.  Replaces mps.svd (mps.py:24-40, sign gauge included) +
  * _mps_truncateC (:802-811): keep = min(#(S > S0*max(eps,tol)), Dmax), discarded = sqrt(sum S[keep:]^2)/S0.
@@ -75,6 +86,15 @@ int tn_svd_trunc(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n
 int tn_svdvals(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* S_host, int* sweeps_host,
                int* info_host, void* ws, int64_t ws_bytes, void* stream);
 int64_t tn_svd_ws_bytes(int64_t k, int64_t n, int vectors);
+/* Strided batches of the two SVD entry points (item i at C + i*bsC, U + i*bsU, S + i*bsS, Vt + i*bsV; the *_host outputs are
+ * arrays of `batch` entries, S_host holds batch * min(k,n) values).  Ranks and convergence are read back per item, so the items
+ * are issued one after the other and share the workspace of a single problem. */
+int tn_svd_trunc_batched(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol, double* U,
+                         int64_t urs, int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_host,
+                         double* discarded_host, int* sweeps_host, int* info_host, int64_t batch, int64_t bsC, int64_t bsU,
+                         int64_t bsS, int64_t bsV, void* ws, int64_t ws_bytes, void* stream);
+int tn_svdvals_batched(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* S_host, int* sweeps_host,
+                       int* info_host, int64_t batch, int64_t bsC, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- K6: out2[0] = 2^floor(log2 max|x|), out2[1] = 1/out2[0] (device).  Replaces mps.nfactor (mps.py:76-85).
  * slot8: 8 bytes of device scratch. */

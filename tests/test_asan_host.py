@@ -31,7 +31,11 @@ i64 = C.c_int64(0); f64 = C.c_double(0); i32 = C.c_int(0)
 assert L.tn_version() == _lib.ABI_VERSION
 expect_neg(L.tn_gemm(-1, 4, 4, 1.0, P, 4, 1, P, 4, 1, 0.0, P, 4, 1, 1, 0, 0, 0, None, 0, None), 'tn_gemm negative dim')
 expect_neg(L.tn_gemm(4, 4, 4, 1.0, None, 4, 1, P, 4, 1, 0.0, P, 4, 1, 1, 0, 0, 0, None, 0, None), 'tn_gemm null')
-expect_neg(L.tn_absorb(None, P, P, 1, 1, 1, 1, 1, 1, 1, 0, None), 'tn_absorb null')
+expect_neg(L.tn_absorb(None, P, P, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, 0, 0, None), 'tn_absorb null')
+expect_neg(L.tn_absorb(P, P, P, 1, 1, 1, 1, 1, 1, 1, 0, -2, 0, 0, 0, None), 'tn_absorb batch')
+expect_neg(L.tn_qr_batched(P, 4, 1, 8, 4, P, 4, 1, P, 4, 1, 32, 0.0, None, 3, 32, 32, 16, P, 16, None, None, 0), 'tn_qr_batched ws')
+expect_neg(L.tn_qr_batched(P, 4, 1, 8, 4, P, 4, 1, P, 4, 1, 32, 0.0, None, 3, 32, 32, 16, P, 1 << 24, None, None, 9), 'tn_qr_batched sides')
+expect_neg(L.tn_svd_trunc_batched(P, 4, 1, 4, 4, 4, 0.0, P, 4, 1, P, P, 4, 1, None, None, None, None, 2, 16, 16, 4, 16, P, 1 << 20, None), 'tn_svd_trunc_batched keep')
 expect_neg(L.tn_qr(P, 4, 1, 0, 4, P, 4, 1, P, 4, 1, 32, 0.0, None, P, 1 << 20, None, None), 'tn_qr empty')
 expect_neg(L.tn_qr(P, 4, 1, 8, 4, P, 4, 1, P, 4, 1, 48, 0.0, None, P, 1 << 20, None, None), 'tn_qr bad nb')
 expect_neg(L.tn_qr(P, 4, 1, 8, 4, P, 4, 1, P, 4, 1, 32, 0.0, None, P, 16, None, None), 'tn_qr small ws')

@@ -453,3 +453,50 @@ def test_svd_general_ill_conditioned_uses_qr_preconditioning(ops):
     assert not bool(flip.any())                                   # gauge fixed point (mps.py:35-39)
     sv = ops.svdvals(C)
     assert np.abs(sv[:keep] - Sref[:keep].cpu().numpy()).max() < 1e-13 * float(Sref[0])
+
+
+# ------------------------------------------------------------------------------------------------ strided batches
+@pytest.mark.parametrize('hconj', [True, False])
+def test_absorb_batched_matches_single_calls(ops, hconj):
+    """tn_absorb with batch = 4 (the same site of the 4 rotations' boundary MPS) in one launch: bit-identical to 4 calls, for
+    a per-item MPO site and for one shared MPO site (stride 0), on the MFMA bulk shape and on a ragged VALU shape."""
+    for (Dl, p, Dr, ba, bb) in [(64, 16, 64, 16, 16), (5, 3, 7, 2, 3)]:
+        g = torch.Generator(device='cuda').manual_seed(Dl + p)
+        A = torch.randn((4, Dl, p, Dr), dtype=torch.float64, device='cuda', generator=g)
+        for bw in (4, 1):
+            W = torch.randn((bw, ba, p, bb, p), dtype=torch.float64, device='cuda', generator=g)
+            out = ops.absorb_batched(A, W, hconj)
+            for i in range(4):
+                assert torch.equal(out[i], ops.absorb(A[i], W[i if bw > 1 else 0], hconj))
+
+
+@pytest.mark.parametrize('m,n,nside', [(4096, 256, 4), (1024, 64, 2), (16384, 1024, 4), (300, 40, 0)])
+def test_qr_batched_concurrent_items_bit_identical(ops, m, n, nside):
+    """tn_qr_batched: 4 independent QRs whose kernel chains interleave on side streams (forked from and joined into the
+    caller's stream inside the call, no host threads) give exactly the factors of 4 separate tn_qr calls."""
+    g = torch.Generator(device='cuda').manual_seed(m + n)
+    T = torch.randn((4, m, n), dtype=torch.float64, device='cuda', generator=g) * \
+        torch.exp(-20.0 * torch.rand((4, 1, n), dtype=torch.float64, device='cuda', generator=g))
+    ref = [ops.qr(T[i]) for i in range(4)]
+    sides = [torch.cuda.Stream() for _ in range(nside)]
+    Q, R, keff = ops.qr_batched(T.clone(), side_streams=sides)
+    after = Q.sum() + R.sum()                      # consumer on the caller's stream: must see the joined results
+    torch.cuda.synchronize()
+    assert keff == [min(m, n)] * 4 and bool(torch.isfinite(after))
+    for i in range(4):
+        assert torch.equal(Q[i], ref[i][0]) and torch.equal(R[i], ref[i][1])
+
+
+def test_svd_trunc_batched_matches_single_calls(ops):
+    g = torch.Generator(device='cuda').manual_seed(9)
+    Rs = []
+    for i in range(3):
+        A = torch.randn((512, 96), dtype=torch.float64, device='cuda', generator=g) * \
+            (10.0 ** (-torch.arange(96, dtype=torch.float64, device='cuda') / (6.0 + i)))
+        Rs.append(ops.qr(A @ torch.randn((96, 128), dtype=torch.float64, device='cuda', generator=g))[1])
+    Cm = torch.stack(Rs)
+    out = ops.svd_trunc_batched(Cm, 64, 1e-17)
+    for i in range(3):
+        U, S, Vt, keep, disc, _ = ops.svd_trunc(Cm[i], 64, 1e-17)
+        assert out[i][3] == keep and out[i][4] == disc
+        assert torch.equal(out[i][0], U) and torch.equal(out[i][1], S) and torch.equal(out[i][2], Vt)

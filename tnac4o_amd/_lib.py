@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libtnpeps.so')
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['api.hip', 'gemm_f64.hip', 'small.hip', 'qr.hip', 'svd.hip', 'absorb.hip', 'misc.hip', 'beam.hip', 'prof.hip', 'tsqr.hip', 'peps.hip', 'env.hip']
+SOURCES = ['api.hip', 'gemm_f64.hip', 'small.hip', 'qr.hip', 'svd.hip', 'absorb.hip', 'misc.hip', 'beam.hip', 'prof.hip', 'tsqr.hip', 'peps.hip', 'env.hip', 'batch.hip']
 
 _i64, _f64, _int, _ptr = C.c_int64, C.c_double, C.c_int, C.c_void_p
 
@@ -19,15 +19,21 @@ SIGNATURES = {
     'tn_gemm': (_int, [_i64, _i64, _i64, _f64, _ptr, _i64, _i64, _ptr, _i64, _i64, _f64, _ptr, _i64, _i64,
                        _i64, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     'tn_gemm_ws_bytes': (_i64, [_i64, _i64, _i64, _i64]),
-    'tn_absorb': (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _ptr]),
+    'tn_absorb': (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _i64, _i64, _i64, _i64, _ptr]),
     'tn_qr': (_int, [_ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _i64, _i64, _int, _f64, C.POINTER(_i64), _ptr, _i64,
               _ptr, _ptr]),
     'tn_qr_ws_bytes': (_i64, [_i64, _i64, _int]),
+    'tn_qr_batched': (_int, [_ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _i64, _i64, _int, _f64, C.POINTER(_i64), _i64, _i64, _i64,
+                      _i64, _ptr, _i64, _ptr, C.POINTER(_ptr), _int]),
     'tn_svd_trunc': (_int, [_ptr, _i64, _i64, _i64, _i64, _i64, _f64, _ptr, _i64, _i64, _ptr, _ptr, _i64, _i64,
                             C.POINTER(_i64), C.POINTER(_f64), C.POINTER(_int), C.POINTER(_int), _ptr, _i64, _ptr]),
     'tn_svdvals': (_int, [_ptr, _i64, _i64, _i64, _i64, C.POINTER(_f64), C.POINTER(_int), C.POINTER(_int), _ptr, _i64,
                           _ptr]),
     'tn_svd_ws_bytes': (_i64, [_i64, _i64, _int]),
+    'tn_svd_trunc_batched': (_int, [_ptr, _i64, _i64, _i64, _i64, _i64, _f64, _ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, C.POINTER(_i64),
+                             C.POINTER(_f64), C.POINTER(_int), C.POINTER(_int), _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr]),
+    'tn_svdvals_batched': (_int, [_ptr, _i64, _i64, _i64, _i64, C.POINTER(_f64), C.POINTER(_int), C.POINTER(_int), _i64, _i64, _ptr, _i64,
+                           _ptr]),
     'tn_nfactor': (_int, [_ptr, _i64, _ptr, _ptr, _ptr]),
     'tn_scale_by': (_int, [_ptr, _i64, _ptr, _ptr]),
     'tn_normalize_pow2': (_int, [_ptr, _i64, _ptr, _ptr, _i64, _ptr]),

@@ -13,10 +13,14 @@
 namespace tn {
 
 template <bool HCONJ>
-__global__ __launch_bounds__(256) void absorb_kernel(const double* __restrict__ A, const double* __restrict__ W,
-                                                     double* __restrict__ out, int Dl, int pold, int Dr, int ba, int po,
-                                                     int bb, int pi) {
+__global__ __launch_bounds__(256) void absorb_kernel(const double* __restrict__ A_, const double* __restrict__ W_,
+                                                     double* __restrict__ out_, int Dl, int pold, int Dr, int ba, int po,
+                                                     int bb, int pi, int64_t bsA, int64_t bsW, int64_t bsO) {
     extern __shared__ double lds[];
+    // blockIdx.y = item of a strided batch of equally shaped sites
+    const double* __restrict__ A = A_ + (int64_t)blockIdx.y * bsA;
+    const double* __restrict__ W = W_ + (int64_t)blockIdx.y * bsW;
+    double* __restrict__ out = out_ + (int64_t)blockIdx.y * bsO;
     // contracted / surviving physical legs of W
     const int pc = HCONJ ? po : pi;        // == pold
     const int pnew = HCONJ ? pi : po;
@@ -72,10 +76,13 @@ __global__ __launch_bounds__(256) void absorb_kernel(const double* __restrict__ 
 typedef double d4a __attribute__((ext_vector_type(4)));
 
 template <bool HCONJ, int TS, int TF, int KS>   // slow tiles, fast tiles, k-steps (pc / 4)
-__global__ __launch_bounds__(256) void absorb_mfma_kernel(const double* __restrict__ A, const double* __restrict__ W,
-                                                          double* __restrict__ out, int Dl, int pold, int Dr, int ba, int po,
-                                                          int bb, int pi) {
+__global__ __launch_bounds__(256) void absorb_mfma_kernel(const double* __restrict__ A_, const double* __restrict__ W_,
+                                                          double* __restrict__ out_, int Dl, int pold, int Dr, int ba, int po,
+                                                          int bb, int pi, int64_t bsA, int64_t bsW, int64_t bsO) {
     extern __shared__ double lds[];
+    const double* __restrict__ A = A_ + (int64_t)blockIdx.y * bsA;
+    const double* __restrict__ W = W_ + (int64_t)blockIdx.y * bsW;
+    double* __restrict__ out = out_ + (int64_t)blockIdx.y * bsO;
     const int pc = pold, pnew = HCONJ ? pi : po;
     double* sA = lds;                      // [pc][Dr]
     double* sW = lds + (int64_t)pc * Dr;   // [pc][pnew][bb]
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(256) void absorb_mfma_kernel(const double* __restri
 
 template <bool HCONJ>
 static bool launch_absorb_mfma(hipStream_t st, dim3 grid, size_t lds, const double* A, const double* W, double* out, int Dl, int pold,
-                               int Dr, int ba, int po, int bb, int pi) {
+                               int Dr, int ba, int po, int bb, int pi, int64_t bsA, int64_t bsW, int64_t bsO) {
     const int slow = HCONJ ? Dr : bb, fast = HCONJ ? bb : Dr;
     if (pold % 4 || slow % 16 || fast % 16) return false;
     const int ts = slow / 16, tf = fast / 16, ks = pold / 4;
@@ -139,7 +146,7 @@ static bool launch_absorb_mfma(hipStream_t st, dim3 grid, size_t lds, const doub
             (void)hipFuncSetAttribute((const void*)absorb_mfma_kernel<HCONJ, TS_, TF_, KS_>,                             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
         hipLaunchKernelGGL((absorb_mfma_kernel<HCONJ, TS_, TF_, KS_>), grid, dim3(256), lds, st, A, W, out, Dl, pold, Dr, ba,  \
-                           po, bb, pi);                                                                                   \
+                           po, bb, pi, bsA, bsW, bsO);                                                                    \
         return true;                                                                                                      \
     }
     // (slow tiles, fast tiles, k steps) of the configurations on the benchmark path: chi in {16,32,64,128}, b = p in {8,16}
@@ -150,34 +157,36 @@ static bool launch_absorb_mfma(hipStream_t st, dim3 grid, size_t lds, const doub
 }
 
 int absorb(hipStream_t st, const double* A, const double* W, double* out, int64_t Dl, int64_t pold, int64_t Dr, int64_t ba,
-           int64_t po, int64_t bb, int64_t pi, int hconj) {
+           int64_t po, int64_t bb, int64_t pi, int hconj, int64_t batch, int64_t bsA, int64_t bsW, int64_t bsO) {
+    if (batch == 0) return 0;
+    TN_CHECK_ARG(batch >= 1 && batch <= 65535, "batch must be in 1..65535");
     TN_CHECK_ARG(Dl >= 1 && pold >= 1 && Dr >= 1 && ba >= 1 && po >= 1 && bb >= 1 && pi >= 1, "non-positive dimension");
     TN_CHECK_ARG(pold == (hconj ? po : pi), "MPS physical leg does not match the contracted MPO leg");
     const int64_t pnew = hconj ? pi : po;
     const int64_t lds = (pold * Dr + pold * pnew * bb) * 8;
     TN_CHECK_ARG(lds <= 160 * 1024, "site too large for the LDS-staged absorb kernel");
     TN_CHECK_ARG(Dl * ba < 2147483647LL, "too many output slabs");
-    dim3 grid((unsigned)(Dl * ba));
+    dim3 grid((unsigned)(Dl * ba), (unsigned)batch);
     prof_begin(st, PROF_ABSORB);
     const bool done = hconj ? launch_absorb_mfma<true>(st, grid, (size_t)lds, A, W, out, (int)Dl, (int)pold, (int)Dr, (int)ba, (int)po,
-                                                       (int)bb, (int)pi)
+                                                       (int)bb, (int)pi, bsA, bsW, bsO)
                             : launch_absorb_mfma<false>(st, grid, (size_t)lds, A, W, out, (int)Dl, (int)pold, (int)Dr, (int)ba, (int)po,
-                                                        (int)bb, (int)pi);
+                                                        (int)bb, (int)pi, bsA, bsW, bsO);
     if (done) {
         // fall through to the bookkeeping below
     } else if (hconj) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)absorb_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((absorb_kernel<true>), grid, dim3(256), (size_t)lds, st, A, W, out, (int)Dl, (int)pold, (int)Dr,
-                           (int)ba, (int)po, (int)bb, (int)pi);
+                           (int)ba, (int)po, (int)bb, (int)pi, bsA, bsW, bsO);
     } else {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)absorb_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((absorb_kernel<false>), grid, dim3(256), (size_t)lds, st, A, W, out, (int)Dl, (int)pold, (int)Dr,
-                           (int)ba, (int)po, (int)bb, (int)pi);
+                           (int)ba, (int)po, (int)bb, (int)pi, bsA, bsW, bsO);
     }
     TN_CHECK_LAUNCH("absorb_kernel");
     {   // as a GEMM (Dl Dr) x (ba bb pnew) x pold: 2MNK flops, 8(MK + KN + MN) bytes
         const double Mg = (double)Dl * Dr, Ng = (double)ba * bb * pnew, Kg = (double)pold;
-        prof_end(st, PROF_ABSORB, 2.0 * Mg * Ng * Kg, 8.0 * (Mg * Kg + Kg * Ng + Mg * Ng));
+        prof_end(st, PROF_ABSORB, 2.0 * Mg * Ng * Kg * batch, 8.0 * (Mg * Kg + Kg * Ng + Mg * Ng) * batch);
     }
     return 0;
 }

@@ -17,7 +17,8 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 // implemented in the other translation units
-int absorb(hipStream_t, const double*, const double*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
+int absorb(hipStream_t, const double*, const double*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int64_t,
+           int64_t, int64_t, int64_t);
 int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
               void*, int64_t, double, int64_t*, hipStream_t);
 int64_t qr_ws_bytes(int64_t, int64_t, int);
@@ -40,6 +41,11 @@ int env_rr_batched(hipStream_t, const double*, const double*, const double*, con
                    int64_t, int64_t, int64_t, int64_t, double*);
 int env_rl_batched(hipStream_t, const double*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, double*);
 int balance(hipStream_t, const double*, int64_t, int64_t, int64_t, double, double*, int*);
+int qr_batched(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int, double,
+               int64_t*, int64_t, int64_t, int64_t, int64_t, void*, int64_t, void* const*, int);
+int svd_trunc_batched(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double, double*, int64_t, int64_t, double*,
+                      double*, int64_t, int64_t, int64_t*, double*, int*, int*, int64_t, int64_t, int64_t, int64_t, int64_t, void*, int64_t);
+int svd_vals_batched(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, double*, int*, int*, int64_t, int64_t, void*, int64_t);
 
 }  // namespace tn
 
@@ -102,10 +108,11 @@ int tn_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int6
 int64_t tn_gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch) { return gemm_ws_bytes(M, N, K, batch); }
 
 int tn_absorb(const double* A, const double* W, double* out, int64_t Dl, int64_t pold, int64_t Dr, int64_t ba, int64_t po,
-              int64_t bb, int64_t pi, int hconj, void* stream) {
-    TN_CHECK_ARG(A && W && out, "null operand");
+              int64_t bb, int64_t pi, int hconj, int64_t batch, int64_t bsA, int64_t bsW, int64_t bsOut, void* stream) {
+    TN_CHECK_ARG(batch >= 0, "negative batch");
+    TN_CHECK_ARG(batch == 0 || (A && W && out), "null operand");
     ProfPhase ph(PH_ABSORB);
-    return absorb(ST, A, W, out, Dl, pold, Dr, ba, po, bb, pi, hconj);
+    return absorb(ST, A, W, out, Dl, pold, Dr, ba, po, bb, pi, hconj, batch, bsA, bsW, bsOut);
 }
 
 int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs, int64_t qcs, double* R, int64_t rrs,
@@ -202,6 +209,36 @@ int tn_balance(const double* A, int64_t rs, int64_t cs, int64_t n, double max_sc
                void* stream) {
     TN_CHECK_ARG(A && scale_out, "null operand");
     return balance(ST, A, rs, cs, n, max_scale, scale_out, iters_out);
+}
+
+int tn_qr_batched(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs, int64_t qcs, double* R, int64_t rrs,
+                  int64_t rcs, int nb, double rank_tol, int64_t* keff_host, int64_t batch, int64_t bsA, int64_t bsQ, int64_t bsR, void* ws,
+                  int64_t ws_bytes, void* stream, void* const* side_streams, int nside) {
+    TN_CHECK_ARG(batch >= 0, "negative batch");
+    TN_CHECK_ARG(batch == 0 || (A && Q && R && ws), "null operand");
+    TN_CHECK_ARG(rank_tol >= 0.0 && rank_tol < 1.0, "rank_tol out of range");
+    ProfPhase ph(PH_QR);
+    const double dm = (double)m, dn = (double)(n < m ? n : m);
+    prof_note(PROF_QR_NOMINAL, (double)batch, batch * (4.0 * dm * dn * dn - 4.0 / 3.0 * dn * dn * dn), batch * 8.0 * (2.0 * dm * dn + dn * dn));
+    return qr_batched(ST, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, rank_tol, keff_host, batch, bsA, bsQ, bsR, ws, ws_bytes,
+                      side_streams, nside);
+}
+int tn_svd_trunc_batched(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol, double* U, int64_t urs,
+                         int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_host, double* discarded_host,
+                         int* sweeps_host, int* info_host, int64_t batch, int64_t bsC, int64_t bsU, int64_t bsS, int64_t bsV, void* ws,
+                         int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(batch >= 0, "negative batch");
+    TN_CHECK_ARG(batch == 0 || (C && U && S && Vt && ws && keep_host), "null operand");
+    ProfPhase ph(PH_SVD);
+    return svd_trunc_batched(ST, C, crs, ccs, k, n, Dmax, tol, U, urs, ucs, S, Vt, vrs, vcs, keep_host, discarded_host, sweeps_host,
+                             info_host, batch, bsC, bsU, bsS, bsV, ws, ws_bytes);
+}
+int tn_svdvals_batched(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* S_host, int* sweeps_host, int* info_host,
+                       int64_t batch, int64_t bsC, void* ws, int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(batch >= 0, "negative batch");
+    TN_CHECK_ARG(batch == 0 || (C && S_host && ws), "null operand");
+    ProfPhase ph(PH_SVDVALS);
+    return svd_vals_batched(ST, C, crs, ccs, k, n, S_host, sweeps_host, info_host, batch, bsC, ws, ws_bytes);
 }
 
 }  // extern "C"

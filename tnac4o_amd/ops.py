@@ -100,8 +100,74 @@ def absorb(A, W, hconj):
     ba, po, bb, pi = W.shape
     pnew = pi if hconj else po
     out = torch.empty((Dl * ba, pnew, Dr * bb), dtype=torch.float64, device=A.device)
-    check(lib().tn_absorb(A.data_ptr(), W.data_ptr(), out.data_ptr(), Dl, p, Dr, ba, po, bb, pi, 1 if hconj else 0,
+    check(lib().tn_absorb(A.data_ptr(), W.data_ptr(), out.data_ptr(), Dl, p, Dr, ba, po, bb, pi, 1 if hconj else 0, 1, 0, 0, 0,
                           _stream()))
+    return out
+
+
+def absorb_batched(A, W, hconj):
+    """`batch` equally shaped sites in one launch: A (batch, Dl, p, Dr), W (batch | 1, ba, po, bb, pi) -- one MPO site
+    absorbed into the same site of several boundary MPS when W has a leading 1.  Returns (batch, Dl*ba, pnew, Dr*bb)."""
+    _need_gpu(A)
+    _need_gpu(W)
+    A, W = A.contiguous(), W.contiguous()
+    batch, Dl, p, Dr = A.shape
+    bw, ba, po, bb, pi = W.shape
+    assert bw in (1, batch)
+    pnew = pi if hconj else po
+    out = torch.empty((batch, Dl * ba, pnew, Dr * bb), dtype=torch.float64, device=A.device)
+    check(lib().tn_absorb(A.data_ptr(), W.data_ptr(), out.data_ptr(), Dl, p, Dr, ba, po, bb, pi, 1 if hconj else 0, batch,
+                          A.stride(0), W.stride(0) if bw > 1 else 0, out.stride(0), _stream()))
+    return out
+
+
+def qr_batched(T, side_streams=(), rank_tol=0.0, nb=None):
+    """Economic QR of every T[i] (batch, m, n; contiguous, destroyed) -- tn_qr_batched.  side_streams: torch streams on which
+    the items run concurrently (forked from / joined into the current stream inside the call).  Returns Q (batch, m, k),
+    R (batch, k, n) and the list of revealed ranks."""
+    _need_gpu(T)
+    assert T.is_contiguous() and T.dim() == 3
+    batch, m, n = T.shape
+    k = min(m, n)
+    nb = nb or QR_NB
+    Q = torch.empty((batch, m, k), dtype=torch.float64, device=T.device)
+    R = torch.empty((batch, k, n), dtype=torch.float64, device=T.device)
+    L = lib()
+    wsi = (L.tn_qr_ws_bytes(m, n, nb) + 255) // 256 * 256
+    ws = workspace(wsi * batch, 4)
+    keff = (C.c_int64 * batch)(*([k] * batch))
+    sides = (C.c_void_p * max(1, len(side_streams)))(*[s.cuda_stream for s in side_streams])
+    check(L.tn_qr_batched(T.data_ptr(), T.stride(1), T.stride(2), m, n, Q.data_ptr(), Q.stride(1), Q.stride(2), R.data_ptr(),
+                          R.stride(1), R.stride(2), nb, float(rank_tol), keff, batch, T.stride(0), Q.stride(0), R.stride(0),
+                          ws.data_ptr(), wsi * batch, _stream(), sides, len(side_streams)))
+    return Q, R, [int(x) for x in keff]
+
+
+def svd_trunc_batched(Cm, Dmax, tol):
+    """Truncated SVDs of every Cm[i] (batch, k, n) in one call (tn_svd_trunc_batched).  Returns a list of the per-item tuples
+    ops.svd_trunc returns."""
+    _need_gpu(Cm)
+    assert Cm.dim() == 3
+    batch, k, n = Cm.shape
+    cap = int(min(k, n, Dmax))
+    U = torch.empty((batch, k, cap), dtype=torch.float64, device=Cm.device)
+    S = torch.empty((batch, cap), dtype=torch.float64, device=Cm.device)
+    Vt = torch.empty((batch, cap, n), dtype=torch.float64, device=Cm.device)
+    L = lib()
+    wsb = L.tn_svd_ws_bytes(k, n, 1)
+    ws = workspace(wsb, 0)
+    keep, disc = (C.c_int64 * batch)(), (C.c_double * batch)()
+    sweeps, info = (C.c_int * batch)(), (C.c_int * batch)()
+    check(L.tn_svd_trunc_batched(Cm.data_ptr(), Cm.stride(1), Cm.stride(2), k, n, cap if Dmax >= cap else int(Dmax), float(tol),
+                                 U.data_ptr(), U.stride(1), U.stride(2), S.data_ptr(), Vt.data_ptr(), Vt.stride(1), Vt.stride(2),
+                                 keep, disc, sweeps, info, batch, Cm.stride(0), U.stride(0), S.stride(0), Vt.stride(0),
+                                 ws.data_ptr(), wsb, _stream()))
+    out = []
+    for i in range(batch):
+        if info[i] != 0:
+            raise TnError('tn_svd_trunc_batched: item %d did not converge (%d sweeps)' % (i, sweeps[i]))
+        kp = int(keep[i])
+        out.append((U[i, :, :kp], S[i, :kp], Vt[i, :kp], kp, float(disc[i]), dict(sweeps=sweeps[i], info=info[i])))
     return out
 
 
