@@ -86,6 +86,10 @@ int tn_svd_trunc(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n
 int tn_svdvals(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* S_host, int* sweeps_host,
                int* info_host, void* ws, int64_t ws_bytes, void* stream);
 int64_t tn_svd_ws_bytes(int64_t k, int64_t n, int vectors);
+/* K5 without the read-back, for centre matrices with both dimensions <= 64 (the Schmidt-value checks of the variational sweeps,
+ * mps.py:550-560, whose results are only needed at the end of a sweep): one asynchronous launch; out66_dev (DEVICE) receives 64
+ * values sorted descending (zero padded), then the executed sweeps and a convergence flag (1 = converged) as doubles. */
+int tn_svdvals_async(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* out66_dev, void* stream);
 /* Strided batches of the two SVD entry points (item i at C + i*bsC, U + i*bsU, S + i*bsS, Vt + i*bsV; the *_host outputs are
  * arrays of `batch` entries, S_host holds batch * min(k,n) values).  Ranks and convergence are read back per item, so the items
  * are issued one after the other and share the workspace of a single problem. */

@@ -30,6 +30,7 @@ SIGNATURES = {
     'tn_svdvals': (_int, [_ptr, _i64, _i64, _i64, _i64, C.POINTER(_f64), C.POINTER(_int), C.POINTER(_int), _ptr, _i64,
                           _ptr]),
     'tn_svd_ws_bytes': (_i64, [_i64, _i64, _int]),
+    'tn_svdvals_async': (_int, [_ptr, _i64, _i64, _i64, _i64, _ptr, _ptr]),
     'tn_svd_trunc_batched': (_int, [_ptr, _i64, _i64, _i64, _i64, _i64, _f64, _ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, C.POINTER(_i64),
                              C.POINTER(_f64), C.POINTER(_int), C.POINTER(_int), _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     'tn_svdvals_batched': (_int, [_ptr, _i64, _i64, _i64, _i64, C.POINTER(_f64), C.POINTER(_int), C.POINTER(_int), _i64, _i64, _ptr, _i64,
@@ -87,6 +88,10 @@ def _stale(L):
     return buf.value.decode() != source_hash()
 
 
+# short, non-blocking entry points (see lib())
+SHORT_CALLS = ('tn_gemm', 'tn_gemm_ws_bytes', 'tn_qr_ws_bytes', 'tn_svd_ws_bytes', 'tn_absorb', 'tn_nfactor', 'tn_scale_by',
+               'tn_normalize_pow2', 'tn_scale_phys', 'tn_calc_pn', 'tn_nfactor_batched', 'tn_env_rr_batched', 'tn_env_rl_batched',
+               'tn_balance', 'tn_svdvals_async', 'tn_peps_factor', 'tn_mpo_from_factor', 'tn_last_error')
 _lib = None
 ABI_VERSION = 2          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
 
@@ -107,6 +112,16 @@ def lib():
         if L.tn_version() != ABI_VERSION:
             raise RuntimeError('libtnpeps.so implements C-ABI version %d, this package binds version %d: rebuild the library'
                                % (L.tn_version(), ABI_VERSION))
+        # Entry points that only enqueue a launch or two return within microseconds: they are bound through PyDLL, i.e.
+        # called WITHOUT releasing the GIL.  With 4 chains driven by 4 host threads, releasing and re-taking the GIL around
+        # every 5 us call costs a futex wake-up each time (measured: 0.9 s of "python + GIL" per chain and sweep against
+        # 0.29 s for a single chain, tools/host_overhead.py); the calls that block or enqueue hundreds of launches (tn_qr*,
+        # tn_svd*) keep releasing it.  TN_PYDLL=0 restores plain CDLL for A/B measurements.
+        if os.environ.get('TN_PYDLL', '1') != '0':
+            P = C.PyDLL(LIB_PATH)
+            for name in SHORT_CALLS:
+                setattr(L, name, getattr(P, name))
+            L._pydll = P
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args

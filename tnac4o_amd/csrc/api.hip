@@ -26,6 +26,7 @@ int svd_trunc(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, in
               double*, int64_t, int64_t, int64_t*, double*, int*, int*, void*, int64_t);
 int svd_vals(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, double*, int*, int*, void*, int64_t);
 int64_t svd_ws_bytes(int64_t, int64_t, int);
+int svd_vals_small_async(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, double*);
 int nfactor(hipStream_t, const double*, int64_t, double*, void*);
 int scale_by(hipStream_t, double*, int64_t, const double*);
 int normalize_pow2(hipStream_t, double*, int64_t, double*, void*, int64_t);
@@ -150,6 +151,13 @@ int tn_svdvals(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, 
     return svd_vals(ST, C, crs, ccs, k, n, S_host, sweeps_host, info_host, ws, ws_bytes);
 }
 int64_t tn_svd_ws_bytes(int64_t k, int64_t n, int vectors) { return svd_ws_bytes(k, n, vectors); }
+int tn_svdvals_async(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* out66_dev, void* stream) {
+    TN_CHECK_ARG(C && out66_dev, "null operand");
+    ProfPhase ph(PH_SVDVALS);
+    const double dm = (double)(k > n ? k : n), dn = (double)(k > n ? n : k);
+    prof_note(PROF_SVDVALS_NOMINAL, 1, 4.0 * dm * dn * dn - 4.0 / 3.0 * dn * dn * dn, 8.0 * (dm * dn + dn));
+    return svd_vals_small_async(ST, C, crs, ccs, k, n, out66_dev);
+}
 
 int tn_nfactor(const double* x, int64_t n, double* out2, void* slot8, void* stream) {
     TN_CHECK_ARG(x && out2 && slot8, "null operand");

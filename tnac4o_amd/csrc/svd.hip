@@ -422,6 +422,18 @@ int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t
     return 0;
 }
 
+// Values-only SVD of a centre matrix with both dimensions <= 64, without any read-back: out (DEVICE, 66 doubles) receives the
+// 64 values sorted descending (zero padded), the executed sweeps and the convergence flag.  One launch, asynchronous.
+int svd_vals_small_async(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* out) {
+    TN_CHECK_ARG(k >= 1 && n >= 1 && k <= 64 && n <= 64, "both dimensions must be in 1..64");
+    const bool rows = k <= n;
+    const int64_t nv = rows ? k : n, L = rows ? n : k;
+    const int64_t vs = rows ? crs : ccs, es = rows ? ccs : crs;
+    TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_vals_small_kernel, dim3(1), dim3(256), 0, st, C, vs, es, (int)nv, (int)L, out));
+    TN_CHECK_LAUNCH("svd_vals_small_kernel");
+    return 0;
+}
+
 // Singular values only, sorted descending, min(k,n) of them (deflated ones reported as 0).  hostS: host pointer.
 int svd_vals(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* hostS,
              int* sweeps_out, int* info, void* ws, int64_t ws_bytes) {

@@ -74,6 +74,65 @@ class MPO:
         self.support[n] = 1
 
 
+class _DeferredSchmidt:
+    """The update_S calls of one variational sweep (mps.py:550-560), taken asynchronously and replayed in order at the end.
+
+    add(): the current centre matrix psi.C at bond psi.pC.  Up to 64 x 64 its singular values are computed by one
+    asynchronous launch (tn_svdvals_async) into a row of a device table -- on the side stream paired with the chain's stream
+    when the chain runs on a stream of its own, so that the launch is off the chain's critical path; larger centre matrices
+    go through the synchronous block-Jacobi path at once.  finish(): one device-to-host copy, then exactly the bookkeeping
+    of update_S for every site in the order the reference performs it; returns max dS over the measured (left-to-right)
+    half."""
+
+    def __init__(self, psi):
+        self.psi = psi
+        self.items = []                 # (pC, measure, row index | None, host array | None, centre tensor kept alive)
+        self.table = None
+        self.side = None
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream != 0 and ops.SCHMIDT_SIDE:   # never make the legacy default stream wait on / for others
+            self.side = ops.side_stream()
+        self.cur = cur
+
+    def add(self, measure):
+        psi = self.psi
+        Cm = psi.C
+        if max(Cm.shape) <= 64:
+            if self.table is None:
+                self.table = torch.zeros((2 * psi.L + 2, 66), dtype=torch.float64, device=Cm.device)
+            row = sum(1 for it in self.items if it[2] is not None)
+            if self.side is not None:
+                self.side.wait_stream(self.cur)
+            ops.svdvals_async(Cm, self.table[row], stream=self.side)
+            self.items.append((psi.pC, measure, row, None, Cm))
+        else:
+            self.items.append((psi.pC, measure, None, ops.svdvals(Cm), None))
+
+    def finish(self):
+        psi = self.psi
+        host = None
+        if self.table is not None:
+            if self.side is not None:
+                self.cur.wait_stream(self.side)
+            host = self.table.cpu().numpy()
+        diff = 0.0
+        for pC, measure, row, S, Cm in self.items:
+            if row is not None:
+                k = min(Cm.shape)
+                if host[row, 65] == 0.0 or not np.all(np.isfinite(host[row, :k])):
+                    S = ops.svdvals(Cm)          # not converged in the fused kernel: the full path (raises if that fails too)
+                else:
+                    S = host[row, :k].copy()
+            if psi.S[pC].size != S.size:
+                psi.S[pC] = psi._one_S(S.size)
+            dS = float(np.sqrt(np.sum((psi.S[pC] - S) ** 2)))
+            psi.S[pC] = S
+            if measure:
+                diff = max(diff, dS)
+        self.items = []
+        return diff
+
+
 class MPS:
     """Boundary MPS with an explicit orthogonality centre C at bond pC (mps.py:96-173).
 
@@ -345,7 +404,9 @@ class MPS:
         return dS
 
     def variational_compress(self, phi, tol=None, max_sweeps=1, verbose=False):
-        """mps.py:238-279."""
+        """mps.py:238-279.  The Schmidt spectra that update_S takes at every site (mps.py:550-560) are only consumed at the
+        end of a sweep (convergence test, mps.py:255/270), so they are taken without synchronising -- tn_svdvals_async on a
+        side stream for centre matrices up to 64 x 64 -- and folded in once per sweep (_DeferredSchmidt)."""
         if tol is None:
             tol = self.zero
         overlap = self.setup_RL_mix(phi)
@@ -353,17 +414,18 @@ class MPS:
         while diff > tol:
             if sweeps >= max_sweeps:
                 return overlap
+            pend = _DeferredSchmidt(self)
             for n in range(self.L - 1, 0, -1):
                 self.optimise_site(phi, n)
                 self.orth_right(n)
-                self.update_S()
+                pend.add(measure=False)
                 self.update_RR_mix(phi, n)
-            diff = 0.0
             for n in range(self.L):
                 self.optimise_site(phi, n)
                 self.orth_left(n)
-                diff = max(diff, self.update_S())
+                pend.add(measure=True)
                 self.update_RL_mix(phi, n)
+            diff = pend.finish()
             overlap = self.R[-1]
             sweeps += 1
         return overlap

@@ -11,6 +11,8 @@ from ._lib import lib, check, TnError
 QR_NB = 32
 _ws = {}
 _aux = {}
+SCHMIDT_SIDE = os.environ.get('TN_SCHMIDT_SIDE', '0') == '1'   # deferred Schmidt-value checks on a side stream (off: with 4
+# chains a second stream per chain costs 6-10 % of the step, measured; on the chain's own stream the launch is still asynchronous)
 LOOKAHEAD = os.environ.get('TN_QR_LOOKAHEAD', '0') == '1'      # tn_qr look-ahead on a second stream per chain (off: no gain measured)
 
 
@@ -18,6 +20,17 @@ def register_aux_stream(main, aux):
     """Pair a chain's stream with the side stream tn_qr may use for its look-ahead (parallel.run_concurrent does this for
     the streams it creates, so the mapping of chains to hardware queues is deterministic)."""
     _aux[(main.device.index, main.cuda_stream)] = aux
+
+
+def side_stream():
+    """The side stream paired with the current stream (created on first use): used for work that is off a chain's critical
+    path (deferred Schmidt-value checks, tn_qr's look-ahead when enabled)."""
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream)
+    a = _aux.get(key)
+    if a is None:
+        a = _aux[key] = torch.cuda.Stream()
+    return a
 
 
 def aux_stream():
@@ -279,6 +292,16 @@ def svdvals(Cm, _preconditioned=False):
         _, R2 = qr(R1.t().contiguous())
         return svdvals(R2, _preconditioned=True)
     return out
+
+
+def svdvals_async(Cm, out66, stream=None):
+    """Schmidt values of a centre matrix with both dimensions <= 64 into the device buffer out66 (66 doubles: 64 values
+    sorted descending, sweeps, converged flag) without synchronising (tn_svdvals_async).  `stream`: a torch stream to launch
+    on instead of the current one (the caller orders it after the producer of Cm and keeps Cm alive until it joins)."""
+    _need_gpu(Cm)
+    k, n = Cm.shape
+    st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    check(lib().tn_svdvals_async(Cm.data_ptr(), Cm.stride(0), Cm.stride(1), k, n, out66.data_ptr(), st))
 
 
 def nfactor_dev(T):

@@ -28,10 +28,11 @@ def run_concurrent(fns):
     # whenever an event had been recorded on the legacy default stream; this form held 1.70 s/sweep over 11 calls.
     streams = [torch.cuda.Stream() for _ in range(n)]
     from . import ops
-    if ops.LOOKAHEAD:
-        # side streams for tn_qr's look-ahead, taken right after the chains' own streams so that the pairing with hardware
-        # queues is the same on every call (torch hands out pool streams round-robin, pool stream k sits on hardware queue
-        # k mod 4): chain i's side stream is rotated by AUX_ROT so that it does not share a queue with its own chain
+    # side streams (deferred Schmidt-value checks; tn_qr's look-ahead when enabled), taken right after the chains' own streams
+    # so that the pairing with hardware queues is the same on every call (torch hands out pool streams round-robin, pool
+    # stream k sits on hardware queue k mod 4): chain i's side stream is rotated by TN_AUX_ROT so that it does not share a
+    # queue with its own chain
+    if ops.LOOKAHEAD or ops.SCHMIDT_SIDE:
         import os
         rot = int(os.environ.get('TN_AUX_ROT', '2'))
         side = [torch.cuda.Stream() for _ in range(n)]

@@ -29,6 +29,27 @@ for name in _lib.SIGNATURES:
         continue
     setattr(L, name, wrap(getattr(L, name)))
 
+# second bucket: torch calls made between library calls (allocation, stream queries, small tensor ops)
+tacc = {}
+
+
+def twrap(fn, key):
+    def inner(*a, **k):
+        t0 = time.perf_counter()
+        r = fn(*a, **k)
+        rec = tacc.setdefault((threading.get_ident(), key), [0.0, 0])
+        rec[0] += time.perf_counter() - t0
+        rec[1] += 1
+        return r
+    return inner
+
+
+for mod, name in ((torch, 'empty'), (torch, 'ones'), (torch, 'ones_like'), (torch, 'diag'), (torch, 'zeros'), (torch.cuda, 'current_stream'),
+                  (torch.cuda, 'current_device')):
+    setattr(mod, name, twrap(getattr(mod, name), name))
+for name in ('contiguous', 'clone', 'view', 't', 'reshape', 'item', 'cpu'):
+    setattr(torch.Tensor, name, twrap(getattr(torch.Tensor, name), 'Tensor.' + name))
+
 n = 16
 J = synthetic_chimera(n, n, 20260004)
 kw = dict(graduate_truncation=True, Dmax=64, tolS=1e-16, tolV=1e-10, max_sweeps=20)
@@ -54,8 +75,11 @@ acc.clear()
 tid, wall = run(solvers[0])
 c, k = acc[tid]
 print('single chain : wall %.3f s  in library %.3f s  calls %d  python+gil %.3f s (%.1f us per call)' % (wall, c, k, wall - c, 1e6 * (wall - c) / k))
+print('      torch: ' + '  '.join('%s %.0f ms/%d' % (key[1], 1e3 * v[0], v[1]) for key, v in sorted(tacc.items(), key=lambda kv: -kv[1][0]) if key[0] == tid)[:400])
+tacc.clear()
 for trial in range(2):
     acc.clear()
+    tacc.clear()
     t0 = time.perf_counter()
     res = parallel.run_concurrent([(lambda s=s: run(s)) for s in solvers])
     tot = time.perf_counter() - t0
@@ -63,3 +87,4 @@ for trial in range(2):
     for tid, wall in res:
         c, k = acc[tid]
         print('   chain wall %.3f s  in library %.3f s  calls %d  python+gil %.3f s (%.1f us per call)' % (wall, c, k, wall - c, 1e6 * (wall - c) / k))
+        print('      torch: ' + '  '.join('%s %.0f ms/%d' % (key[1], 1e3 * v[0], v[1]) for key, v in sorted(tacc.items(), key=lambda kv: -kv[1][0]) if key[0] == tid)[:400])
