@@ -156,6 +156,36 @@ int tn_env_rl_batched(const double* T1, const int32_t* par, const int32_t* didx,
 int tn_balance(const double* A, int64_t rs, int64_t cs, int64_t n, double max_scale, double* scale_out, int* iters_out,
                void* stream);
 
+/* ---- site steps of the sweeps as single calls (compositions of the kernels above with their temporaries in `ws`; results are
+ * bit-identical to the separate calls).  They exist for the host: with 4 chains driven by 4 host threads every separate call and
+ * every temporary tensor is a GIL hand-over.  All matrices contiguous, row-major (C order).
+ * tn_site_qr: attach + QR + nfactor of one canonisation step (mps.py:368-380, 532-548, 772-800).
+ *   side 0 (left sweep):  M = C (kc x Dl) . A (Dl, p, Dr), QR of the (kc p) x Dr matrix: Q (kc p x k), R (k x Dr).
+ *   side 1 (right sweep): M = A (Dl, p, Dr) . C (Dr x kc), QR of the transposed (p kc) x Dl view: Q receives Q^T (k x p kc),
+ *                         R receives R^T (Dl x k).        k = min of the two matrix dimensions.
+ *   C == NULL: no attach, A itself is factored and DESTROYED (kc ignored).  rank_tol / keff_host as in tn_qr.
+ *   nf_out2 != NULL: when the factorisation ran to the end the triangular factor is divided by its nfactor and nf_out2 (device)
+ *   = [nf, 1/nf]; *normalised_host tells whether that happened (it does not after an early exit: the caller slices first). */
+int64_t tn_site_qr_ws_bytes(int side, int64_t Dl, int64_t p, int64_t Dr, int64_t kc, int attach);
+int tn_site_qr(int side, double* A, int64_t Dl, int64_t p, int64_t Dr, const double* C, int64_t kc, double* Q, double* R,
+               double rank_tol, int64_t* keff_host, double* nf_out2, int* normalised_host, void* ws, int64_t ws_bytes, void* stream);
+/* out (c, s, c2) = RL (c x a) . A (a, s, a2) . RR (a2 x c2)      (MPS._mps_RAR, mps.py:748-751) */
+int64_t tn_rar_ws_bytes(int64_t c, int64_t a, int64_t s, int64_t a2, int64_t c2);
+int tn_rar(const double* RL, const double* A, const double* RR, int64_t c, int64_t a, int64_t s, int64_t a2, int64_t c2, double* out,
+           void* ws, int64_t ws_bytes, void* stream);
+/* mixed environments (MPS._mps_RL / _mps_RR, mps.py:655-663), A (a, s, a2), Ac (c, s, c2):
+ *   side 0: out (c2 x a2) = sum_{c,s,a} Ac[c,s,c2] R[c,a] A[a,s,a2];   side 1: out (a x c) = sum A[a,s,a2] R[a2,c2] Ac[c,s,c2] */
+int64_t tn_env_mix_ws_bytes(int side, int64_t a, int64_t s, int64_t a2, int64_t c, int64_t c2);
+int tn_env_mix(int side, const double* R, const double* A, const double* Ac, int64_t a, int64_t s, int64_t a2, int64_t c, int64_t c2,
+               double* out, void* ws, int64_t ws_bytes, void* stream);
+/* projectors of a truncation pushed into the neighbouring sites and the diagonal centre (mps.py:579-583):
+ *   Al_new (ml x keep) = Al (ml x k0) . U (k0 x keep, strides urs/ucs);  Ar_new (keep x nr) = Vt (keep x k1, strides vrs/vcs) . Ar (k1 x nr);
+ *   Cdiag (keep x keep) = diag(S). */
+int64_t tn_apply_truncation_ws_bytes(int64_t ml, int64_t k0, int64_t keep, int64_t k1, int64_t nr);
+int tn_apply_truncation(const double* Al, int64_t ml, int64_t k0, const double* U, int64_t urs, int64_t ucs, int64_t keep,
+                        const double* Vt, int64_t vrs, int64_t vcs, const double* Ar, int64_t k1, int64_t nr, const double* S,
+                        double* Al_new, double* Ar_new, double* Cdiag, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- measurement: bracket every launch of the selected kernel families with HIP events on the launch stream.
  * family ids: 0-3 gemm_kernel<128,128> / <128,32> / <32,128> / <64,64> (all operand layouts), 4 splitk_reduce,
  * 5 absorb, 6 gram_partial, 7 eig_small, 8 rows_times_small, 9 small_t_times_vecs, 10 tsqr_factor/apply,

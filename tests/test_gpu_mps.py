@@ -476,3 +476,28 @@ def test_low_energy_spectrum_adjacency_rmf_golden():
         s.decode_low_energy_states(max_dEng=3.1, max_states=100)
         assert len(s.energy) == 26
         _spectrum_same(s, g, 'RMF_e%d_r%d' % (enc, rot), bits=False)
+
+
+@pytest.mark.gpu
+def test_fused_site_steps_bit_identical():
+    """The single-call site steps (tn_site_qr, tn_rar, tn_env_mix, tn_apply_truncation: csrc/site.hip) run the same kernels in
+    the same order as the separate calls they replace: a whole sweep (all four canonisation passes, both variational sweeps,
+    rank-revealing early exits included) must come out bit-identical with and without them."""
+    from tnac4o_amd import ops
+    kw = dict(graduate_truncation=True, Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20)
+    res = []
+    saved = ops.FUSED_SITE
+    try:
+        for fused in (False, True):
+            ops.FUSED_SITE = fused
+            s = gpu_solver(L=512, rot=1)
+            s._setup_rhoT(**kw)
+            res.append(s)
+    finally:
+        ops.FUSED_SITE = saved
+    a, b = res
+    assert [m.D for m in a.rhoT] == [m.D for m in b.rhoT]
+    assert a.rhoT_discarded == b.rhoT_discarded and a.rhoT_overlap == b.rhoT_overlap
+    for x, y in zip(a.rhoT, b.rhoT):
+        assert all(torch.equal(p, q) for p, q in zip(x.A, y.A))
+        assert all(np.array_equal(p, q) for p, q in zip(x.S, y.S))

@@ -42,6 +42,17 @@ int env_rr_batched(hipStream_t, const double*, const double*, const double*, con
                    int64_t, int64_t, int64_t, int64_t, double*);
 int env_rl_batched(hipStream_t, const double*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, double*);
 int balance(hipStream_t, const double*, int64_t, int64_t, int64_t, double, double*, int*);
+int64_t site_qr_ws_bytes(int, int64_t, int64_t, int64_t, int64_t, int);
+int site_qr(hipStream_t, int, double*, int64_t, int64_t, int64_t, const double*, int64_t, double*, double*, double, int64_t*, double*, int*,
+            void*, int64_t);
+int64_t rar_ws_bytes(int64_t, int64_t, int64_t, int64_t, int64_t);
+int rar(hipStream_t, const double*, const double*, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double*, void*, int64_t);
+int64_t env_mix_ws_bytes(int, int64_t, int64_t, int64_t, int64_t, int64_t);
+int env_mix(hipStream_t, int, const double*, const double*, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double*, void*,
+            int64_t);
+int64_t apply_truncation_ws_bytes(int64_t, int64_t, int64_t, int64_t, int64_t);
+int apply_truncation(hipStream_t, const double*, int64_t, int64_t, const double*, int64_t, int64_t, int64_t, const double*, int64_t, int64_t,
+                     const double*, int64_t, int64_t, const double*, double*, double*, double*, void*, int64_t);
 int qr_batched(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int, double,
                int64_t*, int64_t, int64_t, int64_t, int64_t, void*, int64_t, void* const*, int);
 int svd_trunc_batched(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double, double*, int64_t, int64_t, double*,
@@ -247,6 +258,39 @@ int tn_svdvals_batched(const double* C, int64_t crs, int64_t ccs, int64_t k, int
     TN_CHECK_ARG(batch == 0 || (C && S_host && ws), "null operand");
     ProfPhase ph(PH_SVDVALS);
     return svd_vals_batched(ST, C, crs, ccs, k, n, S_host, sweeps_host, info_host, batch, bsC, ws, ws_bytes);
+}
+
+int64_t tn_site_qr_ws_bytes(int side, int64_t Dl, int64_t p, int64_t Dr, int64_t kc, int attach) {
+    return site_qr_ws_bytes(side, Dl, p, Dr, kc, attach);
+}
+int tn_site_qr(int side, double* A, int64_t Dl, int64_t p, int64_t Dr, const double* C, int64_t kc, double* Q, double* R, double rank_tol,
+               int64_t* keff_host, double* nf_out2, int* normalised_host, void* ws, int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(A && Q && R && ws, "null operand");
+    TN_CHECK_ARG(rank_tol >= 0.0 && rank_tol < 1.0, "rank_tol out of range");
+    return site_qr(ST, side, A, Dl, p, Dr, C, kc, Q, R, rank_tol, keff_host, nf_out2, normalised_host, ws, ws_bytes);
+}
+int64_t tn_rar_ws_bytes(int64_t c, int64_t a, int64_t s, int64_t a2, int64_t c2) { return rar_ws_bytes(c, a, s, a2, c2); }
+int tn_rar(const double* RL, const double* A, const double* RR, int64_t c, int64_t a, int64_t s, int64_t a2, int64_t c2, double* out,
+           void* ws, int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(RL && A && RR && out && ws, "null operand");
+    return rar(ST, RL, A, RR, c, a, s, a2, c2, out, ws, ws_bytes);
+}
+int64_t tn_env_mix_ws_bytes(int side, int64_t a, int64_t s, int64_t a2, int64_t c, int64_t c2) {
+    return env_mix_ws_bytes(side, a, s, a2, c, c2);
+}
+int tn_env_mix(int side, const double* R, const double* A, const double* Ac, int64_t a, int64_t s, int64_t a2, int64_t c, int64_t c2,
+               double* out, void* ws, int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(R && A && Ac && out && ws, "null operand");
+    return env_mix(ST, side, R, A, Ac, a, s, a2, c, c2, out, ws, ws_bytes);
+}
+int64_t tn_apply_truncation_ws_bytes(int64_t ml, int64_t k0, int64_t keep, int64_t k1, int64_t nr) {
+    return apply_truncation_ws_bytes(ml, k0, keep, k1, nr);
+}
+int tn_apply_truncation(const double* Al, int64_t ml, int64_t k0, const double* U, int64_t urs, int64_t ucs, int64_t keep, const double* Vt,
+                        int64_t vrs, int64_t vcs, const double* Ar, int64_t k1, int64_t nr, const double* S, double* Al_new, double* Ar_new,
+                        double* Cdiag, void* ws, int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(Al && U && Vt && Ar && S && Al_new && Ar_new && Cdiag, "null operand");
+    return apply_truncation(ST, Al, ml, k0, U, urs, ucs, keep, Vt, vrs, vcs, Ar, k1, nr, S, Al_new, Ar_new, Cdiag, ws, ws_bytes);
 }
 
 }  // extern "C"

@@ -1,0 +1,157 @@
+// Site steps of the boundary-MPS sweeps as single entry points: each is a fixed composition of the kernels behind tn_gemm /
+// tn_qr / tn_normalize_pow2 with its temporaries carved out of the caller's workspace.  They exist for the host side: with
+// the 4 lattice rotations of an instance driven by 4 host threads, every separate library call (and every temporary torch
+// tensor) is a GIL hand-over, and those -- not the GPU -- account for ~1 s per chain and sweep (tools/host_overhead.py).
+// Results are bit-identical to the separate calls (same kernels, same order, same split-K decisions).
+//
+//   tn_site_qr           attach_CA / attach_AC (mps.py:368-380) + orth_left / orth_right (mps.py:532-548, 772-800)
+//   tn_rar               MPS._mps_RAR  (mps.py:748-751)           optimise_site of the variational sweep
+//   tn_env_mix           MPS._mps_RL / _mps_RR (mps.py:655-663)   mixed environments
+//   tn_apply_truncation  projectors of truncateC into the neighbouring sites + diagonal centre (mps.py:579-583)
+#include "common.h"
+
+namespace tn {
+
+int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
+              void*, int64_t, double, int64_t*, hipStream_t);
+int64_t qr_ws_bytes(int64_t, int64_t, int);
+int normalize_pow2(hipStream_t, double*, int64_t, double*, void*, int64_t);
+
+static inline int64_t up256(int64_t b) { return align_up(b, 256); }
+
+// ---- attach + QR + nfactor ---------------------------------------------------------------------------------------------
+// side 0: M = C (kc x Dl) . A (Dl x p Dr), factored as the (kc p) x Dr matrix  -> Q (kc p x k), R (k x Dr), both row-major
+// side 1: M = A (Dl p x Dr) . C (Dr x kc), factored through its transposed (p kc) x Dl view -> Qt (k x p kc) = Q^T, Ct (Dl x k) = R^T
+// C == nullptr: no attach, A itself is factored (and destroyed); kc is then ignored (kc = Dl resp. Dr).
+struct SiteQrDims { int64_t m, n, k, tmp, rows_l, cols_l; };
+static SiteQrDims site_qr_dims(int side, int64_t Dl, int64_t p, int64_t Dr, int64_t kc, bool attach) {
+    SiteQrDims d;
+    if (side == 0) { const int64_t l = attach ? kc : Dl; d.m = l * p; d.n = Dr; d.tmp = attach ? l * p * Dr : 0; }
+    else { const int64_t r = attach ? kc : Dr; d.m = p * r; d.n = Dl; d.tmp = attach ? Dl * p * r : 0; }
+    d.k = d.m < d.n ? d.m : d.n;
+    d.rows_l = 0; d.cols_l = 0;
+    return d;
+}
+
+int64_t site_qr_ws_bytes(int side, int64_t Dl, int64_t p, int64_t Dr, int64_t kc, int attach) {
+    const SiteQrDims d = site_qr_dims(side, Dl, p, Dr, kc, attach != 0);
+    int64_t g = 0;
+    if (attach) g = side == 0 ? gemm_ws_bytes(kc, p * Dr, Dl, 1) : gemm_ws_bytes(Dl * p, kc, Dr, 1);
+    return up256(d.tmp * 8) + up256(g) + up256(qr_ws_bytes(d.m, d.n, 32)) + 8192;
+}
+
+int site_qr(hipStream_t st, int side, double* A, int64_t Dl, int64_t p, int64_t Dr, const double* C, int64_t kc, double* Q, double* R,
+            double rank_tol, int64_t* keff_host, double* nf_out2, int* normalised_host, void* ws, int64_t ws_bytes) {
+    TN_CHECK_ARG(side == 0 || side == 1, "side must be 0 (left sweep) or 1 (right sweep)");
+    TN_CHECK_ARG(Dl >= 1 && p >= 1 && Dr >= 1 && (C == nullptr || kc >= 1), "non-positive dimension");
+    const bool attach = C != nullptr;
+    TN_CHECK_ARG(ws_bytes >= site_qr_ws_bytes(side, Dl, p, Dr, kc, attach ? 1 : 0), "workspace too small");
+    const SiteQrDims d = site_qr_dims(side, Dl, p, Dr, kc, attach);
+    char* w = (char*)ws;
+    double* M = A;
+    int rc;
+    if (attach) {
+        M = (double*)w;
+        w += up256(d.tmp * 8);
+        const int64_t g = side == 0 ? gemm_ws_bytes(kc, p * Dr, Dl, 1) : gemm_ws_bytes(Dl * p, kc, Dr, 1);
+        double* gws = g > 0 ? (double*)w : nullptr;
+        w += up256(g);
+        if (side == 0) rc = gemm(st, kc, p * Dr, Dl, 1.0, C, Dl, 1, A, p * Dr, 1, 0.0, M, p * Dr, 1, 1, 0, 0, 0, gws, g);
+        else rc = gemm(st, Dl * p, kc, Dr, 1.0, A, Dr, 1, C, kc, 1, 0.0, M, kc, 1, 1, 0, 0, 0, gws, g);
+        if (rc) return rc;
+    }
+    const int64_t qws = up256(qr_ws_bytes(d.m, d.n, 32));
+    void* qw = w;
+    w += qws;
+    int64_t keff = d.k;
+    {
+        ProfPhase ph(PH_QR);
+        const double dm = (double)d.m, dn = (double)d.k;
+        prof_note(PROF_QR_NOMINAL, 1, 4.0 * dm * dn * dn - 4.0 / 3.0 * dn * dn * dn, 8.0 * (2.0 * dm * dn + dn * dn));
+        if (side == 0)      // M (m x n) row-major; Q (m x k) row-major; R (k x n) row-major
+            rc = qr_factor(st, M, d.n, 1, d.m, d.n, Q, d.k, 1, R, d.n, 1, 32, qw, qws, rank_tol, &keff, nullptr);
+        else                // the (p r) x Dl view of the row-major (Dl, p r) array; Q = Qt^T, R = Ct^T
+            rc = qr_factor(st, M, 1, d.m, d.m, d.n, Q, 1, d.m, R, 1, d.k, 32, qw, qws, rank_tol, &keff, nullptr);
+    }
+    if (rc) return rc;
+    if (keff_host) *keff_host = keff;
+    int normalised = 0;
+    if (nf_out2 && keff == d.k) {      // the triangular factor is complete and contiguous: C = R / nfactor(R) (mps.py:781-782, 796-797)
+        if ((rc = normalize_pow2(st, R, d.k * d.n, nf_out2, w, 8192))) return rc;
+        normalised = 1;
+    }
+    if (normalised_host) *normalised_host = normalised;
+    return 0;
+}
+
+// ---- RL . A . RR -------------------------------------------------------------------------------------------------------
+int64_t rar_ws_bytes(int64_t c, int64_t a, int64_t s, int64_t a2, int64_t c2) {
+    const int64_t g1 = gemm_ws_bytes(c, s * a2, a, 1), g2 = gemm_ws_bytes(c * s, c2, a2, 1);
+    return up256(c * s * a2 * 8) + up256(g1 > g2 ? g1 : g2);
+}
+int rar(hipStream_t st, const double* RL, const double* A, const double* RR, int64_t c, int64_t a, int64_t s, int64_t a2, int64_t c2,
+        double* out, void* ws, int64_t ws_bytes) {
+    TN_CHECK_ARG(c >= 1 && a >= 1 && s >= 1 && a2 >= 1 && c2 >= 1, "non-positive dimension");
+    TN_CHECK_ARG(ws_bytes >= rar_ws_bytes(c, a, s, a2, c2), "workspace too small");
+    double* T = (double*)ws;
+    double* gws = (double*)((char*)ws + up256(c * s * a2 * 8));
+    const int64_t g1 = gemm_ws_bytes(c, s * a2, a, 1), g2 = gemm_ws_bytes(c * s, c2, a2, 1);
+    int rc;
+    if ((rc = gemm(st, c, s * a2, a, 1.0, RL, a, 1, A, s * a2, 1, 0.0, T, s * a2, 1, 1, 0, 0, 0, g1 > 0 ? gws : nullptr, g1))) return rc;
+    return gemm(st, c * s, c2, a2, 1.0, T, a2, 1, RR, c2, 1, 0.0, out, c2, 1, 1, 0, 0, 0, g2 > 0 ? gws : nullptr, g2);
+}
+
+// ---- mixed environments ------------------------------------------------------------------------------------------------
+// side 0 (left):  out[c2, a2] = sum_{c,s,a} Ac[c,s,c2] R[c,a] A[a,s,a2]       R: (c x a)
+// side 1 (right): out[a, c]   = sum_{s,a2,c2} A[a,s,a2] R[a2,c2] Ac[c,s,c2]   R: (a2 x c2)
+int64_t env_mix_ws_bytes(int side, int64_t a, int64_t s, int64_t a2, int64_t c, int64_t c2) {
+    int64_t t, g1, g2;
+    if (side == 0) { t = c * s * a2; g1 = gemm_ws_bytes(c, s * a2, a, 1); g2 = gemm_ws_bytes(c2, a2, c * s, 1); }
+    else { t = a * s * c2; g1 = gemm_ws_bytes(a * s, c2, a2, 1); g2 = gemm_ws_bytes(a, c, s * c2, 1); }
+    return up256(t * 8) + up256(g1 > g2 ? g1 : g2);
+}
+int env_mix(hipStream_t st, int side, const double* R, const double* A, const double* Ac, int64_t a, int64_t s, int64_t a2, int64_t c,
+            int64_t c2, double* out, void* ws, int64_t ws_bytes) {
+    TN_CHECK_ARG(side == 0 || side == 1, "side must be 0 (left) or 1 (right)");
+    TN_CHECK_ARG(a >= 1 && s >= 1 && a2 >= 1 && c >= 1 && c2 >= 1, "non-positive dimension");
+    TN_CHECK_ARG(ws_bytes >= env_mix_ws_bytes(side, a, s, a2, c, c2), "workspace too small");
+    double* T = (double*)ws;
+    int rc;
+    if (side == 0) {
+        double* gws = (double*)((char*)ws + up256(c * s * a2 * 8));
+        const int64_t g1 = gemm_ws_bytes(c, s * a2, a, 1), g2 = gemm_ws_bytes(c2, a2, c * s, 1);
+        if ((rc = gemm(st, c, s * a2, a, 1.0, R, a, 1, A, s * a2, 1, 0.0, T, s * a2, 1, 1, 0, 0, 0, g1 > 0 ? gws : nullptr, g1))) return rc;
+        // out = Ac(c s, c2)^T . T(c s, a2)
+        return gemm(st, c2, a2, c * s, 1.0, Ac, 1, c2, T, a2, 1, 0.0, out, a2, 1, 1, 0, 0, 0, g2 > 0 ? gws : nullptr, g2);
+    }
+    double* gws = (double*)((char*)ws + up256(a * s * c2 * 8));
+    const int64_t g1 = gemm_ws_bytes(a * s, c2, a2, 1), g2 = gemm_ws_bytes(a, c, s * c2, 1);
+    if ((rc = gemm(st, a * s, c2, a2, 1.0, A, a2, 1, R, c2, 1, 0.0, T, c2, 1, 1, 0, 0, 0, g1 > 0 ? gws : nullptr, g1))) return rc;
+    // out = T(a, s c2) . Ac(c, s c2)^T
+    return gemm(st, a, c, s * c2, 1.0, T, s * c2, 1, Ac, 1, s * c2, 0.0, out, c, 1, 1, 0, 0, 0, g2 > 0 ? gws : nullptr, g2);
+}
+
+// ---- projectors of a truncation ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void diag_from_vec_kernel(const double* __restrict__ S, int64_t k, double* __restrict__ D) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < k * k) D[e] = (e / k == e % k) ? S[e / k] : 0.0;
+}
+int64_t apply_truncation_ws_bytes(int64_t ml, int64_t k0, int64_t keep, int64_t k1, int64_t nr) {
+    const int64_t g1 = gemm_ws_bytes(ml, keep, k0, 1), g2 = gemm_ws_bytes(keep, nr, k1, 1);
+    return up256(g1 > g2 ? g1 : g2);
+}
+int apply_truncation(hipStream_t st, const double* Al, int64_t ml, int64_t k0, const double* U, int64_t urs, int64_t ucs, int64_t keep,
+                     const double* Vt, int64_t vrs, int64_t vcs, const double* Ar, int64_t k1, int64_t nr, const double* S, double* Al_new,
+                     double* Ar_new, double* Cdiag, void* ws, int64_t ws_bytes) {
+    TN_CHECK_ARG(ml >= 1 && k0 >= 1 && keep >= 1 && k1 >= 1 && nr >= 1, "non-positive dimension");
+    TN_CHECK_ARG(ws_bytes >= apply_truncation_ws_bytes(ml, k0, keep, k1, nr), "workspace too small");
+    const int64_t g1 = gemm_ws_bytes(ml, keep, k0, 1), g2 = gemm_ws_bytes(keep, nr, k1, 1);
+    int rc;
+    if ((rc = gemm(st, ml, keep, k0, 1.0, Al, k0, 1, U, urs, ucs, 0.0, Al_new, keep, 1, 1, 0, 0, 0, g1 > 0 ? (double*)ws : nullptr, g1))) return rc;
+    if ((rc = gemm(st, keep, nr, k1, 1.0, Vt, vrs, vcs, Ar, nr, 1, 0.0, Ar_new, nr, 1, 1, 0, 0, 0, g2 > 0 ? (double*)ws : nullptr, g2))) return rc;
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(diag_from_vec_kernel, dim3((unsigned)cdiv(keep * keep, 256)), dim3(256), 0, st, S, keep, Cdiag));
+    TN_CHECK_LAUNCH("diag_from_vec_kernel");
+    return 0;
+}
+
+}  // namespace tn

@@ -276,6 +276,28 @@ class MPS:
         self.D[n] = k
         self.pC = n
 
+    def _site_left(self, n, Cm, rank_tol=0.0):
+        """attach_CA (Cm given) + orth_left at site n in one library call (tn_site_qr); same state changes."""
+        Q, R, k, nf = ops.site_qr(0, self.A[n], Cm, rank_tol)
+        self._nfs.append(nf)
+        if R.shape == (1, 1):
+            R = torch.ones_like(R)
+        self.A[n] = Q.view(-1, self.A[n].shape[1], k)
+        self.C = R
+        self.D[n], self.D[n + 1] = self.A[n].shape[0], k
+        self.pC = n + 1
+
+    def _site_right(self, n, Cm, rank_tol=0.0):
+        """attach_AC (Cm given) + orth_right at site n in one library call (tn_site_qr); same state changes."""
+        Qt, Ct, k, nf = ops.site_qr(1, self.A[n], Cm, rank_tol)
+        self._nfs.append(nf)
+        if Ct.shape == (1, 1):
+            Ct = torch.ones_like(Ct)
+        self.A[n] = Qt.view(k, self.A[n].shape[1], -1)
+        self.C = Ct
+        self.D[n], self.D[n + 1] = k, self.A[n].shape[2]
+        self.pC = n
+
     def truncateC(self, Dmax, tol=None):
         """SVD-truncate the centre matrix and push the projectors into the neighbours (mps.py:562-585, 802-811)."""
         if 0 < self.pC < self.L:
@@ -284,11 +306,14 @@ class MPS:
             Dcap = int(min(Dmax, min(self.C.shape)))
             U, S, Vt, keep, disc, _ = ops.svd_trunc(self.C, Dcap, tol)
             nl, nr = self.pC - 1, self.pC
-            Dl, p, _ = self.A[nl].shape
-            self.A[nl] = ops.mm(self.A[nl].view(Dl * p, -1), U).view(Dl, p, keep)
-            _, p2, Dr = self.A[nr].shape
-            self.A[nr] = ops.mm(Vt, self.A[nr].view(-1, p2 * Dr)).view(keep, p2, Dr)
-            self.C = torch.diag(S)
+            if ops.FUSED_SITE and keep > 0:
+                self.A[nl], self.A[nr], self.C = ops.apply_truncation(self.A[nl], U, S, Vt, self.A[nr])
+            else:
+                Dl, p, _ = self.A[nl].shape
+                self.A[nl] = ops.mm(self.A[nl].view(Dl * p, -1), U).view(Dl, p, keep)
+                _, p2, Dr = self.A[nr].shape
+                self.A[nr] = ops.mm(Vt, self.A[nr].view(-1, p2 * Dr)).view(keep, p2, Dr)
+                self.C = torch.diag(S)
             self.D[self.pC] = keep
             self.discarded[self.pC] = max(self.discarded[self.pC], disc)
             return disc
@@ -299,10 +324,14 @@ class MPS:
         self.C = torch.ones((1, 1), dtype=torch.float64, device=self.A[0].device)
         self.pC = 0
         for n in range(self.L):
-            self.attach_CA()
             # truncating pass: left part canonical, right part canonical -> the scale of C is the Schmidt scale, so rows of
             # R below 2^-56 of it can be skipped already in the QR (they are deflated by the SVD of truncateC)
-            self.orth_left(n, rank_tol=ops.RANK_TOL if (compress and 0 < n + 1 < self.L) else 0.0)
+            rank_tol = ops.RANK_TOL if (compress and 0 < n + 1 < self.L) else 0.0
+            if ops.FUSED_SITE:
+                self._site_left(n, self.C, rank_tol)
+            else:
+                self.attach_CA()
+                self.orth_left(n, rank_tol=rank_tol)
             if compress:
                 self.truncateC(Dmax, tol)
         self.R[-1] = None
@@ -312,8 +341,12 @@ class MPS:
         self.C = torch.ones((1, 1), dtype=torch.float64, device=self.A[0].device)
         self.pC = self.L
         for n in range(self.L - 1, -1, -1):
-            self.attach_AC()
-            self.orth_right(n, rank_tol=ops.RANK_TOL if (compress and 0 < n < self.L) else 0.0)
+            rank_tol = ops.RANK_TOL if (compress and 0 < n < self.L) else 0.0
+            if ops.FUSED_SITE:
+                self._site_right(n, self.C, rank_tol)
+            else:
+                self.attach_AC()
+                self.orth_right(n, rank_tol=rank_tol)
             if compress:
                 self.truncateC(Dmax, tol)
         self.R[-1] = None
@@ -322,6 +355,8 @@ class MPS:
     @staticmethod
     def _mps_RL(RL, A, Ac):
         """out[c',a'] = sum_{c,s,a} Ac[c,s,c'] RL[c,a] A[a,s,a'] (mps.py:655-658)."""
+        if ops.FUSED_SITE:
+            return ops.env_mix(0, RL, A, Ac)
         a, s, a2 = A.shape
         c, _, c2 = Ac.shape
         T = ops.mm(RL, A.view(a, s * a2))                       # (c, s a')
@@ -330,6 +365,8 @@ class MPS:
     @staticmethod
     def _mps_RR(RR, A, Ac):
         """out[a,c] = sum A[a,s,a'] RR[a',c'] Ac[c,s,c'] (mps.py:660-663)."""
+        if ops.FUSED_SITE:
+            return ops.env_mix(1, RR, A, Ac)
         a, s, a2 = A.shape
         c, _, c2 = Ac.shape
         T = ops.mm(A.view(a * s, a2), RR)                       # (a s, c')
@@ -338,6 +375,8 @@ class MPS:
     @staticmethod
     def _mps_RAR(RL, A, RR):
         """RL . A . RR (mps.py:748-751)."""
+        if ops.FUSED_SITE:
+            return ops.rar(RL, A, RR)
         a, s, a2 = A.shape
         T = ops.mm(RL, A.view(a, s * a2))                       # (c, s a')
         c = RL.shape[0]
@@ -417,12 +456,18 @@ class MPS:
             pend = _DeferredSchmidt(self)
             for n in range(self.L - 1, 0, -1):
                 self.optimise_site(phi, n)
-                self.orth_right(n)
+                if ops.FUSED_SITE:
+                    self._site_right(n, None)
+                else:
+                    self.orth_right(n)
                 pend.add(measure=False)
                 self.update_RR_mix(phi, n)
             for n in range(self.L):
                 self.optimise_site(phi, n)
-                self.orth_left(n)
+                if ops.FUSED_SITE:
+                    self._site_left(n, None)
+                else:
+                    self.orth_left(n)
                 pend.add(measure=True)
                 self.update_RL_mix(phi, n)
             diff = pend.finish()

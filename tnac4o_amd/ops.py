@@ -45,8 +45,21 @@ def aux_stream():
     return a
 
 
+try:                                   # raw handle of the current stream without building a Stream object (and without the
+    _raw_stream = torch._C._cuda_getCurrentRawStream      # GIL hand-over a full torch call costs when 4 chains run)
+    _raw_device = torch._C._cuda_getDevice
+except AttributeError:                 # pragma: no cover - other torch builds
+    _raw_stream = _raw_device = None
+
+
+def _stream_handle():
+    if _raw_stream is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_stream_handle())
 
 
 def _need_gpu(t):
@@ -59,8 +72,8 @@ def _need_gpu(t):
 def workspace(nbytes, slot=0):
     """A persistent scratch buffer of at least nbytes (grown on demand), private to the (device, stream) pair so that
     independent chains running on different streams never share scratch memory."""
-    dev = torch.cuda.current_device()
-    key = (dev, torch.cuda.current_stream().cuda_stream, slot)
+    dev = _raw_device() if _raw_device is not None else torch.cuda.current_device()
+    key = (dev, _stream_handle(), slot)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device='cuda')
@@ -302,6 +315,98 @@ def svdvals_async(Cm, out66, stream=None):
     k, n = Cm.shape
     st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
     check(lib().tn_svdvals_async(Cm.data_ptr(), Cm.stride(0), Cm.stride(1), k, n, out66.data_ptr(), st))
+
+
+# ---- fused site steps (csrc/site.hip) ------------------------------------------------------------------------------------
+FUSED_SITE = os.environ.get('TN_FUSED_SITE', '1') != '0'
+_wsq = {}
+
+
+def _ws_query(name, *args):
+    key = (name,) + args
+    v = _wsq.get(key)
+    if v is None:
+        v = _wsq[key] = int(getattr(lib(), name)(*args))
+    return v
+
+
+def site_qr(side, A, Cm=None, rank_tol=0.0):
+    """One canonisation step in one call (tn_site_qr): attach the centre matrix Cm (side 0: Cm . A, side 1: A . Cm; None = no
+    attach, A is consumed), QR with diag(R) >= 0, power-of-two normalisation of the triangular factor.
+    side 0 returns (Q (l p x k), R (k x Dr), k, nf);  side 1 returns (Q^T (k x p r), R^T (Dl x k), k, nf), nf = device [nf, 1/nf].
+    After a rank-revealing early exit (k below the full rank) the factors are sliced and normalised here."""
+    Dl, p, Dr = A.shape
+    attach = Cm is not None
+    kc = (Cm.shape[0] if side == 0 else Cm.shape[1]) if attach else 0
+    assert A.is_contiguous() and (not attach or (Cm.is_contiguous() and (Cm.shape[1] == Dl if side == 0 else Cm.shape[0] == Dr)))
+    if side == 0:
+        m, n = (kc if attach else Dl) * p, Dr
+    else:
+        m, n = p * (kc if attach else Dr), Dl
+    kf = min(m, n)
+    dev = A.device
+    Q = torch.empty((m, kf) if side == 0 else (kf, m), dtype=torch.float64, device=dev)
+    R = torch.empty((kf, n) if side == 0 else (n, kf), dtype=torch.float64, device=dev)
+    nf = torch.empty(2, dtype=torch.float64, device=dev)
+    wsb = _ws_query('tn_site_qr_ws_bytes', side, Dl, p, Dr, kc, 1 if attach else 0)
+    ws = workspace(wsb, 0)
+    keff, normd = C.c_int64(kf), C.c_int(0)
+    check(lib().tn_site_qr(side, A.data_ptr(), Dl, p, Dr, Cm.data_ptr() if attach else None, kc, Q.data_ptr(), R.data_ptr(),
+                           float(rank_tol), C.byref(keff), nf.data_ptr(), C.byref(normd), ws.data_ptr(), wsb, _stream()))
+    k = int(keff.value)
+    if k < kf:
+        if side == 0:
+            Q, R = Q[:, :k].contiguous(), R[:k].contiguous()
+        else:
+            Q, R = Q[:k].contiguous(), R[:, :k].contiguous()
+    if not normd.value:
+        nf = normalize_pow2_(R)
+    return Q, R, k, nf
+
+
+def rar(RL, A, RR):
+    """RL . A . RR -> (c, s, c2) (tn_rar; MPS._mps_RAR)."""
+    a, s_, a2 = A.shape
+    c, c2 = RL.shape[0], RR.shape[1]
+    assert A.is_contiguous() and RL.shape[1] == a and RR.shape[0] == a2
+    RL, RR = RL if RL.is_contiguous() else RL.contiguous(), RR if RR.is_contiguous() else RR.contiguous()
+    out = torch.empty((c, s_, c2), dtype=torch.float64, device=A.device)
+    wsb = _ws_query('tn_rar_ws_bytes', c, a, s_, a2, c2)
+    ws = workspace(wsb, 1)
+    check(lib().tn_rar(RL.data_ptr(), A.data_ptr(), RR.data_ptr(), c, a, s_, a2, c2, out.data_ptr(), ws.data_ptr(), wsb, _stream()))
+    return out
+
+
+def env_mix(side, Rm, A, Ac):
+    """Mixed environment update (tn_env_mix; MPS._mps_RL for side 0, _mps_RR for side 1)."""
+    a, s_, a2 = A.shape
+    c, _, c2 = Ac.shape
+    assert A.is_contiguous() and Ac.is_contiguous() and tuple(Rm.shape) == ((c, a) if side == 0 else (a2, c2))
+    Rm = Rm if Rm.is_contiguous() else Rm.contiguous()
+    out = torch.empty((c2, a2) if side == 0 else (a, c), dtype=torch.float64, device=A.device)
+    wsb = _ws_query('tn_env_mix_ws_bytes', side, a, s_, a2, c, c2)
+    ws = workspace(wsb, 1)
+    check(lib().tn_env_mix(side, Rm.data_ptr(), A.data_ptr(), Ac.data_ptr(), a, s_, a2, c, c2, out.data_ptr(), ws.data_ptr(), wsb,
+                           _stream()))
+    return out
+
+
+def apply_truncation(Al, U, S, Vt, Ar):
+    """Projectors of a truncation into the neighbours + diagonal centre (tn_apply_truncation).  Al (Dl, p, k0), Ar (k1, p2, Dr),
+    U (k0 x keep), Vt (keep x k1) as strided views.  Returns (Al_new (Dl, p, keep), Ar_new (keep, p2, Dr), diag(S))."""
+    Dl, p, k0 = Al.shape
+    k1, p2, Dr = Ar.shape
+    keep = S.numel()
+    dev = Al.device
+    Aln = torch.empty((Dl, p, keep), dtype=torch.float64, device=dev)
+    Arn = torch.empty((keep, p2, Dr), dtype=torch.float64, device=dev)
+    Cd = torch.empty((keep, keep), dtype=torch.float64, device=dev)
+    wsb = _ws_query('tn_apply_truncation_ws_bytes', Dl * p, k0, keep, k1, p2 * Dr)
+    ws = workspace(max(wsb, 256), 1)
+    check(lib().tn_apply_truncation(Al.data_ptr(), Dl * p, k0, U.data_ptr(), U.stride(0), U.stride(1), keep, Vt.data_ptr(), Vt.stride(0),
+                                    Vt.stride(1), Ar.data_ptr(), k1, p2 * Dr, S.data_ptr(), Aln.data_ptr(), Arn.data_ptr(), Cd.data_ptr(),
+                                    ws.data_ptr(), wsb, _stream()))
+    return Aln, Arn, Cd
 
 
 def nfactor_dev(T):
