@@ -500,3 +500,38 @@ def test_svd_trunc_batched_matches_single_calls(ops):
         U, S, Vt, keep, disc, _ = ops.svd_trunc(Cm[i], 64, 1e-17)
         assert out[i][3] == keep and out[i][4] == disc
         assert torch.equal(out[i][0], U) and torch.equal(out[i][1], S) and torch.equal(out[i][2], Vt)
+
+
+@pytest.mark.parametrize('nbo', [128, 256])
+@pytest.mark.parametrize('colmajor', [False, True])
+def test_qr_two_level_blocking(ops, nbo, colmajor):
+    """The two-level blocked factorisation (outer blocks of 128 / 256 columns with merged T factors, csrc/qr.hip) on the
+    pass-1 shape against the single-level one: same R up to rounding (diag >= 0 fixes the gauge), column-relative residual,
+    orthogonality of Q, on a graded numerically rank-deficient matrix and on a full-rank one."""
+    m, n = 16384, 1024
+    g = torch.Generator(device='cuda').manual_seed(77)
+    lowrank = (torch.randn((m, 200), dtype=torch.float64, device='cuda', generator=g) @
+               torch.randn((200, n), dtype=torch.float64, device='cuda', generator=g)) * \
+        torch.exp(-60.0 * torch.rand((1, n), dtype=torch.float64, device='cuda', generator=g))
+    full = torch.randn((m, n), dtype=torch.float64, device='cuda', generator=g)
+    saved = os.environ.get('TN_QR_NBO')
+    try:
+        for T in (lowrank, full):
+            view = T.t().contiguous().t() if colmajor else T
+            os.environ['TN_QR_NBO'] = '0'
+            Q0, R0 = ops.qr(view)
+            os.environ['TN_QR_NBO'] = str(nbo)
+            Q, R = ops.qr(view)
+            cn = torch.linalg.vector_norm(T, dim=0)
+            assert float(((ops.mm(Q, R) - T).abs().max(dim=0).values / cn).max()) < 1e-13
+            G = ops.mm(Q.t(), Q)
+            assert float((G - torch.eye(n, dtype=torch.float64, device='cuda')).abs().max()) < 1e-13
+            assert float(torch.tril(R, -1).abs().max()) == 0.0 and bool((torch.diagonal(R) >= 0).all())
+            if T is full:          # well conditioned: the factors themselves agree with the single-level ones
+                assert float((R - R0).abs().max()) < 1e-11 * float(R0.abs().max())
+                assert float((Q - Q0).abs().max()) < 1e-11
+    finally:
+        if saved is None:
+            os.environ.pop('TN_QR_NBO', None)
+        else:
+            os.environ['TN_QR_NBO'] = saved

@@ -42,6 +42,21 @@ int copy_mat(hipStream_t st, const double* S, int64_t srs, int64_t scs, double* 
     return 0;
 }
 
+__global__ __launch_bounds__(256) void fill_mat_kernel(double* __restrict__ D, int64_t drs, int64_t dcs, int64_t m, int64_t n, double v,
+                                                       int colfast) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * n) return;
+    const int64_t i = colfast ? e / n : e % m, j = colfast ? e % n : e / m;
+    D[i * drs + j * dcs] = v;
+}
+static int fill_mat(hipStream_t st, double* D, int64_t drs, int64_t dcs, int64_t m, int64_t n, double v) {
+    if (m <= 0 || n <= 0) return 0;
+    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(fill_mat_kernel, dim3((unsigned)cdiv(m * n, 256)), dim3(256), 0, st, D, drs, dcs, m, n, v,
+                       dcs == 1 ? 1 : 0));
+    TN_CHECK_LAUNCH("fill_mat_kernel");
+    return 0;
+}
+
 __device__ __forceinline__ double hash_unit(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return ((double)(x >> 11) * (1.0 / 9007199254740992.0)) - 0.5;
@@ -553,8 +568,10 @@ static void dbg_check(hipStream_t st, const double* p, int64_t rs, int64_t cs, i
     fprintf(stderr, "[tn_qr dbg] panel %d it %d %-10s %lldx%lld nonfinite=%d max=%.3e min|.|=%.3e\n", panel, it, what, (long long)m, (long long)n, bad, mx, mn);
 }
 
+constexpr int QR_NBO_MAX = 256;       // widest outer block of the two-level factorisation
 struct QrWs {
     double *Y, *Wq, *W, *W2, *UT, *UTq, *gemm_ws2;
+    double *G, *Tblk, *Zo, *Zo2, *tmpT;
     double *T, *X, *X2, *part, *Js, *Uinv, *Z, *Tri, *gemm_ws, *cn;
     int* dead;
     int64_t gemm_ws_bytes;
@@ -584,8 +601,23 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     double* cn = (double*)take(2 * n * 8);            // column norms^2: [input | current trailing block]
     // split-K scratch for the tall TN products (b x n, K = m)
     int64_t gw = (int64_t)64 * nb * (n > k ? n : k) * 8;      // upper bound of pick_splitk's partial buffers
+    {   // ... and of the outer-block products (NBO x n', K = m) of the two-level path: pick_splitk asks for about 512 tiles of
+        // 128 x 128 whatever n' is (s = ceil(512 / tiles)), i.e. <= (512 + tiles) 128^2 doubles; take that bound for the widest case
+        const int64_t tiles = cdiv(QR_NBO_MAX, 128) * cdiv(n > k ? n : k, 128);
+        const int64_t g2 = (512 + 2 * tiles) * 128 * 128 * 8;
+        if (g2 > gw) gw = g2;
+    }
     double* gws = (double*)take(gw + 256);
     double* gws2 = (double*)take(gw + 256);           // split-K scratch of the look-ahead stream
+    // two-level blocking: Gram of an outer block, its merged T factors (one per block), the two (NBO x n) operands of the
+    // outer update and a scratch for the T recurrence
+    const int64_t nblk_o = cdiv(k, QR_NBO_MAX / 2);           // enough for the narrowest outer width used (128)
+    double* Gm = (double*)take((int64_t)QR_NBO_MAX * QR_NBO_MAX * 8);
+    double* Tblk = (double*)take(nblk_o * QR_NBO_MAX * QR_NBO_MAX * 8);
+    double* Zb = (double*)take((int64_t)QR_NBO_MAX * (n > k ? n : k) * 8);
+    double* Zb2 = (double*)take((int64_t)QR_NBO_MAX * (n > k ? n : k) * 8);
+    double* tmpT = (double*)take((int64_t)QR_NBO_MAX * 64 * 8);
+    if (w) { w->G = Gm; w->Tblk = Tblk; w->Zo = Zb; w->Zo2 = Zb2; w->tmpT = tmpT; }
     const int64_t tsb = tsqr_ws_bytes(m, nb < 32 ? nb : 32);
     void* tsw = (void*)take(tsb);
     if (w) { w->tsqr_ws = tsw; w->tsqr_bytes = tsb; }
@@ -603,6 +635,105 @@ int64_t qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_layout(m, n, nb, n
 // (A = Q[:, :k_eff] R[:k_eff, :] to rank_tol * max column norm).  Used by the truncating canonisation passes, whose centre
 // matrix is SVD-truncated at eps * S0 right afterwards (the Jacobi SVD deflates rows below 2^-56 anyway); it needs one
 // 16-byte read-back per check.  *keff_host receives the number of columns/rows produced.
+// ---- two-level blocked factorisation (nb = 32 inside outer blocks of `nbo` columns) ---------------------------------------
+// Single-level blocking applies every 32-wide reflector to the whole trailing matrix and again to Q: three passes over up to
+// 134 MB per panel at K = 32, i.e. HBM-bound work that fills the device (12.9 GB for one 16384 x 1024 call against 0.28 GB
+// compulsory) and, with several chains on the GPU, serialises them.  Here the panels of an outer block only update the
+// columns of that block; the columns to its right (and, afterwards, Q) see the block once, through the merged reflector
+//      H_1 ... H_q = I - Y_blk T_blk Y_blk^T,   T_blk = [[T_1, -T_1 (Y_1^T Y_2) T_2, ...], [0, T_2, ...], ...]   (dlarft by blocks)
+// built from the panels' own (Y_p, T_p) and one Gram matrix G = Y_blk^T Y_blk: rank-nbo GEMMs (K = 128 or 256) instead of
+// rank-32 ones, 4-8x fewer bytes.  Used for the plain factorisation only (rank_tol = 0): the rank-revealing early exit of the
+// truncating passes checks the trailing block after every second panel, which needs it up to date.
+static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k, Mat Ym, QrWs& w, int nbo, int64_t rs, int64_t cs,
+                        int64_t yrs, int64_t ycs, int64_t wrs, int64_t wcs, double* Q, int64_t qrs, int64_t qcs, double* R, int64_t rrs,
+                        int64_t rcs) {
+    const int nb = 32;
+    int rc;
+    const int nblk = (int)cdiv(k, nbo);
+    for (int bi = 0; bi < nblk; ++bi) {
+        const int64_t J0 = (int64_t)bi * nbo;
+        const int bw = (int)((k - J0 < nbo) ? k - J0 : nbo);
+        const int64_t Jend = J0 + bw, mb = m - J0;
+        Mat Yb = sub(Ym, J0, J0);
+        // rows of the block above each panel's own top block must read as zero in the merged reflector
+        if ((rc = fill_mat(st, Yb.p, yrs, ycs, bw, bw, 0.0))) return rc;
+        double* Tb = w.Tblk + (int64_t)bi * QR_NBO_MAX * QR_NBO_MAX;            // bw x bw, row-major, pitch bw
+        if ((rc = fill_mat(st, Tb, bw, 1, bw, bw, 0.0))) return rc;
+        const int npan = (int)cdiv(bw, nb);
+        for (int q = 0; q < npan; ++q) {
+            const int64_t j0 = J0 + (int64_t)q * nb;
+            const int b = (int)((Jend - j0 < nb) ? Jend - j0 : nb);
+            const int64_t mp = m - j0, nin = Jend - j0;                         // the panel's update stays inside the block
+            const int p = (int)(j0 / nb);
+            Mat Ap = sub(Am, j0, j0), Yp = sub(Ym, j0, j0);
+            if ((rc = tsqr_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes))) return rc;
+            double* Tp = w.T + (int64_t)p * nb * nb;
+            Mat Wp = mat(w.W, wrs, wcs);
+            // Wq_top goes to a scratch corner of the (otherwise unused here) Wq buffer: only Y, T and W = Y T^T are needed
+            TN_PROF_LAUNCH(st, PROF_LU, hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT,
+                               w.UTq, Wp.p, wrs, wcs, w.Wq));
+            TN_CHECK_LAUNCH("lu_reconstruct_kernel");
+            if (mp > b) {
+                dim3 grid((unsigned)cdiv(mp - b, 256));
+                prof_begin(st, PROF_ROWS_SMALL);
+                hipLaunchKernelGGL(rows_times_small3_mfma_kernel, grid, dim3(256), 0, st, sub(Yp, b, 0).p, yrs, ycs, mp - b, b, w.Uinv, w.UT,
+                                   (const double*)nullptr, sub(Wp, b, 0).p, wrs, wcs, (double*)nullptr);
+                TN_CHECK_LAUNCH("rows_times_small3_kernel");
+                prof_end(st, PROF_ROWS_SMALL, 4.0 * (mp - b) * b * b, 24.0 * (mp - b) * b);
+            }
+            Mat Xm = mat(w.X, nin, 1);
+            if ((rc = gemm(st, b, nin, mp, 1.0, tr(Yp), Ap, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+            if ((rc = gemm(st, mp, nin, b, -1.0, Wp, Xm, 1.0, Ap))) return rc;
+            // T_blk: diagonal block = T_p (its pitch is b); column block from the recurrence once the Gram matrix exists (below)
+            if ((rc = copy_mat(st, Tp, b, 1, Tb + (int64_t)(j0 - J0) * bw + (j0 - J0), bw, 1, b, b))) return rc;
+        }
+        // G = Y_blk^T Y_blk, then T_blk[0:c0, c0:c0+b] = -T_blk[0:c0, 0:c0] (G[0:c0, c0:c0+b] T_q)
+        Mat Gm = mat(w.G, bw, 1);
+        if (npan > 1) {
+            if ((rc = gemm(st, bw, bw, mb, 1.0, tr(Yb), Yb, 0.0, Gm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+            for (int q = 1; q < npan; ++q) {
+                const int64_t c0 = (int64_t)q * nb;
+                const int b = (int)((bw - c0 < nb) ? bw - c0 : nb);
+                Mat Tq = mat(Tb + c0 * bw + c0, bw, 1), tmp = mat(w.tmpT, b, 1);
+                if ((rc = gemm(st, c0, b, b, 1.0, sub(Gm, 0, c0), Tq, 0.0, tmp))) return rc;
+                if ((rc = gemm(st, c0, b, c0, -1.0, mat(Tb, bw, 1), tmp, 0.0, mat(Tb + c0, bw, 1)))) return rc;
+            }
+        }
+        // outer update of everything to the right of the block:  A_r -= Y_blk (T_blk^T (Y_blk^T A_r))
+        const int64_t nr = n - Jend;
+        if (nr > 0) {
+            Mat Ar = sub(Am, J0, Jend), Z = mat(w.Zo, nr, 1), Z2 = mat(w.Zo2, nr, 1);
+            if ((rc = gemm(st, bw, nr, mb, 1.0, tr(Yb), Ar, 0.0, Z, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+            if ((rc = gemm(st, bw, nr, bw, 1.0, tr(mat(Tb, bw, 1)), Z, 0.0, Z2))) return rc;
+            if ((rc = gemm(st, mb, nr, bw, -1.0, Yb, Z2, 1.0, Ar))) return rc;
+        }
+    }
+    // --- triangularise the diagonal blocks, assemble R (as in the single-level path)
+    const int P = (int)cdiv(k, nb);
+    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, Am.p, rs, cs, nb, k, w.Z, w.Tri));
+    TN_CHECK_LAUNCH("diag_qr_kernel");
+    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(assemble_R_kernel, dim3((unsigned)cdiv(k * n, 256)), dim3(256), 0, st, Am.p, rs, cs, nb, k, n, w.Z,
+                       w.Tri, R, rrs, rcs));
+    TN_CHECK_LAUNCH("assemble_R_kernel");
+    // --- Q = H_blk1 ... H_blkB [Z; 0]:  Q[J0:, J0:] -= Y_blk (T_blk (Y_blk^T Q[J0:, J0:]))
+    const int qcolfast = (qcs == 1) ? 1 : 0;
+    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(init_Q_kernel, dim3((unsigned)cdiv(m * k, 256)), dim3(256), 0, st, Q, qrs, qcs, m, k, nb, w.Z,
+                       qcolfast));
+    TN_CHECK_LAUNCH("init_Q_kernel");
+    Mat Qm = mat(Q, qrs, qcs);
+    for (int bi = nblk - 1; bi >= 0; --bi) {
+        const int64_t J0 = (int64_t)bi * nbo;
+        const int bw = (int)((k - J0 < nbo) ? k - J0 : nbo);
+        const int64_t mb = m - J0, nq = k - J0;
+        Mat Yb = sub(Ym, J0, J0), Qb = sub(Qm, J0, J0), Z = mat(w.Zo, nq, 1), Z2 = mat(w.Zo2, nq, 1);
+        double* Tb = w.Tblk + (int64_t)bi * QR_NBO_MAX * QR_NBO_MAX;
+        if ((rc = gemm(st, bw, nq, mb, 1.0, tr(Yb), Qb, 0.0, Z, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+        if ((rc = gemm(st, bw, nq, bw, 1.0, mat(Tb, bw, 1), Z, 0.0, Z2))) return rc;
+        if ((rc = gemm(st, mb, nq, bw, -1.0, Yb, Z2, 1.0, Qb))) return rc;
+    }
+    return 0;
+}
+
 // Look-ahead (aux != nullptr, nb = 32): the trailing update of panel p is split.  The columns of the next panel (and the
 // panel's own) are updated on the caller's stream, which then factors panel p+1 right away -- a chain of latency-bound
 // single-workgroup kernels -- while the device-filling update of everything to the right of it runs on `aux`.  Ordering:
@@ -648,6 +779,14 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
     const int64_t wrs = rowmajor ? nb : 1, wcs = rowmajor ? 1 : m;
     Mat Am = mat(A, rs, cs), Ym = mat(w.Y, yrs, ycs), Wqm = mat(w.Wq, yrs, ycs);
     int rc;
+    {   // two-level blocking for the plain factorisation of matrices with several outer blocks (TN_QR_NBO = 0 disables it)
+        const char* e_nbo = getenv("TN_QR_NBO");                      // read per call: the tests switch it
+        const int v_nbo = e_nbo ? atoi(e_nbo) : 256, nbo = (v_nbo == 128 || v_nbo == 256) ? v_nbo : 0;
+        if (nbo > 0 && nb == 32 && !(rank_tol > 0.0 && keff_host != nullptr) && k >= 2 * nbo && m >= 4 * nbo) {
+            if (keff_host) *keff_host = k;
+            return qr_two_level(st, Am, m, n, k, Ym, w, nbo, rs, cs, yrs, ycs, wrs, wcs, Q, qrs, qcs, R, rrs, rcs);
+        }
+    }
     thread_local LookaheadEvents ev;
     // worth it only when there is a wide part to overlap with (at least 4 panels) and the panel is tall enough to be slow
     const bool lookahead = aux != nullptr && aux != st && nb == 32 && P >= 4 && m >= 2048 && ev.init();
