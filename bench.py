@@ -135,6 +135,9 @@ def main():
     ap.add_argument('--sample', type=int, default=8,
                     help='in the timed region bracket every n-th launch of the dominant kernel family with events')
     ap.add_argument('--no-search', action='store_true', help='skip the (untimed) full ground-state search figure')
+    ap.add_argument('--nrot', type=int, default=4, help='lattice rotations of the instance (4 = the reference driver; fewer only for rehearsals)')
+    ap.add_argument('--rehearse-one-gpu', action='store_true',
+                    help='multi-rank rehearsal on a single GPU: every rank uses cuda:0 and the exchange runs over gloo')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group even with one rank (rehearses the multi-GPU code path on one GPU)')
     args = ap.parse_args()
@@ -152,6 +155,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.rehearse_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or args.force_dist:
@@ -159,7 +164,10 @@ def main():
         for k, v in (('RANK', '0'), ('WORLD_SIZE', '1'), ('MASTER_PORT', '29533')):
             os.environ.setdefault(k, v)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.rehearse_one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     import tnac4o_amd
     from tnac4o_amd import _lib, parallel
@@ -170,7 +178,7 @@ def main():
     inst_seed = seed + (rank if replicas else 0)
     J = synthetic_chimera(n, n, inst_seed) if kind == 'Ising' else synthetic_rmf(n, n, 8, inst_seed)
     kw = dict(graduate_truncation=True, Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
-    NROT = 4
+    NROT = max(1, min(4, args.nrot))
 
     def make(rot=0):
         if kind == 'Ising':
@@ -190,12 +198,12 @@ def main():
     # ---- who does what (sweep mode): teams of B = world / nteams consecutive ranks, rotations dealt round-robin to teams
     if replicas or world == 1:
         nteams, B, team, owner = 1, 1, 0, True
-        my_rots = list(range(max(1, args.concurrent))) if world == 1 else list(range(NROT))
+        my_rots = list(range(max(1, min(args.concurrent, NROT)))) if world == 1 else list(range(NROT))
         beam_group = None
     else:
         nteams = min(world, NROT)
         if world % nteams:
-            raise SystemExit('--gpus must be 1, 2, 4 or a multiple of 4')
+            raise SystemExit('--gpus must be 1, 2, 4 or a multiple of the number of rotations')
         B = world // nteams
         team, owner = rank // B, rank % B == 0
         my_rots = [r for r in range(NROT) if r % nteams == team]
@@ -239,7 +247,7 @@ def main():
     if not args.no_profile:
         dom_mask = mask_all if warm_prof is None else 1 << max(range(len(warm_prof)), key=lambda i: warm_prof[i]['ms'])
         if dist is not None and world > 1:          # every rank samples the family rank 0 found dominant
-            t = torch.tensor([dom_mask], dtype=torch.int64, device='cuda')
+            t = torch.tensor([dom_mask], dtype=torch.int64, device=parallel._comm_device(None))
             dist.broadcast(t, src=0)
             dom_mask = int(t.item())
         lib.tn_profile_reset()
@@ -261,7 +269,7 @@ def main():
         lib.tn_profile_enable(0)
         lib.tn_profile_sample(1)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device=parallel._comm_device(None))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps
