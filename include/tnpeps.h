@@ -165,10 +165,25 @@ int tn_balance(const double* A, int64_t rs, int64_t cs, int64_t n, double max_sc
  *                         R receives R^T (Dl x k).        k = min of the two matrix dimensions.
  *   C == NULL: no attach, A itself is factored and DESTROYED (kc ignored).  rank_tol / keff_host as in tn_qr.
  *   nf_out2 != NULL: when the factorisation ran to the end the triangular factor is divided by its nfactor and nf_out2 (device)
- *   = [nf, 1/nf]; *normalised_host tells whether that happened (it does not after an early exit: the caller slices first). */
+ *   = [nf, 1/nf]; *normalised_host tells whether that happened (it does not after an early exit: the caller slices first).
+ *   dropped2_host (HOST, may be NULL): squared Frobenius norm of the trailing block an early exit dropped (0 otherwise).
+ *   frobenius_exit = 1: the early exit compares the Frobenius norm of the trailing block with rank_tol x the Frobenius norm of
+ *   the input (instead of the largest column norms of the two). */
 int64_t tn_site_qr_ws_bytes(int side, int64_t Dl, int64_t p, int64_t Dr, int64_t kc, int attach);
 int tn_site_qr(int side, double* A, int64_t Dl, int64_t p, int64_t Dr, const double* C, int64_t kc, double* Q, double* R,
-               double rank_tol, int64_t* keff_host, double* nf_out2, int* normalised_host, void* ws, int64_t ws_bytes, void* stream);
+               double rank_tol, int64_t* keff_host, double* nf_out2, int* normalised_host, double* dropped2_host,
+               int frobenius_exit, void* ws, int64_t ws_bytes, void* stream);
+/* ---- helpers of the weighted rank-revealing first canonisation pass (tnac4o_amd/mps.py: canonise_right_weighted; no
+ * counterpart in the reference, whose first pass factors every site in full, mps.py:187):
+ * tn_gram_weights: from the Gram matrix G (n x n) of the unfactored part on the other side of a bond, the squared weight of
+ *   every bond index, d2[c] = max(G_cc, floor_rel max G), and stats2 = [ ||K||_F^2 with K = G / (d d^T), max_c G_cc ].
+ * tn_rows_norm2: out[r] = sum_c A[r,c]^2 for a row-major rows x cols matrix.
+ * tn_gather_scale_rows: inverse = 0: out[j,:] = sqrt(w2[perm[j]]) A[perm[j],:];  inverse = 1: out[perm[j],:] = A[j,:] / sqrt(w2[perm[j]])
+ *   (perm: int64 device vector). */
+int tn_gram_weights(const double* G, int64_t n, double floor_rel, double* d2_out, double* stats2_out, void* stream);
+int tn_rows_norm2(const double* A, int64_t rows, int64_t cols, double* out, void* stream);
+int tn_gather_scale_rows(const double* A, int64_t rows, int64_t cols, const int64_t* perm, const double* w2, double* out, int inverse,
+                         void* stream);
 /* out (c, s, c2) = RL (c x a) . A (a, s, a2) . RR (a2 x c2)      (MPS._mps_RAR, mps.py:748-751) */
 int64_t tn_rar_ws_bytes(int64_t c, int64_t a, int64_t s, int64_t a2, int64_t c2);
 int tn_rar(const double* RL, const double* A, const double* RR, int64_t c, int64_t a, int64_t s, int64_t a2, int64_t c2, double* out,

@@ -486,15 +486,16 @@ def test_fused_site_steps_bit_identical():
     from tnac4o_amd import ops
     kw = dict(graduate_truncation=True, Dmax=32, tolS=1e-16, tolV=1e-10, max_sweeps=20)
     res = []
-    saved = ops.FUSED_SITE
+    saved = ops.FUSED_SITE, ops.PASS1_WEIGHTED
     try:
+        ops.PASS1_WEIGHTED = False               # (the weighted first pass exists in the fused form only)
         for fused in (False, True):
             ops.FUSED_SITE = fused
             s = gpu_solver(L=512, rot=1)
             s._setup_rhoT(**kw)
             res.append(s)
     finally:
-        ops.FUSED_SITE = saved
+        ops.FUSED_SITE, ops.PASS1_WEIGHTED = saved
     a, b = res
     assert [m.D for m in a.rhoT] == [m.D for m in b.rhoT]
     assert a.rhoT_discarded == b.rhoT_discarded and a.rhoT_overlap == b.rhoT_overlap
@@ -529,3 +530,56 @@ def test_bench_sharded_step_rehearsal_four_ranks():
     s = tnac4o_amd.tnac4o(mode='Ising', Nx=4, Ny=4, Nc=8, J=synthetic_chimera(4, 4, 20260002), beta=3.0)
     s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=16)
     assert d['full_solve']['energy'] == pytest.approx(float(s.energy[0]), abs=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('L,chi', [(512, 32), (2048, 64)])
+def test_weighted_first_pass_matches_plain_pass(L, chi):
+    """The weighted rank-revealing first canonisation pass (MPS.canonise_right_weighted) against the plain one (the
+    reference's `canonise_right()`, mps.py:187) on real sweeps: the a-posteriori bound on the relative change of the state
+    holds without fallbacks (<= 2^-56), the compressed boundary MPS are the same states (fidelity 1 - 1e-13), overlaps and
+    discarded weights agree, and the pass really shrinks the bonds."""
+    from tnac4o_amd import ops, mps
+    kw = dict(graduate_truncation=True, Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
+    bounds, bonds = [], []
+    orig = mps.MPS.canonise_right_weighted
+
+    def spy(self):
+        full = sum(self.D)
+        ok = orig(self)
+        bounds.append((ok, self.reveal_error_bound))
+        bonds.append((full, sum(self.D)))
+        return ok
+    res = []
+    saved = ops.PASS1_WEIGHTED, os.environ.get('TN_QR_NBO')
+    mps.MPS.canonise_right_weighted = spy
+    try:
+        # plain pass twice (two-level and single-level QR blocking: a pure rounding-level change), then the weighted pass
+        for weighted, nbo in ((False, '256'), (False, '0'), (True, '256')):
+            ops.PASS1_WEIGHTED = weighted
+            os.environ['TN_QR_NBO'] = nbo
+            # L=512: droplet #1;  L=2048: the synthetic instance bench.py times
+            from tnac4o_amd.auxx import synthetic_chimera
+            s = gpu_solver(L=L, rot=0) if L == 512 else gpu_solver(L=L, J=synthetic_chimera(16, 16, 20260004))
+            s._setup_rhoT(**kw)
+            res.append(s)
+    finally:
+        ops.PASS1_WEIGHTED = saved[0]
+        if saved[1] is None:
+            os.environ.pop('TN_QR_NBO', None)
+        else:
+            os.environ['TN_QR_NBO'] = saved[1]
+        mps.MPS.canonise_right_weighted = orig
+    a, a2, b = res
+    assert bounds and all(ok and 0.0 <= e <= 2.0 ** -57 for ok, e in bounds)
+    print('bond sums before / after the weighted pass:', bonds)
+    if L == 2048:
+        assert sum(got for _, got in bonds) < 0.75 * sum(full for full, _ in bonds)   # the pass really shrinks the bonds
+    np.testing.assert_allclose(np.array(a.rhoT_overlap, dtype=float), np.array(b.rhoT_overlap, dtype=float), rtol=0, atol=1e-12)
+    # discarded weights: 1e-6 relative, or 10x what the plain pass itself moves under the rounding-level change of its QR blocking
+    # (deep rows of a chi=64 sweep amplify rounding: single rows move by tens of per cent between the two plain runs)
+    da, da2, db = (np.array(x.rhoT_discarded, dtype=float) for x in (a, a2, b))
+    assert np.all(np.abs(db - da) <= 1e-14 + 1e-6 * da + 10.0 * np.abs(da2 - da)), (da, da2, db)
+    for x, x2, y in zip(a.rhoT, a2.rhoT, b.rhoT):
+        spread = 1.0 - fidelity(host_chain(x), host_chain(x2))
+        assert 1.0 - fidelity(host_chain(x), host_chain(y)) < 1e-13 + 10.0 * max(spread, 0.0)

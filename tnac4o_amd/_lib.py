@@ -47,7 +47,11 @@ SIGNATURES = {
     'tn_peps_factor': (_int, [_ptr] * 9 + [_i64] * 3 + [_ptr, _ptr]),
     'tn_mpo_from_factor': (_int, [_ptr] * 3 + [_i64] * 5 + [_ptr, _ptr]),
     'tn_site_qr_ws_bytes': (_i64, [_int, _i64, _i64, _i64, _i64, _int]),
-    'tn_site_qr': (_int, [_int, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _f64, C.POINTER(_i64), _ptr, C.POINTER(_int), _ptr, _i64, _ptr]),
+    'tn_site_qr': (_int, [_int, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _f64, C.POINTER(_i64), _ptr, C.POINTER(_int), C.POINTER(_f64),
+                   _int, _ptr, _i64, _ptr]),
+    'tn_gram_weights': (_int, [_ptr, _i64, _f64, _ptr, _ptr, _ptr]),
+    'tn_rows_norm2': (_int, [_ptr, _i64, _i64, _ptr, _ptr]),
+    'tn_gather_scale_rows': (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _int, _ptr]),
     'tn_rar_ws_bytes': (_i64, [_i64] * 5),
     'tn_rar': (_int, [_ptr, _ptr, _ptr] + [_i64] * 5 + [_ptr, _ptr, _i64, _ptr]),
     'tn_env_mix_ws_bytes': (_i64, [_int] + [_i64] * 5),
@@ -101,7 +105,7 @@ def _stale(L):
 SHORT_CALLS = ('tn_gemm', 'tn_gemm_ws_bytes', 'tn_qr_ws_bytes', 'tn_svd_ws_bytes', 'tn_absorb', 'tn_nfactor', 'tn_scale_by',
                'tn_normalize_pow2', 'tn_scale_phys', 'tn_calc_pn', 'tn_nfactor_batched', 'tn_env_rr_batched', 'tn_env_rl_batched',
                'tn_balance', 'tn_svdvals_async', 'tn_rar', 'tn_rar_ws_bytes', 'tn_env_mix', 'tn_env_mix_ws_bytes',
-               'tn_apply_truncation', 'tn_apply_truncation_ws_bytes', 'tn_site_qr_ws_bytes', 'tn_peps_factor', 'tn_mpo_from_factor', 'tn_last_error')
+               'tn_apply_truncation', 'tn_apply_truncation_ws_bytes', 'tn_site_qr_ws_bytes', 'tn_gram_weights', 'tn_rows_norm2', 'tn_gather_scale_rows', 'tn_peps_factor', 'tn_mpo_from_factor', 'tn_last_error')
 _lib = None
 ABI_VERSION = 2          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
 

@@ -758,8 +758,9 @@ struct LookaheadEvents {
 
 int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
               int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
-              int64_t* keff_host, hipStream_t aux) {
+              int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit) {
     TN_CHECK_ARG(m >= 1 && n >= 1, "empty matrix");
+    if (dropped2_host) *dropped2_host = 0.0;
     TN_CHECK_ARG(nb == 32 || nb == 64, "nb must be 32 or 64");
     TN_CHECK_ARG(ws_bytes >= qr_ws_bytes(m, n, nb), "workspace too small");
     QrWs w;
@@ -886,14 +887,20 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
                 return hip_fail(e, "memcpy norms");
             if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync norms");
             const double* tr2 = hcn.data();
+            // measure of "what is left" against the input: largest column norm (default) or, frob_exit, the Frobenius norm
             if (scale2 < 0.0) {
                 scale2 = 0.0;
-                for (int64_t j = 0; j < n; ++j) scale2 = std::max(scale2, hcn[j]);
+                for (int64_t j = 0; j < n; ++j) scale2 = frob_exit ? scale2 + hcn[j] : std::max(scale2, hcn[j]);
                 tr2 = hcn.data() + n;
             }
             double h[2] = {scale2, 0.0};
-            for (int64_t j = 0; j < nt; ++j) h[1] = std::max(h[1], tr2[j]);
+            for (int64_t j = 0; j < nt; ++j) h[1] = frob_exit ? h[1] + tr2[j] : std::max(h[1], tr2[j]);
             if (h[1] <= rank_tol * rank_tol * scale2) {       // nothing left above the threshold: stop here
+                if (dropped2_host) {                           // squared Frobenius norm of the block that is dropped
+                    double fro2 = 0.0;
+                    for (int64_t j = 0; j < nt; ++j) fro2 += tr2[j];
+                    *dropped2_host = fro2;
+                }
                 k = j1;
                 P = p + 1;
                 break;

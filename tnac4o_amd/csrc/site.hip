@@ -13,7 +13,7 @@
 namespace tn {
 
 int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
-              void*, int64_t, double, int64_t*, hipStream_t);
+              void*, int64_t, double, int64_t*, hipStream_t, double* dropped2_host = nullptr, int frob_exit = 0);
 int64_t qr_ws_bytes(int64_t, int64_t, int);
 int normalize_pow2(hipStream_t, double*, int64_t, double*, void*, int64_t);
 
@@ -41,7 +41,8 @@ int64_t site_qr_ws_bytes(int side, int64_t Dl, int64_t p, int64_t Dr, int64_t kc
 }
 
 int site_qr(hipStream_t st, int side, double* A, int64_t Dl, int64_t p, int64_t Dr, const double* C, int64_t kc, double* Q, double* R,
-            double rank_tol, int64_t* keff_host, double* nf_out2, int* normalised_host, void* ws, int64_t ws_bytes) {
+            double rank_tol, int64_t* keff_host, double* nf_out2, int* normalised_host, void* ws, int64_t ws_bytes,
+            double* dropped2_host, int frob_exit) {
     TN_CHECK_ARG(side == 0 || side == 1, "side must be 0 (left sweep) or 1 (right sweep)");
     TN_CHECK_ARG(Dl >= 1 && p >= 1 && Dr >= 1 && (C == nullptr || kc >= 1), "non-positive dimension");
     const bool attach = C != nullptr;
@@ -69,9 +70,9 @@ int site_qr(hipStream_t st, int side, double* A, int64_t Dl, int64_t p, int64_t 
         const double dm = (double)d.m, dn = (double)d.k;
         prof_note(PROF_QR_NOMINAL, 1, 4.0 * dm * dn * dn - 4.0 / 3.0 * dn * dn * dn, 8.0 * (2.0 * dm * dn + dn * dn));
         if (side == 0)      // M (m x n) row-major; Q (m x k) row-major; R (k x n) row-major
-            rc = qr_factor(st, M, d.n, 1, d.m, d.n, Q, d.k, 1, R, d.n, 1, 32, qw, qws, rank_tol, &keff, nullptr);
+            rc = qr_factor(st, M, d.n, 1, d.m, d.n, Q, d.k, 1, R, d.n, 1, 32, qw, qws, rank_tol, &keff, nullptr, dropped2_host, frob_exit);
         else                // the (p r) x Dl view of the row-major (Dl, p r) array; Q = Qt^T, R = Ct^T
-            rc = qr_factor(st, M, 1, d.m, d.m, d.n, Q, 1, d.m, R, 1, d.k, 32, qw, qws, rank_tol, &keff, nullptr);
+            rc = qr_factor(st, M, 1, d.m, d.m, d.n, Q, 1, d.m, R, 1, d.k, 32, qw, qws, rank_tol, &keff, nullptr, dropped2_host, frob_exit);
     }
     if (rc) return rc;
     if (keff_host) *keff_host = keff;
@@ -151,6 +152,98 @@ int apply_truncation(hipStream_t st, const double* Al, int64_t ml, int64_t k0, c
     if ((rc = gemm(st, keep, nr, k1, 1.0, Vt, vrs, vcs, Ar, nr, 1, 0.0, Ar_new, nr, 1, 1, 0, 0, 0, g2 > 0 ? (double*)ws : nullptr, g2))) return rc;
     TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(diag_from_vec_kernel, dim3((unsigned)cdiv(keep * keep, 256)), dim3(256), 0, st, S, keep, Cdiag));
     TN_CHECK_LAUNCH("diag_from_vec_kernel");
+    return 0;
+}
+
+// ---- weights of a bond from the Gram matrix of the unfactored part on its other side (rank-revealing first pass) -----------
+// G (n x n, row-major): Gram matrix of the part of MPO.psi left of a bond with respect to that bond's index (any positive
+// overall scale).  d2[c] = max(G_cc, floor_rel * max_c G_cc): squared weight of index c, floored so that entries the recursion
+// cannot resolve are over- rather than underestimated; stats[0] = sum_{c,c'} (G_cc' / (d_c d_c'))^2, the squared Frobenius norm
+// of the scaled Gram matrix K (lambda_max(K) <= ||K||_F bounds the operator norm of the scaled left part), stats[1] = max G_cc.
+__global__ __launch_bounds__(256) void gram_weights_kernel(const double* __restrict__ G, int n, double floor_rel, double* __restrict__ d2,
+                                                           double* __restrict__ stats) {
+    __shared__ double red[256];
+    __shared__ double gmax;
+    const int tid = threadIdx.x;
+    double m = 0.0;
+    for (int c = tid; c < n; c += 256) m = fmax(m, G[(int64_t)c * n + c]);
+    red[tid] = m;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] = fmax(red[tid], red[tid + k]); __syncthreads(); }
+    if (tid == 0) gmax = red[0];
+    __syncthreads();
+    const double fl = gmax * floor_rel;
+    for (int c = tid; c < n; c += 256) d2[c] = fmax(G[(int64_t)c * n + c], fl);
+    __syncthreads();
+    double s = 0.0;
+    for (int64_t e = tid; e < (int64_t)n * n; e += 256) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        const double g = G[e];
+        s += g * g / (fmax(G[(int64_t)i * n + i], fl) * fmax(G[(int64_t)j * n + j], fl));
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+    if (tid == 0) { stats[0] = red[0]; stats[1] = gmax; }
+}
+int gram_weights(hipStream_t st, const double* G, int64_t n, double floor_rel, double* d2, double* stats) {
+    TN_CHECK_ARG(n >= 1 && n <= 65536 && floor_rel >= 0.0, "bad arguments");
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(gram_weights_kernel, dim3(1), dim3(256), 0, st, G, (int)n, floor_rel, d2, stats));
+    TN_CHECK_LAUNCH("gram_weights_kernel");
+    return 0;
+}
+
+// out[r] = sum_c A[r, c]^2  (rows of a row-major rows x cols matrix), one workgroup per row
+__global__ __launch_bounds__(256) void rows_norm2_kernel(const double* __restrict__ A, int64_t cols, double* __restrict__ out) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const double* a = A + (int64_t)blockIdx.x * cols;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t c = tid;
+    for (; c + 256 < cols; c += 512) { const double x = a[c], y = a[c + 256]; s0 += x * x; s1 += y * y; }
+    for (; c < cols; c += 256) { const double x = a[c]; s0 += x * x; }
+    double s = s0 + s1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+int rows_norm2(hipStream_t st, const double* A, int64_t rows, int64_t cols, double* out) {
+    if (rows <= 0) return 0;
+    TN_CHECK_ARG(cols >= 1 && rows < 2147483647LL, "bad dimensions");
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(rows_norm2_kernel, dim3((unsigned)rows), dim3(256), 0, st, A, cols, out));
+    TN_CHECK_LAUNCH("rows_norm2_kernel");
+    return 0;
+}
+
+// out[j, :] = sqrt(w2[perm[j]]) * A[perm[j], :]      (gather + scale of the rows of a row-major rows x cols matrix)
+__global__ __launch_bounds__(256) void gather_scale_rows_kernel(const double* __restrict__ A, int64_t cols, const int64_t* __restrict__ perm,
+                                                                const double* __restrict__ w2, double* __restrict__ out) {
+    const int64_t src = perm[blockIdx.x];
+    const double sc = sqrt(w2[src]);
+    const double* a = A + src * cols;
+    double* o = out + (int64_t)blockIdx.x * cols;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) o[c] = sc * a[c];
+}
+// out[perm[j], :] = Cp[j, :] / sqrt(w2[perm[j]])     (inverse of the above on the small triangular factor, rows x cols row-major)
+__global__ __launch_bounds__(256) void scatter_unscale_rows_kernel(const double* __restrict__ Cp, int64_t cols, const int64_t* __restrict__ perm,
+                                                                   const double* __restrict__ w2, double* __restrict__ out) {
+    const int64_t dst = perm[blockIdx.x];
+    const double inv = 1.0 / sqrt(w2[dst]);
+    const double* a = Cp + (int64_t)blockIdx.x * cols;
+    double* o = out + dst * cols;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) o[c] = a[c] * inv;
+}
+int gather_scale_rows(hipStream_t st, const double* A, int64_t rows, int64_t cols, const int64_t* perm, const double* w2, double* out,
+                      int inverse) {
+    if (rows <= 0 || cols <= 0) return 0;
+    TN_CHECK_ARG(rows < 2147483647LL, "too many rows");
+    if (inverse)
+        TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(scatter_unscale_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, A, cols, perm, w2, out));
+    else
+        TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(gather_scale_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, A, cols, perm, w2, out));
+    TN_CHECK_LAUNCH("gather_scale_rows_kernel");
     return 0;
 }
 

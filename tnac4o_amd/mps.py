@@ -12,6 +12,10 @@ import torch
 from . import ops
 
 EPS = float(np.finfo(np.float64).eps)
+# weighted rank-revealing first canonisation pass (MPS.canonise_right_weighted)
+PASS1_ACCEPT = 2.0 ** -56        # accepted a-posteriori bound on the relative change of the state (the SVD's deflation level)
+PASS1_FLOOR = 1e-14              # squared weights are floored at this fraction of the largest (what fp64 Gram sums resolve)
+PASS1_MIN_BOND = 256             # bonds narrower than this are factored in full (nothing to gain)
 
 
 def _dev():
@@ -292,6 +296,7 @@ class MPS:
         Qt, Ct, k, nf = ops.site_qr(1, self.A[n], Cm, rank_tol)
         self._nfs.append(nf)
         if Ct.shape == (1, 1):
+            self._c11 = Ct                       # the normalised 1 x 1 centre (its value enters the state norm of the pass)
             Ct = torch.ones_like(Ct)
         self.A[n] = Qt.view(k, self.A[n].shape[1], -1)
         self.C = Ct
@@ -350,6 +355,89 @@ class MPS:
             if compress:
                 self.truncateC(Dmax, tol)
         self.R[-1] = None
+
+    def canonise_right_weighted(self):
+        """The first (non-truncating) pass of compress_mps -- `canonise_right()` at mps.py:187 -- with a rank-revealing
+        early exit made rigorous by a diagonal gauge.  Returns True when the error bound below holds (the caller falls back
+        to the plain pass otherwise; it keeps the input tensors).
+
+        The absorbed MPS has bonds of 1024 with a Schmidt rank of ~100 at 2^-56, but while sweeping right to left the part
+        LEFT of the site is not canonical, so a column of the site matrix that looks negligible may still carry weight
+        (dropping by plain norms moved log2 P by 3e-7 in round 1).  The weight of left-bond index c is the norm of the
+        left part restricted to it, d_c = sqrt(G_L[c,c]), with G_L the Gram matrix of the left part -- obtained for every
+        bond by two GEMMs per site from the absorbed tensors (left to right, before the pass; carried through the last
+        site it also gives the norm of the whole state).  At site n the matrix M_n (left bond x (phys, right bond)) is
+        scaled row-wise by d and its rows are sorted by decreasing weighted norm; tn_qr factors that matrix and stops once
+        the Frobenius norm of the trailing block is below the threshold worked out below.  In the scaled gauge the left
+        part L' = L diag(1/d) has unit columns, so dropping a block E changes the state by at most ||L'||_2 ||E||_F with
+        ||L'||_2^2 = lambda_max(K) <= ||K||_F, K = G_L / (d d^T) (tn_gram_weights).  The norm N_n of the state in the units
+        of step n is ||psi|| divided by the power-of-two factors of the sites already done, so the threshold of site n is
+        set to  (2^-57 / #sites) N_n / (sqrt(g_n) ||K_n||_F^(1/2))  (g_n: scale removed from G_L(n)), i.e. every site may
+        change the state by 2^-57 / #sites of its norm, 2^-57 in total -- below the level (2^-56) at which the Jacobi SVD of
+        the next pass deflates.  The sum of the actual bounds is re-checked from the dropped norms tn_qr reports.
+        Host synchronisations: one before the pass, one small read-back per weighted site."""
+        L = self.L
+        T = self.A
+        dev = T[0].device
+        # Gram matrices of the left part, bond by bond (G_L(n) belongs to the left bond of site n; G_L(L) = ||psi||^2)
+        G = torch.ones((1, 1), dtype=torch.float64, device=dev)
+        weights = [None] * (L + 1)
+        gfac = [None] * (L + 1)                            # device [nf, 1/nf] removed from G_L when it was normalised
+        for n in range(L):
+            Dl, p, Dr = T[n].shape
+            X = ops.mm(G, T[n].view(Dl, p * Dr))
+            G = ops.mm(T[n].view(Dl * p, Dr).t(), X.view(Dl * p, Dr))
+            gfac[n + 1] = ops.normalize_pow2_(G)
+            if n + 1 < L and Dr >= PASS1_MIN_BOND:
+                weights[n + 1] = ops.gram_weights(G, PASS1_FLOOR)
+        used = [n for n in range(L) if weights[n] is not None]
+        if not used:
+            self.canonise_right()
+            self.reveal_error_bound = 0.0
+            return True
+        pack = torch.cat([gfac[m][:1] for m in range(1, L + 1)] + [G.reshape(1)] + [weights[n][1][:1] for n in used]).cpu().numpy()
+        logg = np.concatenate([[0.0], np.cumsum(np.log2(pack[:L]))])              # log2 of the scale removed up to bond n
+        log_psi = 0.5 * (logg[L] + np.log2(pack[L]))                               # log2 ||psi||
+        bound = {n: float(k2) ** 0.25 for n, k2 in zip(used, pack[L + 1:])}        # ||L'||_2 <= ||K||_F^(1/2)
+        budget = 2.0 ** -57 / len(used)
+        self.C = torch.ones((1, 1), dtype=torch.float64, device=dev)
+        self.pC = L
+        lognf_done, pending, err = 0.0, [], 0.0
+        for n in range(L - 1, -1, -1):
+            if weights[n] is None:
+                self._site_right(n, self.C, 0.0)
+                pending.append(self._nfs[-1])
+                continue
+            d2, _ = weights[n]
+            Dl, p, Dr = self.A[n].shape
+            r = self.C.shape[1]
+            A = ops.mm(self.A[n].view(Dl * p, Dr), self.C).view(Dl, p * r)          # M_n (attach_AC)
+            w = d2 * ops.rows_norm2(A)
+            host = torch.cat([w.sum().reshape(1)] + [f[:1] for f in pending]).cpu().numpy()       # the per-site read-back
+            lognf_done += float(np.sum(np.log2(host[1:])))
+            pending = []
+            logN = log_psi - lognf_done                                             # log2 of the state norm in this step's units
+            scale = 2.0 ** (0.5 * logg[n] - logN) * bound[n]                        # relative change of the state per unit ||E||_F
+            fro = float(np.sqrt(host[0]))
+            rel_tol = min(2.0 ** -40, max(1e-30, budget / (scale * fro))) if fro > 0.0 else 0.0
+            perm = torch.argsort(w, descending=True)                                # 1024 keys: index plumbing
+            B = ops.gather_scale_rows(A, perm, d2)
+            info = {}
+            Qt, Ctp, k, _ = ops.site_qr(1, B.view(Dl, p, r), None, rel_tol, normalise=False, info=info, frobenius_exit=True)
+            Ct = ops.gather_scale_rows(Ctp, perm, d2, inverse=True)                 # rows back in place, weights removed
+            self._nfs.append(ops.normalize_pow2_(Ct))
+            pending.append(self._nfs[-1])
+            self.A[n] = Qt.view(k, p, r)
+            self.C = Ct
+            self.D[n], self.D[n + 1] = k, r
+            self.pC = n
+            err += scale * float(np.sqrt(info['dropped2']))
+        self.R[-1] = None
+        self.reveal_error_bound = float(err)
+        if ops.PASS1_TRACE:
+            import sys
+            print('[pass1] D=%s err_bound=%.3e accept=%s' % (self.D, err, err <= PASS1_ACCEPT), file=sys.stderr, flush=True)
+        return bool(err <= PASS1_ACCEPT)
 
     # -- environments -------------------------------------------------------------------------------------
     @staticmethod
@@ -477,7 +565,14 @@ class MPS:
 
     def compress_mps(self, Dmax=np.inf, tolS=None, tolV=None, max_sweeps=4, graduate_truncation=True, verbose=False):
         """Truncate: SVD initialisation + variational sweeps (mps.py:175-200).  Returns the overlap <psi|phi>."""
-        self.canonise_right()
+        if ops.PASS1_WEIGHTED and ops.FUSED_SITE and max(self.D) >= 2 * PASS1_MIN_BOND:
+            keep = (list(self.A), list(self.D), list(self._nfs))
+            if not self.canonise_right_weighted():                   # bound not met: the plain pass on the kept input
+                self.A, self.D, self._nfs = list(keep[0]), list(keep[1]), list(keep[2])
+                self.reveal_fallbacks = getattr(self, 'reveal_fallbacks', 0) + 1
+                self.canonise_right()
+        else:
+            self.canonise_right()
         phi = self.copy()
         self.discarded = [0] * (self.L + 1)
         if graduate_truncation:

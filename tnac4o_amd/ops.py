@@ -319,6 +319,8 @@ def svdvals_async(Cm, out66, stream=None):
 
 # ---- fused site steps (csrc/site.hip) ------------------------------------------------------------------------------------
 FUSED_SITE = os.environ.get('TN_FUSED_SITE', '1') != '0'
+PASS1_WEIGHTED = os.environ.get('TN_PASS1_WEIGHTED', '1') != '0'     # weighted rank-revealing first canonisation pass (mps.py)
+PASS1_TRACE = os.environ.get('TN_PASS1_TRACE', '0') == '1'
 _wsq = {}
 
 
@@ -330,11 +332,13 @@ def _ws_query(name, *args):
     return v
 
 
-def site_qr(side, A, Cm=None, rank_tol=0.0):
+def site_qr(side, A, Cm=None, rank_tol=0.0, normalise=True, info=None, frobenius_exit=False):
     """One canonisation step in one call (tn_site_qr): attach the centre matrix Cm (side 0: Cm . A, side 1: A . Cm; None = no
     attach, A is consumed), QR with diag(R) >= 0, power-of-two normalisation of the triangular factor.
     side 0 returns (Q (l p x k), R (k x Dr), k, nf);  side 1 returns (Q^T (k x p r), R^T (Dl x k), k, nf), nf = device [nf, 1/nf].
-    After a rank-revealing early exit (k below the full rank) the factors are sliced and normalised here."""
+    After a rank-revealing early exit (k below the full rank) the factors are sliced and normalised here.
+    normalise=False leaves the triangular factor as it is (nf = None); `info` (dict) receives 'dropped2', the squared
+    Frobenius norm of the trailing block an early exit dropped."""
     Dl, p, Dr = A.shape
     attach = Cm is not None
     kc = (Cm.shape[0] if side == 0 else Cm.shape[1]) if attach else 0
@@ -350,18 +354,51 @@ def site_qr(side, A, Cm=None, rank_tol=0.0):
     nf = torch.empty(2, dtype=torch.float64, device=dev)
     wsb = _ws_query('tn_site_qr_ws_bytes', side, Dl, p, Dr, kc, 1 if attach else 0)
     ws = workspace(wsb, 0)
-    keff, normd = C.c_int64(kf), C.c_int(0)
+    keff, normd, drop2 = C.c_int64(kf), C.c_int(0), C.c_double(0.0)
     check(lib().tn_site_qr(side, A.data_ptr(), Dl, p, Dr, Cm.data_ptr() if attach else None, kc, Q.data_ptr(), R.data_ptr(),
-                           float(rank_tol), C.byref(keff), nf.data_ptr(), C.byref(normd), ws.data_ptr(), wsb, _stream()))
+                           float(rank_tol), C.byref(keff), nf.data_ptr() if normalise else None, C.byref(normd), C.byref(drop2),
+                           1 if frobenius_exit else 0, ws.data_ptr(), wsb, _stream()))
     k = int(keff.value)
+    if info is not None:
+        info['dropped2'] = float(drop2.value)
     if k < kf:
         if side == 0:
             Q, R = Q[:, :k].contiguous(), R[:k].contiguous()
         else:
             Q, R = Q[:k].contiguous(), R[:, :k].contiguous()
-    if not normd.value:
+    if not normalise:
+        nf = None
+    elif not normd.value:
         nf = normalize_pow2_(R)
     return Q, R, k, nf
+
+
+def gram_weights(G, floor_rel):
+    """(d2, stats) of tn_gram_weights: floored squared weights of a bond's indices from the Gram matrix of the part on its
+    other side, and [ ||K||_F^2, max G_cc ] (device tensors)."""
+    n = G.shape[0]
+    assert G.is_contiguous() and G.shape == (n, n)
+    d2 = torch.empty(n, dtype=torch.float64, device=G.device)
+    st = torch.empty(2, dtype=torch.float64, device=G.device)
+    check(lib().tn_gram_weights(G.data_ptr(), n, float(floor_rel), d2.data_ptr(), st.data_ptr(), _stream()))
+    return d2, st
+
+
+def rows_norm2(A2d):
+    """Squared norms of the rows of a contiguous 2-D tensor (tn_rows_norm2)."""
+    assert A2d.is_contiguous() and A2d.dim() == 2
+    out = torch.empty(A2d.shape[0], dtype=torch.float64, device=A2d.device)
+    check(lib().tn_rows_norm2(A2d.data_ptr(), A2d.shape[0], A2d.shape[1], out.data_ptr(), _stream()))
+    return out
+
+
+def gather_scale_rows(A2d, perm, w2, inverse=False):
+    """inverse=False: out[j] = sqrt(w2[perm[j]]) A2d[perm[j]];  inverse=True: out[perm[j]] = A2d[j] / sqrt(w2[perm[j]])."""
+    assert A2d.is_contiguous() and perm.dtype == torch.int64 and perm.is_contiguous() and w2.is_contiguous()
+    out = torch.empty_like(A2d)
+    check(lib().tn_gather_scale_rows(A2d.data_ptr(), A2d.shape[0], A2d.shape[1], perm.data_ptr(), w2.data_ptr(), out.data_ptr(),
+                                     1 if inverse else 0, _stream()))
+    return out
 
 
 def rar(RL, A, RR):
