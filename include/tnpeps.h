@@ -176,11 +176,12 @@ int tn_site_qr(int side, double* A, int64_t Dl, int64_t p, int64_t Dr, const dou
 /* ---- helpers of the weighted rank-revealing first canonisation pass (tnac4o_amd/mps.py: canonise_right_weighted; no
  * counterpart in the reference, whose first pass factors every site in full, mps.py:187):
  * tn_gram_weights: from the Gram matrix G (n x n) of the unfactored part on the other side of a bond, the squared weight of
- *   every bond index, d2[c] = max(G_cc, floor_rel max G), and stats2 = [ ||K||_F^2 with K = G / (d d^T), max_c G_cc ].
+ *   every bond index, d2[c] = max(G_cc, floor_rel max G), and stats65 = [ 64 partial sums of ||K||_F^2 with K = G / (d d^T) (to be
+ *   added in order: reproducible bit for bit), max_c G_cc ].
  * tn_rows_norm2: out[r] = sum_c A[r,c]^2 for a row-major rows x cols matrix.
  * tn_gather_scale_rows: inverse = 0: out[j,:] = sqrt(w2[perm[j]]) A[perm[j],:];  inverse = 1: out[perm[j],:] = A[j,:] / sqrt(w2[perm[j]])
  *   (perm: int64 device vector). */
-int tn_gram_weights(const double* G, int64_t n, double floor_rel, double* d2_out, double* stats2_out, void* stream);
+int tn_gram_weights(const double* G, int64_t n, double floor_rel, double* d2_out, double* stats65_out, void* stream);
 int tn_rows_norm2(const double* A, int64_t rows, int64_t cols, double* out, void* stream);
 int tn_gather_scale_rows(const double* A, int64_t rows, int64_t cols, const int64_t* perm, const double* w2, double* out, int inverse,
                          void* stream);

@@ -274,9 +274,9 @@ int tn_site_qr(int side, double* A, int64_t Dl, int64_t p, int64_t Dr, const dou
     return site_qr(ST, side, A, Dl, p, Dr, C, kc, Q, R, rank_tol, keff_host, nf_out2, normalised_host, ws, ws_bytes, dropped2_host,
                    frobenius_exit);
 }
-int tn_gram_weights(const double* G, int64_t n, double floor_rel, double* d2_out, double* stats2_out, void* stream) {
-    TN_CHECK_ARG(G && d2_out && stats2_out, "null operand");
-    return gram_weights(ST, G, n, floor_rel, d2_out, stats2_out);
+int tn_gram_weights(const double* G, int64_t n, double floor_rel, double* d2_out, double* stats65_out, void* stream) {
+    TN_CHECK_ARG(G && d2_out && stats65_out, "null operand");
+    return gram_weights(ST, G, n, floor_rel, d2_out, stats65_out);
 }
 int tn_rows_norm2(const double* A, int64_t rows, int64_t cols, double* out, void* stream) {
     TN_CHECK_ARG(rows == 0 || (A && out), "null operand");

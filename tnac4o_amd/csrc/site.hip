@@ -158,10 +158,12 @@ int apply_truncation(hipStream_t st, const double* Al, int64_t ml, int64_t k0, c
 // ---- weights of a bond from the Gram matrix of the unfactored part on its other side (rank-revealing first pass) -----------
 // G (n x n, row-major): Gram matrix of the part of MPO.psi left of a bond with respect to that bond's index (any positive
 // overall scale).  d2[c] = max(G_cc, floor_rel * max_c G_cc): squared weight of index c, floored so that entries the recursion
-// cannot resolve are over- rather than underestimated; stats[0] = sum_{c,c'} (G_cc' / (d_c d_c'))^2, the squared Frobenius norm
-// of the scaled Gram matrix K (lambda_max(K) <= ||K||_F bounds the operator norm of the scaled left part), stats[1] = max G_cc.
-__global__ __launch_bounds__(256) void gram_weights_kernel(const double* __restrict__ G, int n, double floor_rel, double* __restrict__ d2,
-                                                           double* __restrict__ stats) {
+// cannot resolve are over- rather than underestimated; stats[0..63] = partial sums of sum_{c,c'} (G_cc' / (d_c d_c'))^2, the squared
+// Frobenius norm of the scaled Gram matrix K (lambda_max(K) <= ||K||_F bounds the operator norm of the scaled left part),
+// stats[64] = max G_cc.
+constexpr int GW_PARTS = 64;
+__global__ __launch_bounds__(256) void gram_diag_kernel(const double* __restrict__ G, int n, double floor_rel, double* __restrict__ d2,
+                                                        double* __restrict__ stats) {
     __shared__ double red[256];
     __shared__ double gmax;
     const int tid = threadIdx.x;
@@ -170,26 +172,36 @@ __global__ __launch_bounds__(256) void gram_weights_kernel(const double* __restr
     red[tid] = m;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] = fmax(red[tid], red[tid + k]); __syncthreads(); }
-    if (tid == 0) gmax = red[0];
+    if (tid == 0) { gmax = red[0]; stats[GW_PARTS] = red[0]; }
     __syncthreads();
     const double fl = gmax * floor_rel;
     for (int c = tid; c < n; c += 256) d2[c] = fmax(G[(int64_t)c * n + c], fl);
-    __syncthreads();
+}
+// part[b] = sum over the rows owned by block b of (G_ij)^2 / (d2_i d2_j): fixed assignment and fixed order inside a block, so the
+// figure is reproducible bit for bit (the caller adds the GW_PARTS partial sums in order)
+__global__ __launch_bounds__(256) void gram_kfro_kernel(const double* __restrict__ G, int n, const double* __restrict__ d2,
+                                                        double* __restrict__ part) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int rows_per = (n + GW_PARTS - 1) / GW_PARTS;
+    const int r0 = b * rows_per, r1 = (r0 + rows_per < n) ? r0 + rows_per : n;
     double s = 0.0;
-    for (int64_t e = tid; e < (int64_t)n * n; e += 256) {
-        const int i = (int)(e / n), j = (int)(e % n);
-        const double g = G[e];
-        s += g * g / (fmax(G[(int64_t)i * n + i], fl) * fmax(G[(int64_t)j * n + j], fl));
+    for (int i = r0; i < r1; ++i) {
+        const double ri = 1.0 / d2[i];
+        const double* g = G + (int64_t)i * n;
+        for (int j = tid; j < n; j += 256) { const double x = g[j]; s += x * x * ri / d2[j]; }
     }
     red[tid] = s;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
-    if (tid == 0) { stats[0] = red[0]; stats[1] = gmax; }
+    if (tid == 0) part[b] = red[0];
 }
 int gram_weights(hipStream_t st, const double* G, int64_t n, double floor_rel, double* d2, double* stats) {
     TN_CHECK_ARG(n >= 1 && n <= 65536 && floor_rel >= 0.0, "bad arguments");
-    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(gram_weights_kernel, dim3(1), dim3(256), 0, st, G, (int)n, floor_rel, d2, stats));
-    TN_CHECK_LAUNCH("gram_weights_kernel");
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(gram_diag_kernel, dim3(1), dim3(256), 0, st, G, (int)n, floor_rel, d2, stats));
+    TN_CHECK_LAUNCH("gram_diag_kernel");
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(gram_kfro_kernel, dim3(GW_PARTS), dim3(256), 0, st, G, (int)n, d2, stats));
+    TN_CHECK_LAUNCH("gram_kfro_kernel");
     return 0;
 }
 

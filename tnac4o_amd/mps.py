@@ -395,10 +395,11 @@ class MPS:
             self.canonise_right()
             self.reveal_error_bound = 0.0
             return True
-        pack = torch.cat([gfac[m][:1] for m in range(1, L + 1)] + [G.reshape(1)] + [weights[n][1][:1] for n in used]).cpu().numpy()
+        pack = torch.cat([gfac[m][:1] for m in range(1, L + 1)] + [G.reshape(1)] + [weights[n][1][:64] for n in used]).cpu().numpy()
         logg = np.concatenate([[0.0], np.cumsum(np.log2(pack[:L]))])              # log2 of the scale removed up to bond n
         log_psi = 0.5 * (logg[L] + np.log2(pack[L]))                               # log2 ||psi||
-        bound = {n: float(k2) ** 0.25 for n, k2 in zip(used, pack[L + 1:])}        # ||L'||_2 <= ||K||_F^(1/2)
+        kparts = pack[L + 1:].reshape(len(used), 64)
+        bound = {n: float(sum(float(x) for x in kparts[i])) ** 0.25 for i, n in enumerate(used)}       # ||L'||_2 <= ||K||_F^(1/2)
         budget = 2.0 ** -57 / len(used)
         self.C = torch.ones((1, 1), dtype=torch.float64, device=dev)
         self.pC = L

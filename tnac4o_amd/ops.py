@@ -375,11 +375,11 @@ def site_qr(side, A, Cm=None, rank_tol=0.0, normalise=True, info=None, frobenius
 
 def gram_weights(G, floor_rel):
     """(d2, stats) of tn_gram_weights: floored squared weights of a bond's indices from the Gram matrix of the part on its
-    other side, and [ ||K||_F^2, max G_cc ] (device tensors)."""
+    other side, and the 65 statistics [ 64 partial sums of ||K||_F^2, max G_cc ] (device tensors)."""
     n = G.shape[0]
     assert G.is_contiguous() and G.shape == (n, n)
     d2 = torch.empty(n, dtype=torch.float64, device=G.device)
-    st = torch.empty(2, dtype=torch.float64, device=G.device)
+    st = torch.empty(65, dtype=torch.float64, device=G.device)
     check(lib().tn_gram_weights(G.data_ptr(), n, float(floor_rel), d2.data_ptr(), st.data_ptr(), _stream()))
     return d2, st
 

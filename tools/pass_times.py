@@ -18,7 +18,7 @@ def timed(name, fn):
         r = fn(self, *a, **k)
         torch.cuda.synchronize()
         key = name
-        if name in ('canonise_left', 'canonise_right', 'variational_compress'):
+        if name in ('canonise_left', 'canonise_right', 'canonise_right_weighted', 'variational_compress'):
             state['pass'] += 1
             key = '%d %s%s' % (state['pass'], name, ' compress Dmax=%s' % k.get('Dmax') if k.get('compress') else '')
         acc[key] = acc.get(key, 0.0) + time.perf_counter() - t0
@@ -35,7 +35,7 @@ def compress(self, *a, **k):
 
 
 mps.MPS.compress_mps = compress
-for nm in ('canonise_left', 'canonise_right', 'variational_compress', 'apply_mpo', 'copy'):
+for nm in ('canonise_left', 'canonise_right', 'canonise_right_weighted', 'variational_compress', 'apply_mpo', 'copy'):
     setattr(mps.MPS, nm, timed(nm, getattr(mps.MPS, nm)))
 n = 16
 s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=synthetic_chimera(n, n, 20260004), beta=3.0)
