@@ -168,11 +168,15 @@ int tn_balance(const double* A, int64_t rs, int64_t cs, int64_t n, double max_sc
  *   = [nf, 1/nf]; *normalised_host tells whether that happened (it does not after an early exit: the caller slices first).
  *   dropped2_host (HOST, may be NULL): squared Frobenius norm of the trailing block an early exit dropped (0 otherwise).
  *   frobenius_exit = 1: the early exit compares the Frobenius norm of the trailing block with rank_tol x the Frobenius norm of
- *   the input (instead of the largest column norms of the two). */
+ *   the input (instead of the largest column norms of the two).
+ *   pivot_perm_host (HOST, n int64 with n = columns of the factored matrix, may be NULL): panel pivoting.  Before every panel
+ *   the residual norms of all remaining columns are read back; the factorisation stops when their Frobenius norm is below
+ *   rank_tol x the input's, otherwise the 32 columns with the largest residuals form the next panel.  The triangular factor
+ *   is returned in the pivoted column order; pivot_perm_host[j] = input column at position j. */
 int64_t tn_site_qr_ws_bytes(int side, int64_t Dl, int64_t p, int64_t Dr, int64_t kc, int attach);
 int tn_site_qr(int side, double* A, int64_t Dl, int64_t p, int64_t Dr, const double* C, int64_t kc, double* Q, double* R,
                double rank_tol, int64_t* keff_host, double* nf_out2, int* normalised_host, double* dropped2_host,
-               int frobenius_exit, void* ws, int64_t ws_bytes, void* stream);
+               int frobenius_exit, int64_t* pivot_perm_host, void* ws, int64_t ws_bytes, void* stream);
 /* ---- helpers of the weighted rank-revealing first canonisation pass (tnac4o_amd/mps.py: canonise_right_weighted; no
  * counterpart in the reference, whose first pass factors every site in full, mps.py:187):
  * tn_gram_weights: from the Gram matrix G (n x n) of the unfactored part on the other side of a bond, the squared weight of

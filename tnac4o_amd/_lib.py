@@ -48,7 +48,7 @@ SIGNATURES = {
     'tn_mpo_from_factor': (_int, [_ptr] * 3 + [_i64] * 5 + [_ptr, _ptr]),
     'tn_site_qr_ws_bytes': (_i64, [_int, _i64, _i64, _i64, _i64, _int]),
     'tn_site_qr': (_int, [_int, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _f64, C.POINTER(_i64), _ptr, C.POINTER(_int), C.POINTER(_f64),
-                   _int, _ptr, _i64, _ptr]),
+                   _int, C.POINTER(_i64), _ptr, _i64, _ptr]),
     'tn_gram_weights': (_int, [_ptr, _i64, _f64, _ptr, _ptr, _ptr]),
     'tn_rows_norm2': (_int, [_ptr, _i64, _i64, _ptr, _ptr]),
     'tn_gather_scale_rows': (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _int, _ptr]),

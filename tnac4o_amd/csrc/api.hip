@@ -20,7 +20,8 @@ const char* get_error() { return g_err; }
 int absorb(hipStream_t, const double*, const double*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int64_t,
            int64_t, int64_t, int64_t);
 int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
-              void*, int64_t, double, int64_t*, hipStream_t, double* dropped2_host = nullptr, int frob_exit = 0);
+              void*, int64_t, double, int64_t*, hipStream_t, double* dropped2_host = nullptr, int frob_exit = 0,
+              int64_t* pivot_perm_host = nullptr);
 int64_t qr_ws_bytes(int64_t, int64_t, int);
 int svd_trunc(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double, double*, int64_t, int64_t, double*,
               double*, int64_t, int64_t, int64_t*, double*, int*, int*, void*, int64_t);
@@ -44,7 +45,7 @@ int env_rl_batched(hipStream_t, const double*, const int32_t*, const int32_t*, i
 int balance(hipStream_t, const double*, int64_t, int64_t, int64_t, double, double*, int*);
 int64_t site_qr_ws_bytes(int, int64_t, int64_t, int64_t, int64_t, int);
 int site_qr(hipStream_t, int, double*, int64_t, int64_t, int64_t, const double*, int64_t, double*, double*, double, int64_t*, double*, int*,
-            void*, int64_t, double*, int);
+            void*, int64_t, double*, int, int64_t*);
 int gram_weights(hipStream_t, const double*, int64_t, double, double*, double*);
 int rows_norm2(hipStream_t, const double*, int64_t, int64_t, double*);
 int gather_scale_rows(hipStream_t, const double*, int64_t, int64_t, const int64_t*, const double*, double*, int);
@@ -267,12 +268,12 @@ int64_t tn_site_qr_ws_bytes(int side, int64_t Dl, int64_t p, int64_t Dr, int64_t
     return site_qr_ws_bytes(side, Dl, p, Dr, kc, attach);
 }
 int tn_site_qr(int side, double* A, int64_t Dl, int64_t p, int64_t Dr, const double* C, int64_t kc, double* Q, double* R, double rank_tol,
-               int64_t* keff_host, double* nf_out2, int* normalised_host, double* dropped2_host, int frobenius_exit, void* ws,
-               int64_t ws_bytes, void* stream) {
+               int64_t* keff_host, double* nf_out2, int* normalised_host, double* dropped2_host, int frobenius_exit,
+               int64_t* pivot_perm_host, void* ws, int64_t ws_bytes, void* stream) {
     TN_CHECK_ARG(A && Q && R && ws, "null operand");
     TN_CHECK_ARG(rank_tol >= 0.0 && rank_tol < 1.0, "rank_tol out of range");
     return site_qr(ST, side, A, Dl, p, Dr, C, kc, Q, R, rank_tol, keff_host, nf_out2, normalised_host, ws, ws_bytes, dropped2_host,
-                   frobenius_exit);
+                   frobenius_exit, pivot_perm_host);
 }
 int tn_gram_weights(const double* G, int64_t n, double floor_rel, double* d2_out, double* stats65_out, void* stream) {
     TN_CHECK_ARG(G && d2_out && stats65_out, "null operand");

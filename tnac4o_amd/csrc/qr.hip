@@ -57,6 +57,18 @@ static int fill_mat(hipStream_t st, double* D, int64_t drs, int64_t dcs, int64_t
     return 0;
 }
 
+// column swaps of a panel-pivoting step, applied in order to every row: A(r, pairs[2t]) <-> A(r, pairs[2t+1]), t = 0 .. npairs-1
+__global__ __launch_bounds__(256) void swap_columns_kernel(double* __restrict__ A, int64_t rs, int64_t cs, int64_t m,
+                                                           const int* __restrict__ pairs, int npairs) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    double* row = A + r * rs;
+    for (int t = 0; t < npairs; ++t) {
+        const int64_t i1 = pairs[2 * t], i2 = pairs[2 * t + 1];
+        if (i1 != i2) { const double x = row[i1 * cs]; row[i1 * cs] = row[i2 * cs]; row[i2 * cs] = x; }
+    }
+}
+
 __device__ __forceinline__ double hash_unit(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return ((double)(x >> 11) * (1.0 / 9007199254740992.0)) - 0.5;
@@ -758,7 +770,7 @@ struct LookaheadEvents {
 
 int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
               int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
-              int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit) {
+              int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host) {
     TN_CHECK_ARG(m >= 1 && n >= 1, "empty matrix");
     if (dropped2_host) *dropped2_host = 0.0;
     TN_CHECK_ARG(nb == 32 || nb == 64, "nb must be 32 or 64");
@@ -769,7 +781,14 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
     int P = (int)cdiv(k, nb);
     const int64_t kfull = k;
     double scale2 = -1.0;                                            // largest squared column norm of the input (lazily read back)
-    const bool reveal = rank_tol > 0.0 && keff_host != nullptr && P > 2 && nb == 32;
+    // Panel pivoting (pivot_perm_host != NULL; nb = 32, rank_tol > 0): before every panel the residual norms of all remaining
+    // columns are read back, the factorisation stops when their Frobenius norm is below rank_tol x the input's, otherwise the
+    // 32 columns with the largest residuals are swapped to the front and form the next panel (column-pivoted QR at panel
+    // granularity: a strong rank revealer at one extra read-back per panel).  pivot_perm_host[j] = input column now at j.
+    const bool pivot = pivot_perm_host != nullptr && rank_tol > 0.0 && keff_host != nullptr && nb == 32;
+    if (pivot_perm_host)
+        for (int64_t j = 0; j < n; ++j) pivot_perm_host[j] = j;
+    const bool reveal = !pivot && rank_tol > 0.0 && keff_host != nullptr && P > 2 && nb == 32;
     if (reveal) {
         TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_kernel, dim3((unsigned)n), dim3(256), 0, st, A, rs, cs, m, n, w.cn));
         TN_CHECK_LAUNCH("colnorm2_kernel");
@@ -805,6 +824,37 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         const int b = (int)((k - j0 < nb) ? k - j0 : nb);
         const int64_t mp = m - j0, ntr = n - j0;
         Mat Ap = sub(Am, j0, j0), Yp = sub(Ym, j0, j0);
+        if (pivot) {
+            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_kernel, dim3((unsigned)ntr), dim3(256), 0, st, Ap.p, rs, cs, mp, ntr, w.cn));
+            TN_CHECK_LAUNCH("colnorm2_kernel");
+            std::vector<double> hcn((size_t)ntr);
+            if ((he = hipMemcpyAsync(hcn.data(), w.cn, (size_t)ntr * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(he, "memcpy norms");
+            if ((he = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(he, "sync norms");
+            double fro2 = 0.0;
+            for (int64_t j = 0; j < ntr; ++j) fro2 += hcn[j];
+            if (p == 0) scale2 = fro2;
+            if (p > 0 && fro2 <= rank_tol * rank_tol * scale2) {     // what is left is below the threshold: stop before this panel
+                if (dropped2_host) *dropped2_host = fro2;
+                k = j0;
+                P = p;
+                break;
+            }
+            thread_local std::vector<int> pairs;              // outlives the asynchronous upload below
+            pairs.assign((size_t)2 * b, 0);
+            for (int t = 0; t < b; ++t) {                            // selection of the b largest residuals by successive swaps
+                int64_t arg = t;
+                for (int64_t j = t + 1; j < ntr; ++j)
+                    if (hcn[j] > hcn[arg]) arg = j;
+                std::swap(hcn[t], hcn[arg]);
+                std::swap(pivot_perm_host[j0 + t], pivot_perm_host[j0 + arg]);
+                pairs[2 * t] = (int)(j0 + t);
+                pairs[2 * t + 1] = (int)(j0 + arg);
+            }
+            int* dpairs = (int*)(w.cn + 2 * n) - 2 * nb;                 // the tail of the norms buffer (2n doubles) is free here
+            if ((he = hipMemcpyAsync(dpairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(he, "memcpy pairs");
+            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(swap_columns_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, A, rs, cs, m, dpairs, b));
+            TN_CHECK_LAUNCH("swap_columns_kernel");
+        }
         // --- panel orthonormalisation
         if (nb == 32) {
             if ((rc = tsqr_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes))) return rc;

@@ -13,7 +13,8 @@
 namespace tn {
 
 int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
-              void*, int64_t, double, int64_t*, hipStream_t, double* dropped2_host = nullptr, int frob_exit = 0);
+              void*, int64_t, double, int64_t*, hipStream_t, double* dropped2_host = nullptr, int frob_exit = 0,
+              int64_t* pivot_perm_host = nullptr);
 int64_t qr_ws_bytes(int64_t, int64_t, int);
 int normalize_pow2(hipStream_t, double*, int64_t, double*, void*, int64_t);
 
@@ -42,7 +43,7 @@ int64_t site_qr_ws_bytes(int side, int64_t Dl, int64_t p, int64_t Dr, int64_t kc
 
 int site_qr(hipStream_t st, int side, double* A, int64_t Dl, int64_t p, int64_t Dr, const double* C, int64_t kc, double* Q, double* R,
             double rank_tol, int64_t* keff_host, double* nf_out2, int* normalised_host, void* ws, int64_t ws_bytes,
-            double* dropped2_host, int frob_exit) {
+            double* dropped2_host, int frob_exit, int64_t* pivot_perm_host) {
     TN_CHECK_ARG(side == 0 || side == 1, "side must be 0 (left sweep) or 1 (right sweep)");
     TN_CHECK_ARG(Dl >= 1 && p >= 1 && Dr >= 1 && (C == nullptr || kc >= 1), "non-positive dimension");
     const bool attach = C != nullptr;
@@ -70,9 +71,9 @@ int site_qr(hipStream_t st, int side, double* A, int64_t Dl, int64_t p, int64_t 
         const double dm = (double)d.m, dn = (double)d.k;
         prof_note(PROF_QR_NOMINAL, 1, 4.0 * dm * dn * dn - 4.0 / 3.0 * dn * dn * dn, 8.0 * (2.0 * dm * dn + dn * dn));
         if (side == 0)      // M (m x n) row-major; Q (m x k) row-major; R (k x n) row-major
-            rc = qr_factor(st, M, d.n, 1, d.m, d.n, Q, d.k, 1, R, d.n, 1, 32, qw, qws, rank_tol, &keff, nullptr, dropped2_host, frob_exit);
+            rc = qr_factor(st, M, d.n, 1, d.m, d.n, Q, d.k, 1, R, d.n, 1, 32, qw, qws, rank_tol, &keff, nullptr, dropped2_host, frob_exit, pivot_perm_host);
         else                // the (p r) x Dl view of the row-major (Dl, p r) array; Q = Qt^T, R = Ct^T
-            rc = qr_factor(st, M, 1, d.m, d.m, d.n, Q, 1, d.m, R, 1, d.k, 32, qw, qws, rank_tol, &keff, nullptr, dropped2_host, frob_exit);
+            rc = qr_factor(st, M, 1, d.m, d.m, d.n, Q, 1, d.m, R, 1, d.k, 32, qw, qws, rank_tol, &keff, nullptr, dropped2_host, frob_exit, pivot_perm_host);
     }
     if (rc) return rc;
     if (keff_host) *keff_host = keff;

@@ -424,7 +424,10 @@ class MPS:
             perm = torch.argsort(w, descending=True)                                # 1024 keys: index plumbing
             B = ops.gather_scale_rows(A, perm, d2)
             info = {}
-            Qt, Ctp, k, _ = ops.site_qr(1, B.view(Dl, p, r), None, rel_tol, normalise=False, info=info, frobenius_exit=True)
+            Qt, Ctp, k, _ = ops.site_qr(1, B.view(Dl, p, r), None, rel_tol, normalise=False, info=info, frobenius_exit=True,
+                                        pivot=ops.PASS1_PIVOT)
+            if ops.PASS1_PIVOT:
+                perm = perm[info['perm']]                                           # sort order followed by the panel pivoting
             Ct = ops.gather_scale_rows(Ctp, perm, d2, inverse=True)                 # rows back in place, weights removed
             self._nfs.append(ops.normalize_pow2_(Ct))
             pending.append(self._nfs[-1])

@@ -320,6 +320,7 @@ def svdvals_async(Cm, out66, stream=None):
 # ---- fused site steps (csrc/site.hip) ------------------------------------------------------------------------------------
 FUSED_SITE = os.environ.get('TN_FUSED_SITE', '1') != '0'
 PASS1_WEIGHTED = os.environ.get('TN_PASS1_WEIGHTED', '1') != '0'     # weighted rank-revealing first canonisation pass (mps.py)
+PASS1_PIVOT = os.environ.get('TN_PASS1_PIVOT', '1') != '0'           # ... with panel pivoting inside tn_qr
 PASS1_TRACE = os.environ.get('TN_PASS1_TRACE', '0') == '1'
 _wsq = {}
 
@@ -332,7 +333,7 @@ def _ws_query(name, *args):
     return v
 
 
-def site_qr(side, A, Cm=None, rank_tol=0.0, normalise=True, info=None, frobenius_exit=False):
+def site_qr(side, A, Cm=None, rank_tol=0.0, normalise=True, info=None, frobenius_exit=False, pivot=False):
     """One canonisation step in one call (tn_site_qr): attach the centre matrix Cm (side 0: Cm . A, side 1: A . Cm; None = no
     attach, A is consumed), QR with diag(R) >= 0, power-of-two normalisation of the triangular factor.
     side 0 returns (Q (l p x k), R (k x Dr), k, nf);  side 1 returns (Q^T (k x p r), R^T (Dl x k), k, nf), nf = device [nf, 1/nf].
@@ -355,12 +356,15 @@ def site_qr(side, A, Cm=None, rank_tol=0.0, normalise=True, info=None, frobenius
     wsb = _ws_query('tn_site_qr_ws_bytes', side, Dl, p, Dr, kc, 1 if attach else 0)
     ws = workspace(wsb, 0)
     keff, normd, drop2 = C.c_int64(kf), C.c_int(0), C.c_double(0.0)
+    piv = (C.c_int64 * n)() if pivot else None               # panel pivoting: order of the factored matrix's columns
     check(lib().tn_site_qr(side, A.data_ptr(), Dl, p, Dr, Cm.data_ptr() if attach else None, kc, Q.data_ptr(), R.data_ptr(),
                            float(rank_tol), C.byref(keff), nf.data_ptr() if normalise else None, C.byref(normd), C.byref(drop2),
-                           1 if frobenius_exit else 0, ws.data_ptr(), wsb, _stream()))
+                           1 if frobenius_exit else 0, piv, ws.data_ptr(), wsb, _stream()))
     k = int(keff.value)
     if info is not None:
         info['dropped2'] = float(drop2.value)
+        if pivot:
+            info['perm'] = torch.as_tensor(np.frombuffer(piv, dtype=np.int64).copy()).to(A.device)
     if k < kf:
         if side == 0:
             Q, R = Q[:, :k].contiguous(), R[:k].contiguous()
