@@ -224,14 +224,20 @@ def main():
     # events on every kernel family (per-family / per-phase tables), (3) the W warm-up steps.  The timed steps then
     # bracket only the dominant family's launches with events, so the roofline duration is measured inside the timed
     # region at small overhead.
-    warm_prof, single_ms, single_prof_ms, phases = None, None, None, None
+    warm_prof, single_ms, single_prof_ms, phases, panel_stats = None, None, None, None, None
     mask_all = (1 << len(FAMILIES)) - 1
     if owner and rank == 0 and not args.no_profile and args.warmup > 0:
         torch.cuda.synchronize()
+        pst = (C.c_uint64 * 8)()
+        lib.tn_panel_stats(pst, 1)
         t0 = time.perf_counter()
         solver._setup_rhoT(**kw)
         torch.cuda.synchronize()
         single_ms = 1e3 * (time.perf_counter() - t0)
+        lib.tn_panel_stats(pst, 0)
+        panel_stats = {'panels': int(pst[0]), 'substitution_passes': int(pst[1]), 'deferred_pivots': int(pst[2]),
+                       'refilled_columns': int(pst[3]), 'householder_fallbacks': int(pst[4]),
+                       'what': 'iterated Cholesky-QR panel step (csrc/cholqr.hip) over the un-instrumented single-chain sweep'}
         lib.tn_profile_reset()
         lib.tn_profile_enable(mask_all)
         torch.cuda.synchronize()
@@ -381,6 +387,8 @@ def main():
             if ab['ms'] > 0:
                 out['absorb_hbm'] = {'achieved': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                      'frac': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        if panel_stats is not None:
+            out['panel_step'] = panel_stats
         if full is not None:
             out['full_solve'] = full
         if args.cpu_rows > 0 and world == 1 and kind == 'Ising' and solver is not None:

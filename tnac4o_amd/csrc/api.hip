@@ -70,7 +70,7 @@ using namespace tn;
 
 extern "C" {
 
-int tn_version(void) { return 2; }
+int tn_version(void) { return 3; }
 
 #ifndef TN_SRC_HASH
 #define TN_SRC_HASH "unknown"
@@ -141,6 +141,28 @@ int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, in
     return qr_factor(ST, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host, (hipStream_t)aux_stream);
 }
 int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_ws_bytes(m, n, nb); }
+
+int64_t tn_panel_orth_ws_bytes(int64_t nrows, int b) {
+    const int64_t a = tsqr_ws_bytes(nrows, b), c = cholqr_ws_bytes(nrows, b);
+    return a > c ? a : c;
+}
+int tn_panel_orth(const double* X, int64_t rs, int64_t cs, int64_t nrows, int b, double* Y, int64_t yrs, int64_t ycs, int method,
+                  int* state9_host, double* dev_host, void* ws, int64_t ws_bytes, void* stream) {
+    TN_CHECK_ARG(X && Y && ws, "null operand");
+    TN_CHECK_ARG(method == 0 || method == 1, "method must be 0 (Cholesky-QR) or 1 (Householder TSQR)");
+    TN_CHECK_ARG(ws_bytes >= tn_panel_orth_ws_bytes(nrows, b), "workspace too small");
+    ProfPhase ph(PH_QR);
+    if (method == 1) return tsqr_orthonormalize(ST, X, rs, cs, Y, yrs, ycs, nrows, b, ws, ws_bytes);
+    int rc = cholqr_reset(ST, ws);
+    if (rc) return rc;
+    if ((rc = cholqr_orthonormalize(ST, X, rs, cs, Y, yrs, ycs, nrows, b, ws, ws_bytes, 0x5DEECE66DULL))) return rc;
+    if (state9_host && dev_host) return cholqr_debug_state(ST, ws, state9_host, dev_host);
+    return 0;
+}
+int tn_panel_stats(uint64_t* out8_host, int reset) {
+    TN_CHECK_ARG(out8_host, "null output");
+    return cholqr_stats((unsigned long long*)out8_host, reset);
+}
 
 int tn_svd_trunc(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol, double* U,
                  int64_t urs, int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_host,

@@ -1,0 +1,609 @@
+// Panel orthonormalisation for the blocked QR (K3), second generation: iterated Cholesky-QR with deferral.
+//
+// tsqr.hip orthonormalises a tall nrows x b panel (b <= 32) with Householder TSQR: unconditionally stable, but every tree
+// level is a chain of 32 column steps of ~1.3 us in a single workgroup (3 levels x (41 + 22) us for 16384 rows).  Here
+// the serial part shrinks to the Cholesky factorisation of ONE 32 x 32 Gram matrix per pass, done by one wave:
+//
+//   pass 0 (cq_gram_kernel):   G = X^T X    (every workgroup: its 256 rows on the matrix cores; the last workgroup to finish
+//                               sums the per-block partials in block order -- bit-reproducible -- and factors G = R^T R)
+//   pass t (cq_pass_kernel):   X <- X R^-1  (row-parallel substitution), G = X^T X of the new panel, the last workgroup
+//                               decides: converged / one more pass / factor again.
+//
+// In exact arithmetic one pass suffices; in floating point the result is orthonormal to eps kappa(X)^2, so passes repeat
+// until the Gram matrix of the current panel is the identity to rounding (2 passes for kappa < 1e4, 3 otherwise).  What
+// makes it safe for the rank-deficient, graded panels of this path:
+//   * Cholesky is invariant under column scaling, so only the angles between columns matter;
+//   * deferral: a column whose pivot d_j falls below CQ_THETA of its squared norm (it lies in the span of the columns to its
+//     left to within 1e-5 of its norm, so d_j has lost most of its digits to cancellation) is not normalised by that pass
+//     and not used to reduce later columns (row j of R = e_j).  The substitution then leaves its exact residual, computed
+//     in vector arithmetic; the next pass sees that residual with its true norm and treats it as an ordinary column;
+//   * a column that is exactly zero (or whose square underflows) is refilled with hash noise: an arbitrary completion,
+//     exactly what a tau = 0 Householder reflector stands for;
+//   * the panel only has to be an orthonormal basis of span(X): the blocked QR takes R from H^T A (qr.hip), never from here.
+// If the panel is still not orthonormal after CQ_MAXPASS passes, the last workgroup of the last launch redoes it from the
+// untouched input with a plain (slow, single-workgroup) Householder QR: unconditional like tsqr.hip, never seen on the
+// contraction path so far (tn_debug_panel_stats counts it).
+//
+// Launches are plain stream-ordered kernels: nothing spins, nothing needs co-residency, so interleaved chains cannot
+// deadlock.  A launch that finds the panel converged returns at once (~3 us).
+#include "common.h"
+
+// -DTN_CLOCKS: thread 0 of the last workgroup of a launch records the 100 MHz wall clock at phase boundaries (diagnostics only)
+#ifdef TN_CLOCKS
+__device__ long long cq_clk[32];
+extern "C" int tn_debug_clocks2(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cq_clk), sizeof(long long) * (n < 32 ? n : 32));
+}
+#define CQ_CLK_DECL long long clk_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define CQ_CLK(k) do { if (threadIdx.x == 0) clk_[k] = wall_clock64(); } while (0)
+#define CQ_CLK_DUMP(base) do { if (threadIdx.x == 0) for (int q_ = 0; q_ < 12; ++q_) cq_clk[(base) + q_] = clk_[q_]; } while (0)
+#else
+#define CQ_CLK_DECL do {} while (0)
+#define CQ_CLK(k) do {} while (0)
+#define CQ_CLK_DUMP(base) do {} while (0)
+#endif
+
+namespace tn {
+
+typedef double d4c __attribute__((ext_vector_type(4)));
+
+constexpr int CQ_RB = 256;            // rows per workgroup
+constexpr int CQ_P = 33;              // LDS pitch of the row tile
+constexpr int CQ_PART = 768;          // per-block partial Gram: tiles (0,0), (0,1), (1,1) of 16 x 16
+constexpr int CQ_MAXPASS = 5;         // substitution passes enqueued per panel (later ones return at once when converged)
+constexpr double CQ_THETA = 1e-10;    // deferral threshold on pivot / squared column norm
+constexpr double CQ_DONE = 5e-15;     // Gram matrix = identity to rounding: converged
+constexpr double CQ_LAST = 1e-8;      // below this one more pass lands at rounding level without another check
+
+struct CqState {
+    int counter;          // arrival ticket of the workgroups of the launch in flight
+    int done;             // panel orthonormal: remaining launches return at once
+    int final_next;       // the next pass is the last one (no Gram / check after it)
+    int pass;             // passes applied so far
+    int emax;             // power-of-two exponent of the panel's largest entry (pass 0 scaling)
+    unsigned dead;        // columns to refill with noise in the next pass
+    int ndefer_total;     // statistics: deferred pivots, refills, Householder fallbacks of this panel
+    int nrefill_total;
+    int fallback;
+    double dev_hist[CQ_MAXPASS + 1];
+};
+constexpr int CQ_STATE_BYTES = 256;
+static_assert(sizeof(CqState) <= CQ_STATE_BYTES, "state block too small");
+
+__device__ __forceinline__ double cq_readlane(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double cq_rsqrt2(double x) {      // hardware seed (~2^-26) + two Newton steps
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
+}
+// acc -= a * b, pinned in program order: left to itself the compiler sinks the rank-1 updates of the unrolled factorisation
+// into 31-long dependent chains at the point of use and spills the multipliers it keeps alive for them
+__device__ __forceinline__ void cq_fnma(double& acc, double a, double b) {
+    asm volatile("v_fma_f64 %0, -%1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ double cq_hash_unit(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return ((double)(x >> 11) * (1.0 / 9007199254740992.0)) - 0.5;
+}
+__device__ __forceinline__ void cq_block_rows(int64_t nrows, int nblk, int blk, int64_t& r0, int& nr) {
+    const int64_t base = nrows / nblk, rem = nrows % nblk;
+    r0 = blk * base + (blk < rem ? blk : rem);
+    nr = (int)(base + (blk < rem ? 1 : 0));
+}
+
+// Partial Gram of the 256 x 32 LDS tile T (pitch CQ_P): wave w covers rows 64w .. 64w+63 on the matrix cores, the four
+// partials meet in LDS (T is overwritten: callers are done with it) and their sum goes to part[0 .. 767].
+__device__ __forceinline__ void cq_block_gram(double* __restrict__ T, double* __restrict__ part, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    d4c g00 = d4c{0, 0, 0, 0}, g01 = g00, g11 = g00;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int row = wave * 64 + ks * 4 + lk;
+        const double f0 = T[row * CQ_P + li], f1 = T[row * CQ_P + 16 + li];
+        g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, g00, 0, 0, 0);
+        g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, g01, 0, 0, 0);
+        g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, g11, 0, 0, 0);
+    }
+    __syncthreads();                                     // every wave has read its rows of T
+    double* sp = T + wave * CQ_PART;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = lk + 4 * r;
+        sp[i * 16 + li] = g00[r];
+        sp[256 + i * 16 + li] = g01[r];
+        sp[512 + i * 16 + li] = g11[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < CQ_PART; e += 256) part[e] = (T[e] + T[CQ_PART + e]) + (T[2 * CQ_PART + e] + T[3 * CQ_PART + e]);
+}
+
+__device__ __forceinline__ double cq_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int cq_ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// process-wide statistics (diagnostics): panels, passes applied, deferred pivots, refilled columns, Householder fallbacks
+__device__ unsigned long long cq_stats[8];
+
+// 256-thread sum through LDS (two barriers); red: >= 4 doubles
+__device__ __forceinline__ double cq_block_sum(double v, double* red, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Last resort, one workgroup: Householder QR of the whole panel in global memory (dgeqr2 + dorg2r, column by column).
+// Y <- 2^-emax X, reflectors in place, then the explicit Q in place.  Slow by design (one CU streams the panel ~100 times).
+__device__ void cq_fallback_householder(const double* X, int64_t xrs, int64_t xcs, double* Y, int64_t rs, int64_t cs, int64_t nrows, int b,
+                                        int emax, double* lds, int tid) {
+    double* red = lds;              // 4
+    double* wv = lds + 8;           // 32 dot products
+    double* taus = lds + 48;        // 32
+    const double scl = (emax > -2000) ? ldexp(1.0, -emax) : 0.0;
+    for (int64_t e = tid; e < nrows * b; e += 256) {
+        const int64_t i = e / b, j = e % b;
+        Y[i * rs + j * cs] = X[i * xrs + j * xcs] * scl;
+    }
+    __threadfence();
+    __syncthreads();
+    for (int j = 0; j < b; ++j) {
+        double s = 0.0;
+        for (int64_t r = j + 1 + tid; r < nrows; r += 256) { const double y = Y[r * rs + j * cs]; s += y * y; }
+        s = cq_block_sum(s, red, tid);
+        const double alpha = Y[j * rs + j * cs];
+        double tau = 0.0;
+        if (s > 1e-300) {                                   // dlarfg: nothing below the diagonal -> H = I
+            const double beta = -copysign(sqrt(alpha * alpha + s), alpha);
+            tau = (beta - alpha) / beta;
+            const double inv = 1.0 / (alpha - beta);
+            for (int64_t r = j + 1 + tid; r < nrows; r += 256) Y[r * rs + j * cs] *= inv;
+            __threadfence();
+            __syncthreads();
+            for (int c = j + 1; c < b; ++c) {
+                double w = 0.0;
+                for (int64_t r = j + 1 + tid; r < nrows; r += 256) w += Y[r * rs + j * cs] * Y[r * rs + c * cs];
+                w = cq_block_sum(w, red, tid);
+                if (tid == 0) wv[c] = tau * (w + Y[j * rs + c * cs]);
+                __syncthreads();
+                const double tw = wv[c];
+                for (int64_t r = j + 1 + tid; r < nrows; r += 256) Y[r * rs + c * cs] -= Y[r * rs + j * cs] * tw;
+                if (tid == 0) Y[j * rs + c * cs] -= tw;
+            }
+        }
+        if (tid == 0) taus[j] = tau;
+        __threadfence();
+        __syncthreads();
+    }
+    // dorg2r: Q = H_0 ... H_{b-1} [I; 0] in place
+    for (int j = b - 1; j >= 0; --j) {
+        const double tau = taus[j];
+        for (int c = j + 1; c < b; ++c) {                  // apply H_j to the columns already formed
+            double w = 0.0;
+            for (int64_t r = j + 1 + tid; r < nrows; r += 256) w += Y[r * rs + j * cs] * Y[r * rs + c * cs];
+            w = cq_block_sum(w, red, tid);
+            // row j of the columns formed so far is zero (they live in rows > j), so v^T q = w
+            const double tw = tau * w;
+            for (int64_t r = j + 1 + tid; r < nrows; r += 256) Y[r * rs + c * cs] -= Y[r * rs + j * cs] * tw;
+            if (tid == 0) Y[j * rs + c * cs] = -tw;
+            __threadfence();
+            __syncthreads();
+        }
+        for (int64_t r = j + 1 + tid; r < nrows; r += 256) Y[r * rs + j * cs] *= -tau;
+        if (tid == 0) Y[j * rs + j * cs] = 1.0 - tau;
+        for (int64_t r = tid; r < j; r += 256) Y[r * rs + j * cs] = 0.0;
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+// Tail of a launch, run by the last workgroup to arrive: sum the partial Gram matrices (block order, optional per-block
+// power-of-two weights), measure the distance from the identity, decide, and factor G = R^T R with deferral (wave 0).
+// Gs: LDS 32 x 33, Rs: LDS 32 x 32 (16-byte aligned).  pass = number of passes applied to the panel whose Gram matrix this is.  Returns 1 when the caller
+// has to run the Householder fallback (all threads get the same value).
+__device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int nblk, int b, int pass, CqState* stt, double* Rg, double* Gs,
+                                       double* Rs, int tid) {
+    __shared__ int s_dec;
+    const int lane = tid & 63;
+    // exponents of pass 0: block weights 4^(e_blk - emax); every wave finds emax itself (no barrier)
+    int emax = 0;
+    if (bexp) {
+        int e = -100000;
+        for (int i = lane; i < nblk; i += 64) { const int x = cq_ldi(bexp + i); e = x > e ? x : e; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(e, o, 64); e = y > e ? y : e; }
+        emax = e;
+    }
+    {   // thread tid sums entries tid, tid + 256, tid + 512 over the blocks, in block order; 48 loads in flight per thread
+        double acc[3] = {0.0, 0.0, 0.0};
+        for (int blk0 = 0; blk0 < nblk; blk0 += 16) {
+            double v[3][16];
+            int ex[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int blk = blk0 + u;
+                const bool in = blk < nblk;
+                ex[u] = (bexp && in) ? cq_ldi(bexp + blk) : emax;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) v[q][u] = in ? cq_ld(part + (int64_t)blk * CQ_PART + tid + 256 * q) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const double w = bexp ? ldexp(1.0, 2 * (ex[u] - emax)) : 1.0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[q] = fma(w, v[q][u], acc[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = tid + 256 * q, i = (e >> 4) & 15, j = e & 15;
+            const int gi = (q == 2 ? 16 : 0) + i, gj = (q == 0 ? 0 : 16) + j;
+            Gs[gi * CQ_P + gj] = acc[q];
+            if (q == 1) Gs[gj * CQ_P + gi] = acc[q];       // the diagonal tiles carry both triangles already
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // ---- wave 0: lane k (mod 32) holds column k of G; the padding block (rows / columns >= b) becomes the identity
+        const int k = lane & 31;
+        double g[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const double x = Gs[i * CQ_P + k];
+            g[i] = (i < b && k < b) ? x : ((i == k) ? 1.0 : 0.0);
+        }
+        double dev = 0.0;                                 // distance from the identity
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const double x = fabs(g[i] - (i == k ? 1.0 : 0.0));
+            dev = (x == x) ? fmax(dev, x) : 1e300;        // NaN counts as "far"
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dev = fmax(dev, __shfl_xor(dev, o, 64));
+        int dec = 0;                                      // 0: factor again, 1: converged, 2: out of passes -> fallback
+        if (pass > 0 && dev <= CQ_DONE) dec = 1;
+        else if (pass >= CQ_MAXPASS) dec = 2;
+        if (lane == 0) {
+            stt->dev_hist[pass <= CQ_MAXPASS ? pass : CQ_MAXPASS] = dev;
+            if (bexp) stt->emax = emax;
+            s_dec = dec;
+        }
+        if (dec != 0) {
+            if (lane == 0) {
+                stt->done = 1;
+                stt->final_next = 0;
+                stt->dead = 0u;
+                atomicAdd(&cq_stats[0], 1ull);
+                atomicAdd(&cq_stats[1], (unsigned long long)pass);
+                atomicAdd(&cq_stats[2], (unsigned long long)stt->ndefer_total);
+                atomicAdd(&cq_stats[3], (unsigned long long)stt->nrefill_total);
+                if (dec == 2) { atomicAdd(&cq_stats[4], 1ull); stt->fallback = 1; }
+            }
+        } else {
+            // ---- Cholesky, right-looking.  Lane k holds column k of the trailing matrix; row j of R (lane k: R[j][k]) goes
+            // to LDS, from where every lane reads the multipliers R[j][i] as broadcasts (a cross-lane read per multiplier
+            // would cost three VALU instructions per update instead of one).  Only the multiplier of row j+1, which the next
+            // pivot waits for, is read across lanes, so the LDS round trip stays off the critical path.
+            double gd = 0.0;                              // squared norm of column k before any reduction
+#pragma unroll
+            for (int i = 0; i < 32; ++i) gd = (i == k) ? g[i] : gd;
+            // a zero (underflowing, non-finite) column is refilled with noise in the next pass; a pivot below CQ_THETA of the
+            // column's squared norm is deferred; either way row j of R = e_j
+            const bool zero_k = !(gd > 1e-290) || !(gd < 1e300);
+            const unsigned deadmask = (unsigned)(__ballot(zero_k) & 0xffffffffull);
+            const double thr_k = zero_k ? 1e308 : CQ_THETA * gd;
+            unsigned badmask = 0u;
+            double dkk = 1.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const double d = cq_readlane(g[j], j), thr = cq_readlane(thr_k, j);
+                const bool ok = d > thr;                  // uniform
+                badmask |= ok ? 0u : (1u << j);
+                const double rinv = cq_rsqrt2(ok ? d : 1.0);
+                double r = (k >= j) ? g[j] * (ok ? rinv : 0.0) : 0.0;
+                r = (!ok && k == j) ? 1.0 : r;
+                if (j == k) dkk = r;
+                if (lane < 32) Rs[j * 32 + k] = r;
+                if (j < 31) {
+                    const double m1 = cq_readlane(r, j + 1);
+                    const int i0 = (j + 3) & ~1;          // 16-byte pairs (i, i+1) with i even; an odd row j+2 goes alone
+                    double2 m[16];
+                    double m2 = 0.0;
+                    if (j + 2 < 32 && ((j + 2) & 1)) m2 = Rs[j * 32 + j + 2];
+#pragma unroll
+                    for (int i = i0; i < 32; i += 2) m[i >> 1] = *reinterpret_cast<const double2*>(&Rs[j * 32 + i]);   // all reads in flight
+                    cq_fnma(g[j + 1], m1, r);
+                    if (j + 2 < 32 && ((j + 2) & 1)) cq_fnma(g[j + 2], m2, r);
+#pragma unroll
+                    for (int i = i0; i < 32; i += 2) {
+                        cq_fnma(g[i], m[i >> 1].x, r);
+                        cq_fnma(g[i + 1], m[i >> 1].y, r);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);        // keep the updates of step j in step j (the scheduler otherwise
+            }                                             // sinks them into 31-long dependent chains and spills the multipliers)
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < 1024; e += 64) Rg[e] = Rs[e];
+            if (lane < 32) Rg[1024 + k] = fast_rcp(dkk);  // reciprocal diagonal for the substitution
+            if (lane == 0) {
+                const int ndefer = __popc(badmask & ~deadmask);
+                stt->final_next = (pass > 0 && dev <= CQ_LAST && badmask == 0u) ? 1 : 0;
+                stt->dead = deadmask;
+                stt->ndefer_total += ndefer;
+                stt->nrefill_total += __popc(deadmask);
+            }
+        }
+    }
+    __syncthreads();
+    return s_dec == 2 ? 1 : 0;
+}
+
+// ---- pass 0: Gram matrix of the input panel -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__ X, int64_t rs, int64_t cs, int64_t nrows, int b, int nblk,
+                                                      double* part, int* bexp, CqState* stt, double* Rg) {
+    __shared__ double T[CQ_RB * CQ_P];
+    __shared__ double Gs[32 * CQ_P];
+    __shared__ __attribute__((aligned(16))) double Rs[32 * 32];
+    __shared__ double red[4];
+    __shared__ int s_ticket;
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    int64_t r0;
+    int nr;
+    cq_block_rows(nrows, nblk, blk, r0, nr);
+    const bool colfast = (cs == 1);
+    double amax = 0.0;
+    {
+        double xv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = tid + 256 * u;
+            const int i = colfast ? e >> 5 : e & 255, j = colfast ? e & 31 : e >> 8;
+            xv[u] = (i < nr && j < b) ? X[(r0 + i) * rs + j * cs] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = tid + 256 * u;
+            const int i = colfast ? e >> 5 : e & 255, j = colfast ? e & 31 : e >> 8;
+            T[i * CQ_P + j] = xv[u];
+            const double a = fabs(xv[u]);
+            amax = (a == a) ? fmax(amax, a) : 1.7e308;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    int ex = -2000;                                       // an all-zero block weighs nothing
+    if (amax > 0.0 && amax < 1.7e308) frexp(amax, &ex);
+    const double scl = (ex > -2000) ? ldexp(1.0, -ex) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const int e = tid + 256 * u;
+        T[(e >> 5) * CQ_P + (e & 31)] *= scl;
+    }
+    __syncthreads();
+    cq_block_gram(T, part + (int64_t)blk * CQ_PART, tid);
+    if (tid == 0) bexp[blk] = ex;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(&stt->counter, 1);
+    __syncthreads();
+    if (s_ticket != nblk - 1) return;
+    __threadfence();
+    if (tid == 0) { stt->counter = 0; stt->done = 0; stt->pass = 0; stt->ndefer_total = 0; stt->nrefill_total = 0; stt->fallback = 0; }
+    __syncthreads();
+    cq_tail(part, bexp, nblk, b, 0, stt, Rg, Gs, Rs, tid);
+}
+
+// ---- pass t >= 1: X <- X R^-1, then the Gram matrix of the new panel -----------------------------------------------
+// first: the source is the caller's panel (scaled by 2^-emax on the way in), later passes work in place on Y.
+__global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_t srs, int64_t scs, double* Y, int64_t rs, int64_t cs,
+                                                      int64_t nrows, int b, int nblk, int first, int launch_no, double* part, CqState* stt,
+                                                      double* Rg, uint64_t seed) {
+    __shared__ double T[CQ_RB * CQ_P];
+    __shared__ double Gs[32 * CQ_P];
+    __shared__ __attribute__((aligned(16))) double Rs[32 * 32 + 32];
+    __shared__ int s_ticket;
+    __shared__ int s_st[4];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    CQ_CLK_DECL;
+    CQ_CLK(0);
+    int64_t r0;
+    int nr;
+    cq_block_rows(nrows, nblk, blk, r0, nr);
+    const double* src = first ? Xsrc : Y;
+    const int64_t xrs = first ? srs : rs, xcs = first ? scs : cs;
+    const bool colfast = (xcs == 1);
+    {   // the state, the tile and the triangular factor in one memory round trip (a launch that finds the panel converged
+        // throws the tile away)
+        double xv[32], rv[5];
+        int sv = 0;
+        if (tid < 4) sv = cq_ldi(tid == 0 ? &stt->done : tid == 1 ? &stt->final_next : tid == 2 ? &stt->emax : (const int*)&stt->dead);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) rv[u] = (tid + 256 * u < 1056) ? Rg[tid + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = tid + 256 * u;
+            const int i = colfast ? e >> 5 : e & 255, j = colfast ? e & 31 : e >> 8;
+            xv[u] = (i < nr && j < b) ? src[(r0 + i) * xrs + j * xcs] : 0.0;
+        }
+        if (tid < 4) s_st[tid] = sv;
+        __syncthreads();
+        if (s_st[0]) return;
+        const int emax0 = s_st[2];
+        const double scl = first ? ((emax0 > -2000) ? ldexp(1.0, -emax0) : 0.0) : 1.0;
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+            if (tid + 256 * u < 1056) Rs[tid + 256 * u] = rv[u];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = tid + 256 * u;
+            const int i = colfast ? e >> 5 : e & 255, j = colfast ? e & 31 : e >> 8;
+            T[i * CQ_P + j] = xv[u] * scl;
+        }
+    }
+    const int fin = s_st[1], emax = s_st[2];
+    const unsigned deadmask = (unsigned)s_st[3];
+    __syncthreads();
+    CQ_CLK(1);
+    {   // substitution on row tid (right-looking: after step j all later columns are independent updates).  The multipliers
+        // of step j+1 are fetched from LDS (broadcast reads) while step j computes; the scheduling barriers keep the compiler
+        // from hoisting all 250 reads to the top (512 VGPRs and spills otherwise).
+        double x[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) x[j] = T[tid * CQ_P + j];
+        double2 mc[16], mn[16];
+        double dc = Rs[1024], dn = 0.0, sc = Rs[1], sn = 0.0;      // reciprocal diagonal, the odd first multiplier
+#pragma unroll
+        for (int q = 1; q < 16; ++q) mc[q] = *reinterpret_cast<const double2*>(&Rs[2 * q]);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (j < 31) {                                 // prefetch step j+1
+                dn = Rs[1024 + j + 1];
+                if (j + 2 < 32 && ((j + 2) & 1)) sn = Rs[(j + 1) * 32 + j + 2];
+#pragma unroll
+                for (int q = (j + 3) >> 1; q < 16; ++q) mn[q] = *reinterpret_cast<const double2*>(&Rs[(j + 1) * 32 + 2 * q]);
+            }
+            const double xj = x[j] * dc;
+            x[j] = xj;
+            if (j < 31) {
+                if ((j + 1) & 1) cq_fnma(x[j + 1], xj, sc);
+#pragma unroll
+                for (int q = (j + 2) >> 1; q < 16; ++q) {
+                    cq_fnma(x[2 * q], xj, mc[q].x);
+                    cq_fnma(x[2 * q + 1], xj, mc[q].y);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dc = dn; sc = sn;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) mc[q] = mn[q];
+        }
+        if (deadmask) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if ((deadmask >> j) & 1u) x[j] = (tid < nr) ? cq_hash_unit(seed + (uint64_t)(r0 + tid) * 64 + j) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) T[tid * CQ_P + j] = x[j];
+    }
+    __syncthreads();
+    CQ_CLK(2);
+    {   // coalesced store of the tile
+        const bool ofast = (cs == 1);
+#pragma unroll
+        for (int u0 = 0; u0 < 32; u0 += 8) {
+            double ov[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * (u0 + u);
+                const int i = ofast ? e >> 5 : e & 255, j = ofast ? e & 31 : e >> 8;
+                ov[u] = T[i * CQ_P + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * (u0 + u);
+                const int i = ofast ? e >> 5 : e & 255, j = ofast ? e & 31 : e >> 8;
+                if (i < nr && j < b) Y[(r0 + i) * rs + j * cs] = ov[u];
+            }
+        }
+    }
+    if (!fin) cq_block_gram(T, part + (int64_t)blk * CQ_PART, tid);      // (its first barrier follows its reads of T)
+    CQ_CLK(3);
+    __threadfence();
+    __syncthreads();
+    CQ_CLK(4);
+    if (tid == 0) s_ticket = atomicAdd(&stt->counter, 1);
+    __syncthreads();
+    CQ_CLK(5);
+    if (s_ticket != nblk - 1) return;
+    __threadfence();
+    CQ_CLK(6);
+    if (tid == 0) { stt->counter = 0; stt->pass = launch_no; }
+    if (fin) {
+        if (tid == 0) {
+            stt->done = 1; stt->final_next = 0; stt->dead = 0u;
+            atomicAdd(&cq_stats[0], 1ull);
+            atomicAdd(&cq_stats[1], (unsigned long long)launch_no);
+            atomicAdd(&cq_stats[2], (unsigned long long)stt->ndefer_total);
+            atomicAdd(&cq_stats[3], (unsigned long long)stt->nrefill_total);
+        }
+        return;
+    }
+    __syncthreads();
+    const int fb = cq_tail(part, nullptr, nblk, b, launch_no, stt, Rg, Gs, Rs, tid);
+    CQ_CLK(7);
+    if (launch_no <= 2) CQ_CLK_DUMP(12 * (launch_no - 1));
+    if (fb) cq_fallback_householder(Xsrc, srs, scs, Y, rs, cs, nrows, b, emax, Gs, tid);
+}
+
+// ---- host driver ---------------------------------------------------------------------------------------------------
+int64_t cholqr_ws_bytes(int64_t nrows, int b) {
+    (void)b;
+    const int64_t nblk = cdiv(nrows, CQ_RB);
+    return CQ_STATE_BYTES + align_up((1024 + 32) * 8, 256) + align_up(nblk * CQ_PART * 8, 256) + align_up(nblk * 4, 256) + 256;
+}
+
+// The state block at the head of the workspace must be zero before the first panel of a call (the kernels leave it clean).
+int cholqr_reset(hipStream_t st, void* ws) {
+    const hipError_t e = hipMemsetAsync(ws, 0, CQ_STATE_BYTES, st);
+    return e == hipSuccess ? 0 : hip_fail(e, "memset panel state");
+}
+
+// Y (nrows x b, strides rs/cs) receives an orthonormal basis of the column space of the panel X (read only; must not
+// overlap Y).
+int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows,
+                          int b, void* ws, int64_t ws_bytes, uint64_t seed) {
+    TN_CHECK_ARG(b >= 1 && b <= 32, "panel width must be <= 32");
+    TN_CHECK_ARG(nrows >= b, "panel must have at least b rows");
+    TN_CHECK_ARG(ws_bytes >= cholqr_ws_bytes(nrows, b), "workspace too small");
+    TN_CHECK_ARG(X != Y, "panel and basis must not alias");
+    const int nblk = (int)cdiv(nrows, CQ_RB);
+    char* p = (char*)ws;
+    CqState* stt = (CqState*)p; p += CQ_STATE_BYTES;
+    double* Rg = (double*)p; p += align_up((1024 + 32) * 8, 256);
+    double* part = (double*)p; p += align_up((int64_t)nblk * CQ_PART * 8, 256);
+    int* bexp = (int*)p;
+    prof_begin(st, PROF_TSQR);
+    hipLaunchKernelGGL(cq_gram_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, nrows, b, nblk, part, bexp, stt, Rg);
+    TN_CHECK_LAUNCH("cq_gram_kernel");
+    prof_end(st, PROF_TSQR, 2.0 * nrows * b * b, 8.0 * nrows * b);
+    for (int t = 1; t <= CQ_MAXPASS; ++t) {
+        prof_begin(st, PROF_TSQR);
+        hipLaunchKernelGGL(cq_pass_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, t == 1 ? 1 : 0, t, part, stt,
+                           Rg, seed + 0x9E3779B97F4A7C15ULL * (uint64_t)t);
+        TN_CHECK_LAUNCH("cq_pass_kernel");
+        prof_end(st, PROF_TSQR, 3.0 * nrows * b * b, 16.0 * nrows * b);
+    }
+    return 0;
+}
+
+// diagnostics: state block of the last panel (synchronises the stream) and the process-wide counters
+int cholqr_debug_state(hipStream_t st, const void* ws, int* ints9, double* dev_hist) {
+    CqState h;
+    hipError_t e = hipMemcpyAsync(&h, ws, sizeof(CqState), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return hip_fail(e, "memcpy state");
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync state");
+    ints9[0] = h.counter; ints9[1] = h.done; ints9[2] = h.final_next; ints9[3] = h.pass; ints9[4] = h.emax; ints9[5] = (int)h.dead;
+    ints9[6] = h.ndefer_total; ints9[7] = h.nrefill_total; ints9[8] = h.fallback;
+    for (int i = 0; i <= CQ_MAXPASS; ++i) dev_hist[i] = h.dev_hist[i];
+    return 0;
+}
+int cholqr_stats(unsigned long long* out8, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(cq_stats), 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) return hip_fail(e, "read panel statistics");
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if ((e = hipMemcpyToSymbol(HIP_SYMBOL(cq_stats), z, sizeof(z))) != hipSuccess) return hip_fail(e, "reset panel statistics");
+    }
+    return 0;
+}
+
+}  // namespace tn

@@ -154,4 +154,13 @@ int64_t tsqr_ws_bytes(int64_t nrows, int b);
 int tsqr_orthonormalize(hipStream_t st, const double* Xin, int64_t irs, int64_t ics, double* X, int64_t rs, int64_t cs,
                         int64_t nrows, int b, void* ws, int64_t ws_bytes);
 
+
+// ---- iterated Cholesky-QR panel orthonormalisation (cholqr.hip), the default panel step -------------------------------
+int64_t cholqr_ws_bytes(int64_t nrows, int b);
+int cholqr_reset(hipStream_t st, void* ws);          // zero the state block once per call, before the first panel
+int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows,
+                          int b, void* ws, int64_t ws_bytes, uint64_t seed);
+int cholqr_debug_state(hipStream_t st, const void* ws, int* ints9, double* dev_hist);
+int cholqr_stats(unsigned long long* out8, int reset);
+
 }  // namespace tn

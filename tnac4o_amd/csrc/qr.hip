@@ -580,6 +580,17 @@ static void dbg_check(hipStream_t st, const double* p, int64_t rs, int64_t cs, i
     fprintf(stderr, "[tn_qr dbg] panel %d it %d %-10s %lldx%lld nonfinite=%d max=%.3e min|.|=%.3e\n", panel, it, what, (long long)m, (long long)n, bad, mx, mn);
 }
 
+// The panel step: iterated Cholesky-QR (cholqr.hip) by default, TN_PANEL=tsqr selects the Householder TSQR (A/B, cross-checks).
+static bool panel_tsqr() {
+    const char* e = getenv("TN_PANEL");                              // read per call: the tests switch it
+    return e && e[0] == 't';
+}
+static int panel_orthonormalize(hipStream_t st, const double* Xin, int64_t irs, int64_t ics, double* X, int64_t rs, int64_t cs, int64_t nrows,
+                                int b, void* ws, int64_t ws_bytes, bool tsqr, uint64_t seed) {
+    if (tsqr) return tsqr_orthonormalize(st, Xin, irs, ics, X, rs, cs, nrows, b, ws, ws_bytes);
+    return cholqr_orthonormalize(st, Xin, irs, ics, X, rs, cs, nrows, b, ws, ws_bytes, seed);
+}
+
 constexpr int QR_NBO_MAX = 256;       // widest outer block of the two-level factorisation
 struct QrWs {
     double *Y, *Wq, *W, *W2, *UT, *UTq, *gemm_ws2;
@@ -630,7 +641,7 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     double* Zb2 = (double*)take((int64_t)QR_NBO_MAX * (n > k ? n : k) * 8);
     double* tmpT = (double*)take((int64_t)QR_NBO_MAX * 64 * 8);
     if (w) { w->G = Gm; w->Tblk = Tblk; w->Zo = Zb; w->Zo2 = Zb2; w->tmpT = tmpT; }
-    const int64_t tsb = tsqr_ws_bytes(m, nb < 32 ? nb : 32);
+    const int64_t tsb = std::max(tsqr_ws_bytes(m, nb < 32 ? nb : 32), cholqr_ws_bytes(m, nb < 32 ? nb : 32));
     void* tsw = (void*)take(tsb);
     if (w) { w->tsqr_ws = tsw; w->tsqr_bytes = tsb; }
     if (w) { w->Wq = Wq; w->W = Wp; w->W2 = Wp2; w->UT = UT; w->UTq = UTq; w->gemm_ws2 = gws2; }
@@ -658,7 +669,7 @@ int64_t qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_layout(m, n, nb, n
 // truncating passes checks the trailing block after every second panel, which needs it up to date.
 static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k, Mat Ym, QrWs& w, int nbo, int64_t rs, int64_t cs,
                         int64_t yrs, int64_t ycs, int64_t wrs, int64_t wcs, double* Q, int64_t qrs, int64_t qcs, double* R, int64_t rrs,
-                        int64_t rcs) {
+                        int64_t rcs, bool use_tsqr) {
     const int nb = 32;
     int rc;
     const int nblk = (int)cdiv(k, nbo);
@@ -678,7 +689,7 @@ static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k,
             const int64_t mp = m - j0, nin = Jend - j0;                         // the panel's update stays inside the block
             const int p = (int)(j0 / nb);
             Mat Ap = sub(Am, j0, j0), Yp = sub(Ym, j0, j0);
-            if ((rc = tsqr_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes))) return rc;
+            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1))) return rc;
             double* Tp = w.T + (int64_t)p * nb * nb;
             Mat Wp = mat(w.W, wrs, wcs);
             // Wq_top goes to a scratch corner of the (otherwise unused here) Wq buffer: only Y, T and W = Y T^T are needed
@@ -799,12 +810,14 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
     const int64_t wrs = rowmajor ? nb : 1, wcs = rowmajor ? 1 : m;
     Mat Am = mat(A, rs, cs), Ym = mat(w.Y, yrs, ycs), Wqm = mat(w.Wq, yrs, ycs);
     int rc;
+    const bool use_tsqr = panel_tsqr();
+    if (nb == 32 && !use_tsqr && (rc = cholqr_reset(st, w.tsqr_ws))) return rc;
     {   // two-level blocking for the plain factorisation of matrices with several outer blocks (TN_QR_NBO = 0 disables it)
         const char* e_nbo = getenv("TN_QR_NBO");                      // read per call: the tests switch it
         const int v_nbo = e_nbo ? atoi(e_nbo) : 256, nbo = (v_nbo == 128 || v_nbo == 256) ? v_nbo : 0;
         if (nbo > 0 && nb == 32 && !(rank_tol > 0.0 && keff_host != nullptr) && k >= 2 * nbo && m >= 4 * nbo) {
             if (keff_host) *keff_host = k;
-            return qr_two_level(st, Am, m, n, k, Ym, w, nbo, rs, cs, yrs, ycs, wrs, wcs, Q, qrs, qcs, R, rrs, rcs);
+            return qr_two_level(st, Am, m, n, k, Ym, w, nbo, rs, cs, yrs, ycs, wrs, wcs, Q, qrs, qcs, R, rrs, rcs, use_tsqr);
         }
     }
     thread_local LookaheadEvents ev;
@@ -857,7 +870,7 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         }
         // --- panel orthonormalisation
         if (nb == 32) {
-            if ((rc = tsqr_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes))) return rc;
+            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1))) return rc;
         } else {
             if ((rc = copy_mat(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b))) return rc;
             const int nchunk = gram_nchunk(mp);
