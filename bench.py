@@ -237,6 +237,8 @@ def main():
         lib.tn_panel_stats(pst, 0)
         panel_stats = {'panels': int(pst[0]), 'substitution_passes': int(pst[1]), 'deferred_pivots': int(pst[2]),
                        'refilled_columns': int(pst[3]), 'householder_fallbacks': int(pst[4]),
+                       'panels_with_3_or_more_passes': int(pst[5]), 'panels_with_4_or_more_passes': int(pst[6]),
+                       'panels_with_5_passes': int(pst[7]),
                        'what': 'iterated Cholesky-QR panel step (csrc/cholqr.hip) over the un-instrumented single-chain sweep'}
         lib.tn_profile_reset()
         lib.tn_profile_enable(mask_all)

@@ -26,6 +26,8 @@
 //
 // Launches are plain stream-ordered kernels: nothing spins, nothing needs co-residency, so interleaved chains cannot
 // deadlock.  A launch that finds the panel converged returns at once (~3 us).
+#include <stdlib.h>
+
 #include "common.h"
 
 // -DTN_CLOCKS: thread 0 of the last workgroup of a launch records the 100 MHz wall clock at phase boundaries (diagnostics only)
@@ -50,7 +52,7 @@ typedef double d4c __attribute__((ext_vector_type(4)));
 constexpr int CQ_RB = 256;            // rows per workgroup
 constexpr int CQ_P = 33;              // LDS pitch of the row tile
 constexpr int CQ_PART = 768;          // per-block partial Gram: tiles (0,0), (0,1), (1,1) of 16 x 16
-constexpr int CQ_MAXPASS = 5;         // substitution passes enqueued per panel (later ones return at once when converged)
+constexpr int CQ_MAXPASS = 4;         // substitution passes enqueued per panel (later ones return at once when converged)
 constexpr double CQ_THETA = 1e-10;    // deferral threshold on pivot / squared column norm
 constexpr double CQ_DONE = 5e-15;     // Gram matrix = identity to rounding: converged
 constexpr double CQ_LAST = 1e-8;      // below this one more pass lands at rounding level without another check
@@ -65,7 +67,7 @@ struct CqState {
     int ndefer_total;     // statistics: deferred pivots, refills, Householder fallbacks of this panel
     int nrefill_total;
     int fallback;
-    double dev_hist[CQ_MAXPASS + 1];
+    double dev_hist[CQ_MAXPASS + 2];
 };
 constexpr int CQ_STATE_BYTES = 256;
 static_assert(sizeof(CqState) <= CQ_STATE_BYTES, "state block too small");
@@ -97,6 +99,15 @@ __device__ __forceinline__ void cq_block_rows(int64_t nrows, int nblk, int blk, 
     nr = (int)(base + (blk < rem ? 1 : 0));
 }
 
+__device__ __forceinline__ double cq_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// What the workgroups publish to the last one (partial Gram matrices, block exponents) is written with agent-scope stores:
+// they go through to memory, so the publisher only waits for their completion before it takes its ticket -- a release
+// fence would also write back every dirty line of the XCD's L2 (the tile just stored: 3.6 us measured against ~1).
+__device__ __forceinline__ void cq_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cq_sti(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cq_publish_wait() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); }
+__device__ __forceinline__ int cq_ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Partial Gram of the 256 x 32 LDS tile T (pitch CQ_P): wave w covers rows 64w .. 64w+63 on the matrix cores, the four
 // partials meet in LDS (T is overwritten: callers are done with it) and their sum goes to part[0 .. 767].
 __device__ __forceinline__ void cq_block_gram(double* __restrict__ T, double* __restrict__ part, int tid) {
@@ -120,14 +131,18 @@ __device__ __forceinline__ void cq_block_gram(double* __restrict__ T, double* __
         sp[512 + i * 16 + li] = g11[r];
     }
     __syncthreads();
-    for (int e = tid; e < CQ_PART; e += 256) part[e] = (T[e] + T[CQ_PART + e]) + (T[2 * CQ_PART + e] + T[3 * CQ_PART + e]);
+    for (int e = tid; e < CQ_PART; e += 256) cq_st(part + e, (T[e] + T[CQ_PART + e]) + (T[2 * CQ_PART + e] + T[3 * CQ_PART + e]));
 }
-
-__device__ __forceinline__ double cq_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int cq_ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // process-wide statistics (diagnostics): panels, passes applied, deferred pivots, refilled columns, Householder fallbacks
 __device__ unsigned long long cq_stats[8];
+// one thread, once per panel: two packed 64-bit adds instead of up to seven (each costs the last workgroup ~0.5 us)
+//   [0] = panels + (passes << 32),  [1] = deferred + (>= 3 passes << 32) + (>= 4 passes << 48),  [2] = refilled + (fallbacks << 32) (rare)
+__device__ __forceinline__ void cq_count(int passes, int ndefer, int nrefill, bool fallback) {
+    atomicAdd(&cq_stats[0], 1ull + ((unsigned long long)passes << 32));
+    atomicAdd(&cq_stats[1], (unsigned long long)ndefer + ((unsigned long long)(passes >= 3 ? 1 : 0) << 32) + ((unsigned long long)(passes >= 4 ? 1 : 0) << 48));
+    if (nrefill > 0 || fallback) atomicAdd(&cq_stats[2], (unsigned long long)nrefill + ((unsigned long long)(fallback ? 1 : 0) << 32));
+}
 
 // 256-thread sum through LDS (two barriers); red: >= 4 doubles
 __device__ __forceinline__ double cq_block_sum(double v, double* red, int tid) {
@@ -203,12 +218,161 @@ __device__ void cq_fallback_householder(const double* X, int64_t xrs, int64_t xc
     }
 }
 
+// acc -= s * v with the first factor wave-uniform (an SGPR pair), pinned in program order like cq_fnma
+__device__ __forceinline__ void cq_fnma_s(double& acc, double s_uniform, double v) {
+    asm volatile("v_fma_f64 %0, -%1, %2, %0" : "+v"(acc) : "s"(s_uniform), "v"(v));
+}
+
+// Slots of the reconstruction buffer `lu` (7 x 1024 doubles, 32 x 32 row-major each): the top block of the orthonormal panel as
+// published by workgroup 0, then what the Householder reconstruction leaves for the post-processing launch.
+enum { CQ_LU_YTOP = 0, CQ_LU_Y1 = 1024, CQ_LU_UINV = 2048, CQ_LU_UT = 3072, CQ_LU_UTQ = 4096, CQ_LU_WTOP = 5120, CQ_LU_WQTOP = 6144, CQ_LU_DOUBLES = 7168 };
+
+// Householder reconstruction of the panel (Ballard et al. 2014; same mathematics as lu_reconstruct_kernel in qr.hip) by one
+// workgroup:  Q1_top - S = L U  with the sign choice s_i = -sign(u_ii) (|pivot| >= 1, no pivoting needed), then
+//   Y1 = L,  T = -U S L^-T,  Uinv = U^-1,  UT = Uinv T^T,  UTq = Uinv T,  Wtop = L T^T,  Wqtop = L T
+// so that rows below the top block follow as  Y = Q1 Uinv,  W = Y T^T = Q1 UT,  Wq = Y T = Q1 UTq.
+// The elimination runs in wave 0 without barriers: lane r holds row r, the pivot row reaches the other lanes through
+// cross-lane reads (SGPR operands of the updates).  scr: LDS, >= 4 * 32 * 33 + 32 doubles.  Tp: b x b, pitch b.
+__device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, int b, double* lu, double* Tp, double* scr, int tid) {
+    constexpr int P = 33;
+    double* Um = scr;                  // U (zeros below the diagonal), then U S, then T
+    double* Lm = scr + 32 * P;         // L (unit lower, zeros above)
+    double* Ui = scr + 2 * 32 * P;     // U^-1
+    double* Li = scr + 3 * 32 * P;     // L^-1
+    double* sg = scr + 4 * 32 * P;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) {
+        const int r = lane & 31;
+        double u[32], l[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const double x = coherent_loads ? cq_ld(ytop + r * 32 + c) : ytop[r * 32 + c];
+            u[c] = (r < b && c < b) ? x : ((r == c) ? 1.0 : 0.0);       // padding: identity block, never eliminated
+            l[c] = (r == c) ? 1.0 : 0.0;
+        }
+        double mysg = 1.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const double bii = cq_readlane(u[i], i);
+            const bool live = i < b;                      // uniform
+            const double sgn = (bii >= 0.0) ? -1.0 : 1.0, piv = bii - sgn, rp = fast_rcp(live ? piv : 1.0);
+            const double li = (live && r > i) ? u[i] * rp : 0.0;
+#pragma unroll
+            for (int c = i + 1; c < 32; ++c) {
+                const double uic = cq_readlane(u[c], i);
+                cq_fnma_s(u[c], uic, li);
+            }
+            l[i] = (r > i) ? li : l[i];
+            u[i] = (r > i) ? 0.0 : ((r == i && live) ? piv : u[i]);
+            if (r == i) mysg = live ? sgn : 1.0;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane < 32) {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) { Um[r * P + c] = u[c]; Lm[r * P + c] = l[c]; Ui[r * P + c] = 0.0; Li[r * P + c] = 0.0; }
+            sg[r] = mysg;
+        }
+    }
+    __syncthreads();
+    // U^-1 and L^-1 by substitution, one column per lane with the column in registers (wave 0: U^-1, wave 1: L^-1)
+    if (wave == 0 && lane < 32) {
+        const int j = lane;
+        double x[32], rd[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) rd[i] = fast_rcp(Um[i * P + i]);
+#pragma unroll
+        for (int i = 31; i >= 0; --i) {
+            double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = i + 1; k < 32; ++k) sa[k & 3] += Um[i * P + k] * x[k];
+            const double t = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+            x[i] = (i > j) ? 0.0 : ((i == j) ? rd[i] : -t * rd[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) Ui[i * P + j] = x[i];
+    } else if (wave == 1 && lane < 32) {
+        const int j = lane;
+        double x[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < i; ++k) sa[k & 3] += Lm[i * P + k] * x[k];
+            const double t = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+            x[i] = (i < j) ? 0.0 : ((i == j) ? 1.0 : -t);
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) Li[i * P + j] = x[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) Um[(e >> 5) * P + (e & 31)] *= sg[e & 31];      // U S, in place
+    __syncthreads();
+    const int li_ = lane & 15, lk = lane >> 4;
+    // 32 x 32 products on the matrix cores, one wave each: acc[ti][tj] = op(A) op(B)
+    auto mm = [&](const double* Am, const double* Bm, bool bt, d4c (&acc)[2][2]) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = d4c{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int k = ks * 4 + lk;
+            double fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int i = t * 16 + li_;
+                fa[t] = Am[i * P + k];
+                fb[t] = bt ? Bm[i * P + k] : Bm[k * P + i];
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fb[tj], acc[ti][tj], 0, 0, 0);
+        }
+    };
+    d4c acc[2][2];
+    if (wave == 0) mm(Um, Li, true, acc);                 // (U S) L^-T
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = ti * 16 + lk + 4 * q, j = tj * 16 + li_;
+                    const double t = (i <= j && j < b) ? -acc[ti][tj][q] : 0.0;
+                    Um[i * P + j] = t;                     // T
+                    if (i < b && j < b) Tp[i * b + j] = t;
+                }
+    }
+    __syncthreads();
+    // wave 0: UT = Uinv T^T, wave 1: UTq = Uinv T, wave 2: Wtop = L T^T, wave 3: Wqtop = L T
+    mm((wave < 2) ? Ui : Lm, Um, (wave & 1) == 0, acc);
+    double* dst = lu + (wave == 0 ? CQ_LU_UT : wave == 1 ? CQ_LU_UTQ : wave == 2 ? CQ_LU_WTOP : CQ_LU_WQTOP);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = ti * 16 + lk + 4 * q, j = tj * 16 + li_;
+                dst[i * 32 + j] = (i < b && j < b) ? acc[ti][tj][q] : 0.0;
+            }
+    for (int e = tid; e < 1024; e += 256) {
+        const int i = e >> 5, j = e & 31;
+        lu[CQ_LU_UINV + e] = (i < b && j < b) ? Ui[i * P + j] : 0.0;
+        lu[CQ_LU_Y1 + e] = Lm[i * P + j];
+    }
+    __syncthreads();
+}
+
 // Tail of a launch, run by the last workgroup to arrive: sum the partial Gram matrices (block order, optional per-block
 // power-of-two weights), measure the distance from the identity, decide, and factor G = R^T R with deferral (wave 0).
 // Gs: LDS 32 x 33, Rs: LDS 32 x 32 (16-byte aligned).  pass = number of passes applied to the panel whose Gram matrix this is.  Returns 1 when the caller
 // has to run the Householder fallback (all threads get the same value).
 __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int nblk, int b, int pass, CqState* stt, double* Rg, double* Gs,
-                                       double* Rs, int tid) {
+                                       double* Rs, double* lu, double* Tp, double* scr, int maxpass, int tid) {
     __shared__ int s_dec;
     const int lane = tid & 63;
     // exponents of pass 0: block weights 4^(e_blk - emax); every wave finds emax itself (no barrier)
@@ -220,13 +384,13 @@ __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int 
         for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(e, o, 64); e = y > e ? y : e; }
         emax = e;
     }
-    {   // thread tid sums entries tid, tid + 256, tid + 512 over the blocks, in block order; 48 loads in flight per thread
+    {   // thread tid sums entries tid, tid + 256, tid + 512 over the blocks, in block order; 96 loads in flight per thread
         double acc[3] = {0.0, 0.0, 0.0};
-        for (int blk0 = 0; blk0 < nblk; blk0 += 16) {
-            double v[3][16];
-            int ex[16];
+        for (int blk0 = 0; blk0 < nblk; blk0 += 32) {
+            double v[3][32];
+            int ex[32];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < 32; ++u) {
                 const int blk = blk0 + u;
                 const bool in = blk < nblk;
                 ex[u] = (bexp && in) ? cq_ldi(bexp + blk) : emax;
@@ -234,7 +398,7 @@ __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int 
                 for (int q = 0; q < 3; ++q) v[q][u] = in ? cq_ld(part + (int64_t)blk * CQ_PART + tid + 256 * q) : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < 32; ++u) {
                 const double w = bexp ? ldexp(1.0, 2 * (ex[u] - emax)) : 1.0;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) acc[q] = fma(w, v[q][u], acc[q]);
@@ -268,7 +432,7 @@ __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int 
         for (int o = 32; o > 0; o >>= 1) dev = fmax(dev, __shfl_xor(dev, o, 64));
         int dec = 0;                                      // 0: factor again, 1: converged, 2: out of passes -> fallback
         if (pass > 0 && dev <= CQ_DONE) dec = 1;
-        else if (pass >= CQ_MAXPASS) dec = 2;
+        else if (pass >= maxpass) dec = 2;
         if (lane == 0) {
             stt->dev_hist[pass <= CQ_MAXPASS ? pass : CQ_MAXPASS] = dev;
             if (bexp) stt->emax = emax;
@@ -279,11 +443,8 @@ __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int 
                 stt->done = 1;
                 stt->final_next = 0;
                 stt->dead = 0u;
-                atomicAdd(&cq_stats[0], 1ull);
-                atomicAdd(&cq_stats[1], (unsigned long long)pass);
-                atomicAdd(&cq_stats[2], (unsigned long long)stt->ndefer_total);
-                atomicAdd(&cq_stats[3], (unsigned long long)stt->nrefill_total);
-                if (dec == 2) { atomicAdd(&cq_stats[4], 1ull); stt->fallback = 1; }
+                if (dec == 2) stt->fallback = 1;
+                cq_count(pass, stt->ndefer_total, stt->nrefill_total, dec == 2);
             }
         } else {
             // ---- Cholesky, right-looking.  Lane k holds column k of the trailing matrix; row j of R (lane k: R[j][k]) goes
@@ -341,7 +502,9 @@ __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int 
         }
     }
     __syncthreads();
-    return s_dec == 2 ? 1 : 0;
+    const int dec_all = s_dec;
+    if (dec_all == 1 && lu) cq_lu(lu + CQ_LU_YTOP, true, b, lu, Tp, scr, tid);      // converged: reconstruct the reflectors right here
+    return dec_all == 2 ? 1 : 0;
 }
 
 // ---- pass 0: Gram matrix of the input panel -------------------------------------------------------------------------
@@ -390,8 +553,8 @@ __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__
     }
     __syncthreads();
     cq_block_gram(T, part + (int64_t)blk * CQ_PART, tid);
-    if (tid == 0) bexp[blk] = ex;
-    __threadfence();
+    if (tid == 0) cq_sti(bexp + blk, ex);
+    cq_publish_wait();
     __syncthreads();
     if (tid == 0) s_ticket = atomicAdd(&stt->counter, 1);
     __syncthreads();
@@ -399,14 +562,14 @@ __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__
     __threadfence();
     if (tid == 0) { stt->counter = 0; stt->done = 0; stt->pass = 0; stt->ndefer_total = 0; stt->nrefill_total = 0; stt->fallback = 0; }
     __syncthreads();
-    cq_tail(part, bexp, nblk, b, 0, stt, Rg, Gs, Rs, tid);
+    cq_tail(part, bexp, nblk, b, 0, stt, Rg, Gs, Rs, nullptr, nullptr, T, CQ_MAXPASS, tid);
 }
 
 // ---- pass t >= 1: X <- X R^-1, then the Gram matrix of the new panel -----------------------------------------------
 // first: the source is the caller's panel (scaled by 2^-emax on the way in), later passes work in place on Y.
 __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_t srs, int64_t scs, double* Y, int64_t rs, int64_t cs,
                                                       int64_t nrows, int b, int nblk, int first, int launch_no, double* part, CqState* stt,
-                                                      double* Rg, uint64_t seed) {
+                                                      double* Rg, uint64_t seed, double* lu, double* Tp, int maxpass) {
     __shared__ double T[CQ_RB * CQ_P];
     __shared__ double Gs[32 * CQ_P];
     __shared__ __attribute__((aligned(16))) double Rs[32 * 32 + 32];
@@ -515,9 +678,16 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
             }
         }
     }
+    if (lu && blk == 0) {                                 // the top block, for the reconstruction by the last workgroup
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            cq_st(lu + CQ_LU_YTOP + e, T[(e >> 5) * CQ_P + (e & 31)]);
+        }
+    }
     if (!fin) cq_block_gram(T, part + (int64_t)blk * CQ_PART, tid);      // (its first barrier follows its reads of T)
     CQ_CLK(3);
-    __threadfence();
+    cq_publish_wait();
     __syncthreads();
     CQ_CLK(4);
     if (tid == 0) s_ticket = atomicAdd(&stt->counter, 1);
@@ -530,25 +700,148 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
     if (fin) {
         if (tid == 0) {
             stt->done = 1; stt->final_next = 0; stt->dead = 0u;
-            atomicAdd(&cq_stats[0], 1ull);
-            atomicAdd(&cq_stats[1], (unsigned long long)launch_no);
-            atomicAdd(&cq_stats[2], (unsigned long long)stt->ndefer_total);
-            atomicAdd(&cq_stats[3], (unsigned long long)stt->nrefill_total);
+            cq_count(launch_no, stt->ndefer_total, stt->nrefill_total, false);
         }
+        __syncthreads();
+        if (lu) cq_lu(lu + CQ_LU_YTOP, true, b, lu, Tp, T, tid);
         return;
     }
     __syncthreads();
-    const int fb = cq_tail(part, nullptr, nblk, b, launch_no, stt, Rg, Gs, Rs, tid);
+    cq_tail(part, nullptr, nblk, b, launch_no, stt, Rg, Gs, Rs, lu, Tp, T, maxpass, tid);
     CQ_CLK(7);
     if (launch_no <= 2) CQ_CLK_DUMP(12 * (launch_no - 1));
-    if (fb) cq_fallback_householder(Xsrc, srs, scs, Y, rs, cs, nrows, b, emax, Gs, tid);
+}
+
+// ---- post-processing: the reflector panels from the orthonormal one ---------------------------------------------------
+// rows >= b:  Y <- Q1 Uinv,  W <- Q1 UT (= Y T^T),  Wq <- Q1 UTq (= Y T, optional);  rows < b come from the reconstruction.
+// One tile of <= 256 rows on the matrix cores (wave w owns rows 64w .. 64w+63); tile: LDS 256 x CQ_P, Ss: LDS 3 x 1024.
+__device__ __forceinline__ void cq_post_tile(int blk, int nblk, int64_t nrows, int b, double* Y, int64_t rs, int64_t cs, double* W, int64_t wrs,
+                                             int64_t wcs, double* Wq, const double* lu, double* tile, double* Ss, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    int64_t r0;
+    int nr;
+    cq_block_rows(nrows, nblk, blk, r0, nr);
+    const bool xrow = (cs == 1);
+    {
+        double sv[3][4], xv[32];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = tid + 256 * t;
+            sv[0][t] = lu[CQ_LU_UINV + e];
+            sv[1][t] = lu[CQ_LU_UT + e];
+            sv[2][t] = lu[CQ_LU_UTQ + e];
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = tid + 256 * u;
+            const int i = xrow ? e >> 5 : e & 255, j = xrow ? e & 31 : e >> 8;
+            xv[u] = (i < nr && j < b) ? Y[(r0 + i) * rs + j * cs] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = tid + 256 * t;
+            Ss[e] = sv[0][t]; Ss[1024 + e] = sv[1][t]; Ss[2048 + e] = sv[2][t];
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = tid + 256 * u;
+            const int i = xrow ? e >> 5 : e & 255, j = xrow ? e & 31 : e >> 8;
+            tile[i * CQ_P + j] = xv[u];
+        }
+    }
+    __syncthreads();
+    double fa[4][8];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) fa[mt][ks] = tile[(wave * 64 + mt * 16 + li) * CQ_P + ks * 4 + lk];
+    __syncthreads();
+#pragma unroll 1
+    for (int o = 0; o < 3; ++o) {
+        double* dst = (o == 0) ? Y : (o == 1) ? W : Wq;
+        if (dst == nullptr) continue;                      // uniform
+        const int64_t drs = (o == 1) ? wrs : rs, dcs = (o == 1) ? wcs : cs;
+        const double* Sm = Ss + 1024 * o;
+        const double* top = lu + ((o == 0) ? CQ_LU_Y1 : (o == 1) ? CQ_LU_WTOP : CQ_LU_WQTOP);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            double fb[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) fb[ks] = Sm[(ks * 4 + lk) * 32 + nt * 16 + li];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                d4c acc = d4c{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[mt][ks], fb[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tile[(wave * 64 + mt * 16 + lk + 4 * q) * CQ_P + nt * 16 + li] = acc[q];
+            }
+        }
+        __syncthreads();
+        const bool drow = (dcs == 1);
+#pragma unroll
+        for (int u0 = 0; u0 < 32; u0 += 8) {
+            double ov[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * (u0 + u);
+                const int i = drow ? e >> 5 : e & 255, j = drow ? e & 31 : e >> 8;
+                ov[u] = (r0 + i < b) ? top[(r0 + i) * 32 + j] : tile[i * CQ_P + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * (u0 + u);
+                const int i = drow ? e >> 5 : e & 255, j = drow ? e & 31 : e >> 8;
+                if (i < nr && j < b) dst[(r0 + i) * drs + j * dcs] = ov[u];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void cq_post_kernel(const double* X, int64_t xrs, int64_t xcs, double* Y, int64_t rs, int64_t cs, int64_t nrows,
+                                                      int b, int nblk, CqState* stt, double* lu, double* Tp, double* W, int64_t wrs, int64_t wcs,
+                                                      double* Wq) {
+    __shared__ double tile[CQ_RB * CQ_P];
+    __shared__ double Ss[3 * 1024];
+    __shared__ double scr[4 * 32 * 33 + 64];
+    __shared__ int s_st[2];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    if (tid == 0) { s_st[0] = cq_ldi(&stt->fallback); s_st[1] = cq_ldi(&stt->emax); }
+    __syncthreads();
+    if (!s_st[0]) {
+        if (lu) cq_post_tile(blk, nblk, nrows, b, Y, rs, cs, W, wrs, wcs, Wq, lu, tile, Ss, tid);
+        return;
+    }
+    // The passes did not converge (never seen on the contraction path): workgroup 0 redoes the panel with Householder
+    // reflections and post-processes every tile itself.
+    if (blk != 0) return;
+    cq_fallback_householder(X, xrs, xcs, Y, rs, cs, nrows, b, s_st[1], scr, tid);
+    if (!lu) return;
+    __threadfence();
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+        const int i = e >> 5, j = e & 31;
+        lu[CQ_LU_YTOP + e] = (i < b && j < b && i < nrows) ? cq_ld(Y + (int64_t)i * rs + j * cs) : 0.0;
+    }
+    __threadfence();
+    __syncthreads();
+    cq_lu(lu + CQ_LU_YTOP, true, b, lu, Tp, scr, tid);
+    __threadfence();
+    __syncthreads();
+    for (int t = 0; t < nblk; ++t) {
+        cq_post_tile(t, nblk, nrows, b, Y, rs, cs, W, wrs, wcs, Wq, lu, tile, Ss, tid);
+        __threadfence();
+        __syncthreads();
+    }
 }
 
 // ---- host driver ---------------------------------------------------------------------------------------------------
 int64_t cholqr_ws_bytes(int64_t nrows, int b) {
     (void)b;
     const int64_t nblk = cdiv(nrows, CQ_RB);
-    return CQ_STATE_BYTES + align_up((1024 + 32) * 8, 256) + align_up(nblk * CQ_PART * 8, 256) + align_up(nblk * 4, 256) + 256;
+    return CQ_STATE_BYTES + align_up((1024 + 32) * 8, 256) + align_up(nblk * CQ_PART * 8, 256) + align_up(nblk * 4, 256) +
+           align_up((int64_t)CQ_LU_DOUBLES * 8, 256) + 256;
 }
 
 // The state block at the head of the workspace must be zero before the first panel of a call (the kernels leave it clean).
@@ -557,32 +850,48 @@ int cholqr_reset(hipStream_t st, void* ws) {
     return e == hipSuccess ? 0 : hip_fail(e, "memset panel state");
 }
 
-// Y (nrows x b, strides rs/cs) receives an orthonormal basis of the column space of the panel X (read only; must not
-// overlap Y).
-int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows,
-                          int b, void* ws, int64_t ws_bytes, uint64_t seed) {
+// One panel step.  Y (nrows x b, strides rs/cs) receives an orthonormal basis Q1 of the column space of the panel X (read
+// only; must not overlap Y).  With reconstruct != 0 the launches go on to the Householder reconstruction (Ballard et al.):
+// on return Y holds the unit lower trapezoidal reflectors, Tp (b x b, pitch b) their T factor, W = Y T^T (nrows x b, strides
+// wrs/wcs) and, when Wq != NULL, Wq = Y T (strides of Y), i.e. what lu_reconstruct_kernel + rows_times_small3 of qr.hip produce,
+// in the launch slots that would otherwise return at once.
+int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws,
+                 int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq) {
     TN_CHECK_ARG(b >= 1 && b <= 32, "panel width must be <= 32");
     TN_CHECK_ARG(nrows >= b, "panel must have at least b rows");
     TN_CHECK_ARG(ws_bytes >= cholqr_ws_bytes(nrows, b), "workspace too small");
     TN_CHECK_ARG(X != Y, "panel and basis must not alias");
+    TN_CHECK_ARG(!reconstruct || (Tp && W), "reconstruction needs T and W");
     const int nblk = (int)cdiv(nrows, CQ_RB);
     char* p = (char*)ws;
     CqState* stt = (CqState*)p; p += CQ_STATE_BYTES;
     double* Rg = (double*)p; p += align_up((1024 + 32) * 8, 256);
     double* part = (double*)p; p += align_up((int64_t)nblk * CQ_PART * 8, 256);
-    int* bexp = (int*)p;
+    int* bexp = (int*)p; p += align_up((int64_t)nblk * 4, 256);
+    double* lu = reconstruct ? (double*)p : nullptr;
     prof_begin(st, PROF_TSQR);
     hipLaunchKernelGGL(cq_gram_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, nrows, b, nblk, part, bexp, stt, Rg);
     TN_CHECK_LAUNCH("cq_gram_kernel");
     prof_end(st, PROF_TSQR, 2.0 * nrows * b * b, 8.0 * nrows * b);
-    for (int t = 1; t <= CQ_MAXPASS; ++t) {
+    // TN_PANEL_MAXPASS (1 .. CQ_MAXPASS): fewer substitution passes, to drive the Householder fallback in tests
+    static const int maxpass = [] { const char* e = getenv("TN_PANEL_MAXPASS"); const int v = e ? atoi(e) : CQ_MAXPASS; return v >= 1 && v <= CQ_MAXPASS ? v : CQ_MAXPASS; }();
+    for (int t = 1; t <= maxpass; ++t) {
         prof_begin(st, PROF_TSQR);
         hipLaunchKernelGGL(cq_pass_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, t == 1 ? 1 : 0, t, part, stt,
-                           Rg, seed + 0x9E3779B97F4A7C15ULL * (uint64_t)t);
+                           Rg, seed + 0x9E3779B97F4A7C15ULL * (uint64_t)t, lu, Tp, maxpass);
         TN_CHECK_LAUNCH("cq_pass_kernel");
         prof_end(st, PROF_TSQR, 3.0 * nrows * b * b, 16.0 * nrows * b);
     }
+    prof_begin(st, PROF_TSQR);
+    hipLaunchKernelGGL(cq_post_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, stt, lu, Tp, W, wrs, wcs, Wq);
+    TN_CHECK_LAUNCH("cq_post_kernel");
+    prof_end(st, PROF_TSQR, reconstruct ? (Wq ? 6.0 : 4.0) * nrows * b * b : 0.0, reconstruct ? (Wq ? 32.0 : 24.0) * nrows * b : 0.0);
     return 0;
+}
+
+int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows,
+                          int b, void* ws, int64_t ws_bytes, uint64_t seed) {
+    return cholqr_panel(st, X, irs, ics, Y, rs, cs, nrows, b, ws, ws_bytes, seed, 0, nullptr, nullptr, 0, 0, nullptr);
 }
 
 // diagnostics: state block of the last panel (synchronises the stream) and the process-wide counters
@@ -593,12 +902,21 @@ int cholqr_debug_state(hipStream_t st, const void* ws, int* ints9, double* dev_h
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync state");
     ints9[0] = h.counter; ints9[1] = h.done; ints9[2] = h.final_next; ints9[3] = h.pass; ints9[4] = h.emax; ints9[5] = (int)h.dead;
     ints9[6] = h.ndefer_total; ints9[7] = h.nrefill_total; ints9[8] = h.fallback;
-    for (int i = 0; i <= CQ_MAXPASS; ++i) dev_hist[i] = h.dev_hist[i];
+    for (int i = 0; i <= CQ_MAXPASS + 1; ++i) dev_hist[i] = h.dev_hist[i];
     return 0;
 }
 int cholqr_stats(unsigned long long* out8, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(cq_stats), 8 * sizeof(unsigned long long));
+    unsigned long long raw[8];
+    hipError_t e = hipMemcpyFromSymbol(raw, HIP_SYMBOL(cq_stats), 8 * sizeof(unsigned long long));
     if (e != hipSuccess) return hip_fail(e, "read panel statistics");
+    out8[0] = raw[0] & 0xffffffffull;             // panels
+    out8[1] = raw[0] >> 32;                       // substitution passes
+    out8[2] = raw[1] & 0xffffffffull;             // deferred pivots
+    out8[3] = raw[2] & 0xffffffffull;             // refilled columns
+    out8[4] = raw[2] >> 32;                       // Householder fallbacks
+    out8[5] = (raw[1] >> 32) & 0xffffull;         // panels with >= 3 passes
+    out8[6] = raw[1] >> 48;                       // panels with >= 4 passes
+    out8[7] = 0;
     if (reset) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if ((e = hipMemcpyToSymbol(HIP_SYMBOL(cq_stats), z, sizeof(z))) != hipSuccess) return hip_fail(e, "reset panel statistics");

@@ -689,9 +689,15 @@ static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k,
             const int64_t mp = m - j0, nin = Jend - j0;                         // the panel's update stays inside the block
             const int p = (int)(j0 / nb);
             Mat Ap = sub(Am, j0, j0), Yp = sub(Ym, j0, j0);
-            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1))) return rc;
             double* Tp = w.T + (int64_t)p * nb * nb;
             Mat Wp = mat(w.W, wrs, wcs);
+            if (!use_tsqr) {
+                // orthonormalisation + Householder reconstruction + the tall products in one chain of launches (cholqr.hip)
+                if ((rc = cholqr_panel(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, (uint64_t)p + 1, 1, Tp, Wp.p, wrs, wcs,
+                                       nullptr)))
+                    return rc;
+            } else {
+            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1))) return rc;
             // Wq_top goes to a scratch corner of the (otherwise unused here) Wq buffer: only Y, T and W = Y T^T are needed
             TN_PROF_LAUNCH(st, PROF_LU, hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT,
                                w.UTq, Wp.p, wrs, wcs, w.Wq));
@@ -703,6 +709,7 @@ static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k,
                                    (const double*)nullptr, sub(Wp, b, 0).p, wrs, wcs, (double*)nullptr);
                 TN_CHECK_LAUNCH("rows_times_small3_kernel");
                 prof_end(st, PROF_ROWS_SMALL, 4.0 * (mp - b) * b * b, 24.0 * (mp - b) * b);
+            }
             }
             Mat Xm = mat(w.X, nin, 1);
             if ((rc = gemm(st, b, nin, mp, 1.0, tr(Yp), Ap, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
@@ -869,7 +876,14 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
             TN_CHECK_LAUNCH("swap_columns_kernel");
         }
         // --- panel orthonormalisation
-        if (nb == 32) {
+        const bool fused_panel = (nb == 32 && !use_tsqr);     // orthonormalisation + reconstruction + tall products in one chain (cholqr.hip)
+        if (fused_panel) {
+            double* Tpf = w.T + (int64_t)p * nb * nb;
+            Mat Wqf = sub(Wqm, j0, j0), Wpf = mat((lookahead && (p & 1)) ? w.W2 : w.W, wrs, wcs);
+            if ((rc = cholqr_panel(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, (uint64_t)p + 1, 1, Tpf, Wpf.p, wrs, wcs,
+                                   Wqf.p)))
+                return rc;
+        } else if (nb == 32) {
             if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1))) return rc;
         } else {
             if ((rc = copy_mat(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b))) return rc;
@@ -895,16 +909,17 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         // --- Householder reconstruction
         double* Tp = w.T + (int64_t)p * nb * nb;
         Mat Wqp = sub(Wqm, j0, j0), Wp = mat((lookahead && (p & 1)) ? w.W2 : w.W, wrs, wcs);
-        if (nb == 32)
+        if (fused_panel) {
+        } else if (nb == 32)
             TN_PROF_LAUNCH(st, PROF_LU, hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT, w.UTq,
                                Wp.p, wrs, wcs, Wqp.p));
         else
             TN_PROF_LAUNCH(st, PROF_LU, hipLaunchKernelGGL((lu_reconstruct_kernel<64>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT, w.UTq,
                                Wp.p, wrs, wcs, Wqp.p));
-        TN_CHECK_LAUNCH("lu_reconstruct_kernel");
+        if (!fused_panel) TN_CHECK_LAUNCH("lu_reconstruct_kernel");
         dbg_check(st, Tp, b, 1, b, b, "T", p, 9);
         dbg_check(st, w.Uinv, b, 1, b, b, "Uinv", p, 9);
-        if (mp > b) {            // rows below the top block: Y <- Q1 Uinv,  W <- Q1 (Uinv T^T),  Wq <- Q1 (Uinv T)
+        if (mp > b && !fused_panel) {            // rows below the top block: Y <- Q1 Uinv,  W <- Q1 (Uinv T^T),  Wq <- Q1 (Uinv T)
             dim3 grid((unsigned)cdiv(mp - b, 256));
             prof_begin(st, PROF_ROWS_SMALL);
             if (nb == 32)
