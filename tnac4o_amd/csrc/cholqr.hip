@@ -786,13 +786,19 @@ __device__ __forceinline__ void cq_post_tile(int blk, int nblk, int64_t nrows, i
             for (int u = 0; u < 8; ++u) {
                 const int e = tid + 256 * (u0 + u);
                 const int i = drow ? e >> 5 : e & 255, j = drow ? e & 31 : e >> 8;
-                ov[u] = (r0 + i < b) ? top[(r0 + i) * 32 + j] : tile[i * CQ_P + j];
+                ov[u] = tile[i * CQ_P + j];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = tid + 256 * (u0 + u);
                 const int i = drow ? e >> 5 : e & 255, j = drow ? e & 31 : e >> 8;
-                if (i < nr && j < b) dst[(r0 + i) * drs + j * dcs] = ov[u];
+                if (i < nr && j < b && r0 + i >= b) dst[(r0 + i) * drs + j * dcs] = ov[u];
+            }
+        }
+        if (r0 < b) {                                     // (the first tile only) the top block comes from the reconstruction
+            for (int e = tid; e < 1024; e += 256) {
+                const int i = e >> 5, j = e & 31;
+                if (i >= r0 && i - r0 < nr && i < b && j < b) dst[(int64_t)i * drs + j * dcs] = top[i * 32 + j];
             }
         }
         __syncthreads();

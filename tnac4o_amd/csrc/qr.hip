@@ -453,7 +453,26 @@ __global__ __launch_bounds__(256) void diag_qr_kernel(const double* __restrict__
         __syncthreads();
     }
     const int c = tid % NB, g = tid / NB;
-    for (int j = 0; j < b; ++j) {
+    // Fast path: the panel step hands over an orthonormal basis Q1 with span(Q1[:, :j]) = span(panel[:, :j]) (Cholesky-QR and the
+    // Householder TSQR are both triangular orthogonalisations), so the block D = S Q1^T A_panel is upper triangular already, up to
+    // rounding (|d_ij| <~ eps ||a_j|| below the diagonal).  Then Z = I: dropping entries below 4e-15 of their column's norm is a
+    // column-wise backward error of the size every other step of the factorisation makes, and it saves the 2 x 32 serial
+    // Householder steps (50 us of pure latency per tn_qr call).  Anything else (64-wide first-generation panels) takes the general path.
+    __shared__ int notri;
+    if (tid == 0) notri = 0;
+    __syncthreads();
+    if (tid < b) {
+        double below = 0.0, all2 = 0.0;
+        for (int r = 0; r < b; ++r) {
+            const double x = D[r * P + tid];
+            all2 += x * x;
+            if (r > tid) below = fmax(below, fabs(x));
+        }
+        if (!(below * below <= 1.6e-29 * all2)) notri = 1;          // (4e-15)^2; NaN lands here too
+    }
+    __syncthreads();
+    const bool tri = (notri == 0);
+    for (int j = 0; j < b && !tri; ++j) {
         double s = 0.0;
         if (c < b)
             for (int r = j + 1 + g; r < b; r += NG) s += D[r * P + j] * D[r * P + c];
@@ -483,7 +502,7 @@ __global__ __launch_bounds__(256) void diag_qr_kernel(const double* __restrict__
         if (tid == 0) tau[j] = t;
         __syncthreads();
     }
-    for (int j = b - 1; j >= 0; --j) {            // Z = H_0 ... H_{b-1}
+    for (int j = b - 1; j >= 0 && !tri; --j) {    // Z = H_0 ... H_{b-1}
         const double t = tau[j];
         if (t != 0.0) {                            // uniform
             double s = 0.0;
