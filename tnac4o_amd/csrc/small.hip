@@ -104,10 +104,8 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
     __shared__ double G[NB * P];
     __shared__ double J[NB * P];
     __shared__ double dsc[NB];
-    __shared__ double rc[NB / 2], rsn[NB / 2];
-    __shared__ int rp[NB / 2], rq[NB / 2];
     __shared__ int cnt, total;
-    __shared__ int stepflag[NB];            // one flag per round-robin step (no reset barrier inside the sweep)
+    __shared__ int stepflag[2];             // "some rotation in this step", double-buffered over consecutive steps
     __shared__ double red[256];
     const int tid = threadIdx.x, grp = blockIdx.x;
     const int n = (nvec + 1) & ~1;          // even working size (a padding index never rotates)
@@ -198,73 +196,92 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
     // so they never rotate).  Trip counts are compile-time so that each phase issues all of its LDS loads at once.
     const bool need = (mode != 1) && (nvec >= 2) && (red[0] > 8.881784197001252e-16);
     if (need) {
-        constexpr int HP = NB / 2, IT = HP * NB / 256;
+        // Each step of the round-robin tournament applies NB/2 disjoint plane rotations R: G <- R^T G R as independent 2 x 2
+        // blocks (rotation a x rotation b), J <- J R as (row i, rotation b).  A thread keeps the same rotation slots for the
+        // whole sweep and derives their index pairs arithmetically, so a step costs it one 16-byte read per coefficient pair
+        // plus the data itself (the first version fetched indices and coefficients separately for every element: twice as
+        // many LDS instructions as data accesses, and the step is LDS-bound).
+        constexpr int HP = NB / 2, GB = HP * HP / 256, JB = NB * HP / 256;
+        __shared__ __attribute__((aligned(16))) double cs2[HP * 2];      // (c, s) of slot a
         const double tol = 8.881784197001252e-16;      // 2^-50
+        // thread -> (rotation b = tid % HP on the column side, rotations / rows tid / HP + (256 / HP) k on the row side): the HP
+        // lanes that share a row read HP distinct columns of it (no bank conflicts), and b is the same for all of a thread's work
+        const int tb = tid % HP, t0 = tid / HP;
+        constexpr int TS = 256 / HP;
+        auto slot_pair = [](int s, int a, int& p, int& q) {
+            if (a == 0) { p = NB - 1; q = s; }
+            else { p = s + a; p -= (p >= NB - 1) ? NB - 1 : 0; q = s - a; q += (q < 0) ? NB - 1 : 0; }
+            if (p > q) { const int t = p; p = q; q = t; }
+        };
         for (int sweep = 0; sweep < max_sweeps; ++sweep) {
             if (tid == 0) cnt = 0;
-            if (tid < NB) stepflag[tid] = 0;
             int mine = 0;                                  // rotations decided by this thread in this sweep
             __syncthreads();
             for (int s = 0; s < NB - 1; ++s) {
-                if (tid < HP) {
-                    int p, q;
-                    rr_pair(NB, s, tid, p, q);
-                    const double gpq = G[p * P + q], gpp = G[p * P + p], gqq = G[q * P + q];
-                    double c = 1.0, sn = 0.0;
-                    // rotate iff |g_pq| > tol sqrt(g_pp g_qq), tested on the squares (no square root on the critical path)
-                    const double g2 = gpq * gpq;
-                    if (g2 > tol * tol * fabs(gpp * gqq)) {
-                        // smaller-angle rotation from the double angle: cos 2t = |d| / hyp, d = g_qq - g_pp,
-                        // hyp^2 = d^2 + 4 g_pq^2;  c^2 = (1 + cos 2t) / 2,  s = g_pq / (hyp c) with the sign of d g_pq
-                        // (two reciprocal square roots in sequence instead of rcp - rsqrt - rcp - rsqrt)
-                        const double d = gqq - gpp;
-                        const double rh = fast_rsqrt(d * d + 4.0 * g2);
-                        const double c2 = 0.5 + 0.5 * fabs(d) * rh;
-                        const double rcv = fast_rsqrt(c2);
-                        const double sabs = fabs(gpq) * rh * rcv;
-                        if (sabs <= 1.0 && c2 <= 1.0000000000000002) {     // (fails for non-finite intermediates: no rotation)
-                            c = c2 * rcv;
-                            sn = ((d >= 0.0) == (gpq >= 0.0)) ? sabs : -sabs;
-                            ++mine;
-                            stepflag[s] = 1;
+                if (tid < 64) {                            // wave 0 decides the rotations of this step
+                    bool rot = false;
+                    if (tid < HP) {
+                        int p, q;
+                        slot_pair(s, tid, p, q);
+                        const double gpq = G[p * P + q], gpp = G[p * P + p], gqq = G[q * P + q];
+                        double c = 1.0, sn = 0.0;
+                        // rotate iff |g_pq| > tol sqrt(g_pp g_qq), tested on the squares (no square root on the critical path)
+                        const double g2 = gpq * gpq;
+                        if (g2 > tol * tol * fabs(gpp * gqq)) {
+                            // smaller-angle rotation from the double angle: cos 2t = |d| / hyp, d = g_qq - g_pp,
+                            // hyp^2 = d^2 + 4 g_pq^2;  c^2 = (1 + cos 2t) / 2,  s = g_pq / (hyp c) with the sign of d g_pq
+                            const double d = gqq - gpp;
+                            const double rh = fast_rsqrt(d * d + 4.0 * g2);
+                            const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+                            const double rcv = fast_rsqrt(c2);
+                            const double sabs = fabs(gpq) * rh * rcv;
+                            if (sabs <= 1.0 && c2 <= 1.0000000000000002) {     // (fails for non-finite intermediates: no rotation)
+                                c = c2 * rcv;
+                                sn = ((d >= 0.0) == (gpq >= 0.0)) ? sabs : -sabs;
+                                ++mine;
+                                rot = true;
+                            }
                         }
+                        *reinterpret_cast<double2*>(&cs2[2 * tid]) = make_double2(c, sn);
                     }
-                    rc[tid] = c; rsn[tid] = sn; rp[tid] = p; rq[tid] = q;
+                    const unsigned long long any = __ballot(rot);
+                    if (tid == 0) stepflag[s & 1] = (any != 0ull) ? 1 : 0;
                 }
                 __syncthreads();
-                if (stepflag[s] == 0) continue;                    // uniform: nothing to rotate in this step
-                {   // G <- R^T G R as independent 2x2 blocks (pair a x pair b);  J <- J R as (row i, pair b)
-                    constexpr int GB = HP * HP / 256, JB = NB * HP / 256;
-                    double g00[GB], g01[GB], g10[GB], g11[GB], jp[JB], jq[JB];
+                if (stepflag[s & 1] == 0) continue;                // uniform: nothing to rotate in this step
+                {
+                    int pb, qb;
+                    slot_pair(s, tb, pb, qb);
+                    const double2 rb = *reinterpret_cast<const double2*>(&cs2[2 * tb]);
+                    const double cb = rb.x, sb = rb.y;
+                    double g00[GB], g01[GB], g10[GB], g11[GB];
+                    int pa[GB], qa[GB];
+                    double2 ra[GB];
 #pragma unroll
                     for (int k = 0; k < GB; ++k) {
-                        const int e = tid + 256 * k, a = e / HP, b = e % HP;
-                        const int pa = rp[a], qa = rq[a], pb2 = rp[b], qb = rq[b];
-                        g00[k] = G[pa * P + pb2]; g01[k] = G[pa * P + qb];
-                        g10[k] = G[qa * P + pb2]; g11[k] = G[qa * P + qb];
+                        slot_pair(s, t0 + TS * k, pa[k], qa[k]);
+                        ra[k] = *reinterpret_cast<const double2*>(&cs2[2 * (t0 + TS * k)]);
+                        g00[k] = G[pa[k] * P + pb]; g01[k] = G[pa[k] * P + qb];
+                        g10[k] = G[qa[k] * P + pb]; g11[k] = G[qa[k] * P + qb];
                     }
+                    double jp[JB], jq[JB];
 #pragma unroll
                     for (int k = 0; k < JB; ++k) {
-                        const int e = tid + 256 * k, i = e / HP, b = e % HP;
-                        jp[k] = J[i * P + rp[b]];
-                        jq[k] = J[i * P + rq[b]];
+                        jp[k] = J[(t0 + TS * k) * P + pb];
+                        jq[k] = J[(t0 + TS * k) * P + qb];
                     }
 #pragma unroll
                     for (int k = 0; k < GB; ++k) {
-                        const int e = tid + 256 * k, a = e / HP, b = e % HP;
-                        const int pa = rp[a], qa = rq[a], pb2 = rp[b], qb = rq[b];
-                        const double ca = rc[a], sa = rsn[a], cb = rc[b], sb = rsn[b];
+                        const double ca = ra[k].x, sa = ra[k].y;
                         const double t00 = ca * g00[k] - sa * g10[k], t01 = ca * g01[k] - sa * g11[k];
                         const double t10 = sa * g00[k] + ca * g10[k], t11 = sa * g01[k] + ca * g11[k];
-                        G[pa * P + pb2] = cb * t00 - sb * t01; G[pa * P + qb] = sb * t00 + cb * t01;
-                        G[qa * P + pb2] = cb * t10 - sb * t11; G[qa * P + qb] = sb * t10 + cb * t11;
+                        G[pa[k] * P + pb] = cb * t00 - sb * t01; G[pa[k] * P + qb] = sb * t00 + cb * t01;
+                        G[qa[k] * P + pb] = cb * t10 - sb * t11; G[qa[k] * P + qb] = sb * t10 + cb * t11;
                     }
 #pragma unroll
                     for (int k = 0; k < JB; ++k) {
-                        const int e = tid + 256 * k, i = e / HP, b = e % HP;
-                        const double cb = rc[b], sb = rsn[b];
-                        J[i * P + rp[b]] = cb * jp[k] - sb * jq[k];
-                        J[i * P + rq[b]] = sb * jp[k] + cb * jq[k];
+                        J[(t0 + TS * k) * P + pb] = cb * jp[k] - sb * jq[k];
+                        J[(t0 + TS * k) * P + qb] = sb * jp[k] + cb * jq[k];
                     }
                 }
                 __syncthreads();
