@@ -40,6 +40,11 @@ expect_neg(L.tn_qr(P, 4, 1, 0, 4, P, 4, 1, P, 4, 1, 32, 0.0, None, P, 1 << 20, N
 expect_neg(L.tn_qr(P, 4, 1, 8, 4, P, 4, 1, P, 4, 1, 48, 0.0, None, P, 1 << 20, None, None), 'tn_qr bad nb')
 expect_neg(L.tn_qr(P, 4, 1, 8, 4, P, 4, 1, P, 4, 1, 32, 0.0, None, P, 16, None, None), 'tn_qr small ws')
 expect_neg(L.tn_qr(P, 4, 1, 8, 4, P, 4, 1, P, 4, 1, 32, 2.0, None, P, 1 << 20, None, None), 'tn_qr rank_tol')
+expect_neg(L.tn_panel_orth(None, 4, 1, 64, 4, P, 4, 1, 0, None, None, P, 1 << 20, None), 'tn_panel_orth null')
+expect_neg(L.tn_panel_orth(P, 4, 1, 64, 4, P, 4, 1, 2, None, None, P, 1 << 20, None), 'tn_panel_orth method')
+expect_neg(L.tn_panel_orth(P, 4, 1, 64, 4, P, 4, 1, 0, None, None, P, 16, None), 'tn_panel_orth ws')
+expect_neg(L.tn_panel_orth(P, 40, 1, 64, 40, C.cast(C.byref(host, 8), C.c_void_p), 40, 1, 1, None, None, P, 1 << 22, None), 'tn_panel_orth width')
+expect_neg(L.tn_panel_stats(None, 0), 'tn_panel_stats null')
 expect_neg(L.tn_svd_trunc(P, 4, 1, 4, 4, 0, 0.0, P, 4, 1, P, P, 4, 1, C.byref(i64), None, None, None, P, 1 << 20, None), 'tn_svd_trunc Dmax')
 expect_neg(L.tn_svd_trunc(P, 4, 1, 4, 4, 4, 0.0, P, 4, 1, P, P, 4, 1, None, None, None, None, P, 1 << 20, None), 'tn_svd_trunc keep')
 expect_neg(L.tn_svd_trunc(P, 4, 1, 4, 4, 4, 0.0, P, 4, 1, P, P, 4, 1, C.byref(i64), None, None, None, P, 8, None), 'tn_svd_trunc ws')

@@ -535,3 +535,89 @@ def test_qr_two_level_blocking(ops, nbo, colmajor):
             os.environ.pop('TN_QR_NBO', None)
         else:
             os.environ['TN_QR_NBO'] = saved
+
+
+# ------------------------------------------------------------------------------------------------ panel step of tn_qr
+def _panel_cases():
+    g = torch.Generator(device='cpu').manual_seed(7)
+    rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g).cuda()
+    out = [('randn 16384x32', rn(16384, 32)), ('col-major', rn(32, 5000).t()), ('ragged 300x32', rn(300, 32)), ('square', rn(32, 32)),
+           ('narrow 1000x17', rn(1000, 17)), ('single column', rn(5000, 1)),
+           ('graded columns', rn(8192, 32) * torch.logspace(0, -30, 32, dtype=torch.float64).cuda()[None, :])]
+    for kappa in (1e4, 1e8, 1e12, 1e15):
+        U, _ = torch.linalg.qr(rn(4096, 32))
+        V, _ = torch.linalg.qr(rn(32, 32))
+        out.append(('kappa %.0e' % kappa, (U * torch.logspace(0, -float(np.log10(kappa)), 32, dtype=torch.float64).cuda()[None, :]) @ V.t()))
+    X = rn(4096, 32)
+    X[:, 5] = 0.0
+    X[:, 9] = X[:, 2]
+    X[:, 20] = 2.0 * X[:, 3]
+    X[:, 31] = X[:, 0] + 1e-13 * X[:, 31]
+    out += [('zero / duplicate / dependent columns', X), ('all zero', torch.zeros(2048, 32, dtype=torch.float64).cuda()),
+            ('rank 3', rn(4096, 3) @ rn(3, 32)), ('scaled 1e-200', rn(2048, 32) * 1e-200), ('one block 1e150 larger', rn(4096, 32))]
+    out[-1][1][:256] *= 1e150
+    return out
+
+
+def _panel_quality(X, Y):
+    b = X.shape[1]
+    orth = (Y.t() @ Y - torch.eye(b, dtype=torch.float64, device=X.device)).abs().max().item()
+    cn = X.norm(dim=0)
+    res = ((X - Y @ (Y.t() @ X)).norm(dim=0) / torch.where(cn > 0, cn, torch.ones_like(cn))).max().item()
+    return orth, res
+
+
+@pytest.mark.parametrize('method', [0, 1])
+def test_panel_orth_basis_of_the_column_space(ops, method):
+    """tn_panel_orth (the panel step of tn_qr: iterated Cholesky-QR with deferral, and the Householder TSQR it replaced): an
+    orthonormal basis to 2e-14 whose span contains every column of the panel to 2e-14 of its norm, on well-conditioned, graded,
+    nearly dependent (kappa up to 1e15), rank-deficient, zero and badly scaled panels; the input is left untouched."""
+    for name, X in _panel_cases():
+        Xc = X.clone()
+        Y = ops.panel_orth(X, method)
+        assert torch.equal(X, Xc), name
+        orth, res = _panel_quality(X, Y)
+        assert orth < 2e-14 and res < 2e-14, (name, orth, res)
+
+
+def test_panel_orth_state_and_reproducibility(ops):
+    """A well-conditioned panel converges in one substitution pass, kappa = 1e12 needs deferrals and more passes, a zero column is
+    refilled; two runs on the same panel are bit-identical (partial Gram matrices are summed in block order)."""
+    cases = dict(_panel_cases())
+    Y, st, dev = ops.panel_orth(cases['randn 16384x32'], 0, state=True)
+    assert st[1] == 1 and st[3] == 1 and st[6] == 0 and st[7] == 0 and st[8] == 0 and dev[1] < 5e-15
+    Y2 = ops.panel_orth(cases['randn 16384x32'], 0)
+    assert torch.equal(Y, Y2)
+    _, st, _ = ops.panel_orth(cases['kappa 1e+12'], 0, state=True)
+    assert st[1] == 1 and st[3] >= 2 and st[6] > 0 and st[8] == 0
+    _, st, _ = ops.panel_orth(cases['zero / duplicate / dependent columns'], 0, state=True)
+    assert st[7] >= 1 and st[8] == 0
+
+
+def test_qr_fused_panel_matches_tsqr_panel(ops):
+    """tn_qr with the fused Cholesky-QR panel chain (orthonormalisation + Householder reconstruction + reflector products in
+    cholqr.hip) against the same factorisation with the Householder TSQR panel step and separate reconstruction kernels: both are
+    QR factorisations to rounding and agree in |R|."""
+    g = torch.Generator(device='cpu').manual_seed(11)
+    rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g).cuda()
+    A = (rn(8192, 256) * torch.logspace(0, -20, 256, dtype=torch.float64).cuda()[None, :]) @ torch.linalg.qr(rn(256, 256))[0]
+    mats = [rn(4096, 256), rn(300, 1000).t(), rn(300, 1000), rn(50, 7), rn(4096, 64) @ rn(64, 512), A]
+    saved = os.environ.get('TN_PANEL')
+    try:
+        for T in mats:
+            res = {}
+            for panel in ('chol', 'tsqr'):
+                os.environ['TN_PANEL'] = panel
+                Q, R = ops.qr(T)
+                k = Q.shape[1]
+                rel = ((Q @ R - T).norm(dim=0) / T.norm(dim=0).clamp_min(1e-300)).max().item()
+                orth = (Q.t() @ Q - torch.eye(k, dtype=torch.float64, device='cuda')).abs().max().item()
+                assert rel < 1e-13 and orth < 1e-13, (tuple(T.shape), panel, rel, orth)
+                assert (torch.diagonal(R) >= 0).all()
+                res[panel] = R
+            assert ((res['chol'].abs() - res['tsqr'].abs()).abs().max() / T.abs().max()).item() < 1e-12
+    finally:
+        if saved is None:
+            os.environ.pop('TN_PANEL', None)
+        else:
+            os.environ['TN_PANEL'] = saved

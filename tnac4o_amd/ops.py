@@ -220,6 +220,34 @@ def qr_into(T, Q, R, overwrite=False, nb=None, rank_tol=0.0):
     return Q, R, int(keff.value)
 
 
+def panel_orth(X, method=0, state=False, out=None):
+    """The panel step of tn_qr on its own (tn_panel_orth): an orthonormal basis of the column space of the (strided) n x b panel X,
+    b <= 32.  method 0: iterated Cholesky-QR with deferral (what tn_qr uses), 1: Householder TSQR.  With state=True also returns
+    the panel's state record (list of 9 ints, see include/tnpeps.h) and max|X^T X - I| before each pass (synchronises)."""
+    _need_gpu(X)
+    n, b = X.shape
+    L = lib()
+    wsb = L.tn_panel_orth_ws_bytes(n, b)
+    ws = workspace(wsb, 7)
+    Y = out if out is not None else torch.empty_like(X)
+    st9 = (C.c_int * 9)() if state else None
+    dev = (C.c_double * 8)() if state else None
+    check(L.tn_panel_orth(X.data_ptr(), X.stride(0), X.stride(1), n, b, Y.data_ptr(), Y.stride(0), Y.stride(1), int(method), st9, dev,
+                          ws.data_ptr(), wsb, _stream()))
+    if state:
+        return Y, list(st9), [dev[i] for i in range(6)]
+    return Y
+
+
+def panel_stats(reset=False):
+    """Process-wide counters of the Cholesky-QR panel step since the last reset (tn_panel_stats): dict."""
+    st = (C.c_uint64 * 8)()
+    check(lib().tn_panel_stats(st, 1 if reset else 0))
+    keys = ('panels', 'substitution_passes', 'deferred_pivots', 'refilled_columns', 'householder_fallbacks', 'panels_with_3_or_more_passes',
+            'panels_with_4_or_more_passes')
+    return {k: int(st[i]) for i, k in enumerate(keys)}
+
+
 def qr(T, overwrite=False, nb=None):
     """Economic QR (Q, R) of a 2-D view; T is preserved unless overwrite is set."""
     m, n = T.shape

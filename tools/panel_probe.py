@@ -12,19 +12,7 @@ from tnac4o_amd import ops
 from tnac4o_amd._lib import lib, check
 
 
-def panel_orth(X, method=0, state=False, out=None):
-    n, b = X.shape
-    L = lib()
-    wsb = L.tn_panel_orth_ws_bytes(n, b)
-    ws = ops.workspace(wsb, 7)
-    Y = out if out is not None else torch.empty_like(X)
-    st9 = (C.c_int * 9)() if state else None
-    dev = (C.c_double * 8)() if state else None
-    check(L.tn_panel_orth(X.data_ptr(), X.stride(0), X.stride(1), n, b, Y.data_ptr(), Y.stride(0), Y.stride(1), method, st9, dev,
-                          ws.data_ptr(), wsb, ops._stream()))
-    if state:
-        return Y, list(st9), [dev[i] for i in range(6)]
-    return Y
+panel_orth = ops.panel_orth
 
 
 def quality(X, Y):
