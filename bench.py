@@ -36,14 +36,17 @@ import torch         # noqa: E402
 
 FAMILIES = ['gemm_kernel<128,128>', 'gemm_kernel<128,32>', 'gemm_kernel<32,128>', 'gemm_kernel<64,64>',
             'splitk_reduce_kernel', 'absorb_kernel', 'gram_partial_kernel', 'eig_small_kernel',
-            'rows_times_small_kernel', 'small_t_times_vecs_kernel', 'tsqr_factor/apply_kernel',
+            'rows_times_small_kernel', 'small_t_times_vecs_kernel', 'panel step (cq_gram / cq_pass / cq_post)',
             'lu_reconstruct_kernel', 'qr_aux (diag_qr, assemble_R, init_Q, norms, copies)',
             'svd_aux (norms, init, gather)', 'misc (nfactor, scaling, builders)']
 COUNTERS = {'qr_nominal': 15, 'svd_nominal': 16, 'svd_stream': 17, 'svdvals_nominal': 18}   # counter-only families
 PHASES = ['gemm_var (attach / projector / environment GEMMs, scaling)', 'absorb', 'qr', 'svd_trunc', 'svdvals', 'mpo_build']
 MFMA_FAM = {0, 1, 2, 3}
 SERIAL_FAM = {7: ('eig_small_kernel', 'Jacobi step (32 plane rotations of a 64 x 64 Gram matrix in LDS)', 126),
-              10: ('tsqr_factor/apply_kernel', 'Householder column of a 256 x 32 block', 32)}
+              10: ('panel step (cq_gram / cq_pass / cq_post)',
+                   'launch of the panel chain (6 per panel: Gram + 32-step one-wave Cholesky, up to 4 substitution passes of which '
+                   'those after convergence return at once, reflector products); each is a chain of 3-6 dependent memory round trips '
+                   'plus the serial tail of its last workgroup', 1)}
 PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X fp64 matrix peak (vendor figure quoted in SURVEY.md §7; not in the microarch guide)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 WORKLOADS = {'chimera2048': ('Ising', 16, 20260004, 3.0), 'chimera512': ('Ising', 8, 20260003, 3.0),

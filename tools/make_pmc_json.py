@@ -41,21 +41,17 @@ for k in F:
                'traffic_bytes_per_launch': (fb + wb) / n}
 
 fam = {}
-ts = [k for k in kern if 'tsqr_factor_kernel' in k or 'tsqr_apply_wy_kernel' in k]
+ts = [k for k in kern if 'cq_gram_kernel' in k or 'cq_pass_kernel' in k or 'cq_post_kernel' in k]
 n = sum(kern[k]['dispatches'] for k in ts)
 fb = sum(kern[k]['fetch_bytes_per_launch'] * kern[k]['dispatches'] for k in ts)
 wb = sum(kern[k]['write_bytes_per_launch'] * kern[k]['dispatches'] for k in ts)
-# algorithmic bytes of the TSQR family over one 16384 x 1024 QR: 16 B per panel element per level (read + write), levels shrink 8x
+# algorithmic bytes of the panel chain over one 16384 x 1024 QR: per panel the Gram launch reads the panel (8 B per element), a
+# substitution pass reads and writes it (16 B), the post launch reads it and writes Y and W (24 B); two passes per panel assumed
 alg = 0.0
 for p in range(32):
     rows = 16384 - 32 * p
-    while True:
-        nblk = -(-rows // 256)
-        alg += 2 * 16.0 * rows * 32          # factor + apply of this level
-        if nblk == 1:
-            break
-        rows = nblk * 32
-fam['tsqr_factor/apply_kernel'] = {'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
+    alg += (8.0 + 2 * 16.0 + 24.0) * rows * 32
+fam['panel step (cq_gram / cq_pass / cq_post)'] = {'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
                                    'traffic_bytes_per_launch': (fb + wb) / n, 'algorithmic_bytes_per_launch': alg / n,
                                    'traffic_over_algorithmic': (fb + wb) / alg}
 for name, pat in (('eig_small_kernel', 'eig_small_kernel'), ('absorb_kernel', 'absorb_mfma_kernel')):
@@ -66,7 +62,7 @@ for name, pat in (('eig_small_kernel', 'eig_small_kernel'), ('absorb_kernel', 'a
 
 # whole-call traffic: tn_qr 16384 x 1024 = every kernel of the QR (the probe runs exactly one such QR under the counters;
 # gemm<128,128,true,false> also contains the 3 plain 16384x1024x1024 products of the probe, which are subtracted)
-qr_names = ['tsqr_factor_kernel', 'tsqr_apply_wy_kernel', 'lu_reconstruct_kernel', 'rows_times_small3_mfma_kernel', 'diag_qr_kernel',
+qr_names = ['cq_gram_kernel', 'cq_pass_kernel', 'cq_post_kernel', 'diag_qr_kernel',
             'assemble_R_kernel', 'init_Q_kernel', 'splitk_reduce_kernel', 'gemm_kernel<32, 128, false, false, false>',
             'gemm_kernel<128, 32, true, false, false>']
 qr_bytes = 0.0
@@ -106,7 +102,7 @@ for k in kern:
                    'mfma_busy_over_wave_cycles': a['SQ_VALU_MFMA_BUSY_CYCLES'][2] / max(1.0, b.get('SQ_WAVE_CYCLES', (0, 0, 1))[2])}
 out = {'source': 'rocprofv3 --pmc (separate passes: FETCH_SIZE; WRITE_SIZE; SQ MFMA counters) over tools/pmc_probe.py on MI355X, '
                  'round 2; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md); KB -> bytes',
-       'shapes': 'tn_qr 16384 x 1024 (nb=32, 32 panels x 3 TSQR levels), tn_svd_trunc 320 x 1024 (leading rows of the triangular factor of a graded rank-300 matrix), tn_absorb bulk '
+       'shapes': 'tn_qr 16384 x 1024 (nb=32, 32 panels x 6 launches of the Cholesky-QR panel chain), tn_svd_trunc 320 x 1024 (leading rows of the triangular factor of a graded rank-300 matrix), tn_absorb bulk '
                  'site, tn_gemm 16384 x 1024 x 1024',
        'families': fam, 'kernels': kern, 'whole_call': whole, 'svd_step': svd,
        'mfma_counters': {'file': 'profiles/r02_pmc_traffic.json (mfma_counters.kernels)', 'kernels': mfma,

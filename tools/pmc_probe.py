@@ -1,5 +1,5 @@
 """Tiny workload for PMC collection: absorb at the bulk shape (x5), one large GEMM (x3), ONE QR of an absorbed-bulk-site shape
-(16384 x 1024, nb = 32: tsqr_factor / tsqr_apply / lu_reconstruct / rows_times_small3 / trailing GEMMs) and ONE truncated SVD
+(16384 x 1024, nb = 32: the Cholesky-QR panel chain cq_gram / cq_pass / cq_post and the trailing GEMMs) and ONE truncated SVD
 of a centre matrix as the sweep produces them (the leading 320 rows of the triangular factor of a graded rank-300 matrix,
 i.e. what the rank-revealing QR of a truncating pass hands over: eig_small + pair GEMMs).  Inputs are prepared with torch
 (rocSOLVER / rocBLAS kernels, not counted).  Run under rocprofv3 --pmc in separate passes (tools/collect_profiles.sh);
