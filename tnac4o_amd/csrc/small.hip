@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                                                         int max_sweeps, double dead_thresh,
                                                         double* __restrict__ out, int* __restrict__ dead,
                                                         int* __restrict__ nrot_out, double* __restrict__ maxoff_out,
-                                                        double relevant2) {
+                                                        double relevant2, double bip_thr) {
     constexpr int P = NB + 1;
     __shared__ double G[NB * P];
     __shared__ double J[NB * P];
@@ -172,21 +172,24 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
             rdg[tid] = (gii > relevant2 && tid < nvec) ? fast_rcp(gii) : 0.0;
         }
         __syncthreads();
-        double m = 0.0;
+        double m = 0.0, mw = 0.0;                          // all pairs / pairs inside one half (one block of the SVD's pair)
 #pragma unroll
         for (int t = 0; t < NB * NB / 256; ++t) {
             const int e = tid + 256 * t, i = e / NB, j = e % NB;
             const double g = G[i * P + j];
             const double r2 = (i < j) ? g * g * rdg[i] * rdg[j] : 0.0;
             m = r2 > m ? r2 : m;
+            if ((i < NB / 2) == (j < NB / 2)) mw = r2 > mw ? r2 : mw;
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
-        if ((tid & 63) == 0) red[tid >> 6] = m;
+        for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o, 64)); mw = fmax(mw, __shfl_xor(mw, o, 64)); }
+        if ((tid & 63) == 0) { red[tid >> 6] = m; red[8 + (tid >> 6)] = mw; }
         __syncthreads();
         if (tid == 0) {
             const double mm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            const double mmw = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
             red[0] = sqrt(mm);
+            red[4] = sqrt(mmw);
             if (maxoff_out) maxoff_out[grp] = red[0];
         }
         __syncthreads();
@@ -208,7 +211,15 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
         // lanes that share a row read HP distinct columns of it (no bank conflicts), and b is the same for all of a thread's work
         const int tb = tid % HP, t0 = tid / HP;
         constexpr int TS = 256 / HP;
-        auto slot_pair = [](int s, int a, int& p, int& q) {
+        // Bipartite sweeps (SVD pair step): when the two halves are each orthogonal already -- every block leaves its previous
+        // visit that way -- and the coupling between them is small, only the NB/2 x NB/2 cross pairs are rotated: NB/2 steps
+        // (slot a pairs a with NB/2 + (a + s) mod NB/2) instead of NB - 1.  What a cross rotation of angle t re-creates inside
+        // a half is O(t^2), the same order a cyclic sweep leaves behind, so the quadratic convergence of the outer block Jacobi
+        // is kept at half the steps; a pair that does not qualify (first visits, large angles) gets the cyclic sweep.
+        const bool bip = (bip_thr > 0.0) && (mode == 2) && (nvec == NB) && (red[0] <= bip_thr) && (red[4] <= 0.1 * red[0]);
+        const int nsteps = bip ? HP : NB - 1;
+        auto slot_pair = [bip](int s, int a, int& p, int& q) {
+            if (bip) { p = a; q = HP + ((a + s) & (HP - 1)); return; }
             if (a == 0) { p = NB - 1; q = s; }
             else { p = s + a; p -= (p >= NB - 1) ? NB - 1 : 0; q = s - a; q += (q < 0) ? NB - 1 : 0; }
             if (p > q) { const int t = p; p = q; q = t; }
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
             if (tid == 0) cnt = 0;
             int mine = 0;                                  // rotations decided by this thread in this sweep
             __syncthreads();
-            for (int s = 0; s < NB - 1; ++s) {
+            for (int s = 0; s < nsteps; ++s) {
                 if (tid < 64) {                            // wave 0 decides the rotations of this step
                     bool rot = false;
                     if (tid < HP) {
@@ -361,16 +372,16 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
 }
 
 int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngroups, int mode, int max_sweeps,
-              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2) {
+              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2, double bip_thr) {
     TN_CHECK_ARG(nvec >= 1 && nvec <= NBMAX, "nvec out of range");
     if (ngroups <= 0) return 0;
     prof_begin(st, PROF_EIG);
     if (nvec <= 32)
         hipLaunchKernelGGL((eig_small_kernel<32>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,
-                           dead_thresh, out, dead, nrot, maxoff, relevant2);
+                           dead_thresh, out, dead, nrot, maxoff, relevant2, bip_thr);
     else
         hipLaunchKernelGGL((eig_small_kernel<64>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,
-                           dead_thresh, out, dead, nrot, maxoff, relevant2);
+                           dead_thresh, out, dead, nrot, maxoff, relevant2, bip_thr);
     TN_CHECK_LAUNCH("eig_small_kernel");
     prof_end(st, PROF_EIG, 0.0, 8.0 * ngroups * ((double)nchunk + 1.0) * nvec * nvec);
     return 0;
