@@ -18,6 +18,7 @@ EPS = float(np.finfo(np.float64).eps)
 PASS1_ACCEPT = 2.0 ** -56        # accepted a-posteriori bound on the relative change of the state (the SVD's deflation level)
 PASS1_FLOOR = 1e-14              # squared weights are floored at this fraction of the largest (what fp64 Gram sums resolve)
 PASS1_MIN_BOND = 256             # bonds narrower than this are factored in full (nothing to gain)
+LAZY_SCHMIDT = os.environ.get('TN_LAZY_SCHMIDT', '1') != '0'              # see _LazyS
 PASS1_STRUCTURED = os.environ.get('TN_PASS1_STRUCTURED', '1') != '0'     # Gram recursion through the MPS (x) MPO structure
 
 
@@ -120,6 +121,50 @@ class MPO:
         self.support[n] = 1
 
 
+class _LazyS:
+    """Schmidt values that nothing has asked for yet: the centre matrix they would be computed from.  variational_compress
+    only ever compares a bond's Schmidt values with the previous ones OF THE SAME LENGTH (mps.py:555-556 resets them otherwise),
+    and the values taken during the last sweep a call is allowed to make cannot influence that call any more (the sweep limit
+    returns the same overlap whatever the change was).  So in such a sweep update_S is recorded, not evaluated: the next
+    update_S at that bond materialises the values if the bond still has the same dimension -- with the same kernel on the same
+    data, i.e. bit-identical to the eager evaluation -- and drops them otherwise.  On the contraction path the graduated stage
+    (one sweep at 4 chi) is followed by a stage at chi, so its 256 x 256 centre matrices are never decomposed (0.9 ms each)."""
+
+    def __init__(self, Cm):
+        self.Cm = Cm
+        self.size = min(Cm.shape)
+
+    def values(self):
+        return ops.svdvals(self.Cm)
+
+
+class _SchmidtList(list):
+    """psi.S: reading an entry evaluates it if it is still a _LazyS (whoever looks at the attribute sees plain arrays, as in
+    the reference); the sweeps themselves go through _previous_S, which drops a lazy entry of the wrong length unevaluated."""
+
+    def __getitem__(self, i):
+        v = list.__getitem__(self, i)
+        if isinstance(v, _LazyS):
+            v = v.values()
+            list.__setitem__(self, i, v)
+        elif isinstance(i, slice):
+            v = [self[j] for j in range(*i.indices(len(self)))]
+        return v
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def _previous_S(psi, pC, size):
+    """psi.S[pC] as update_S sees it before taking new values of length `size` (mps.py:555-556)."""
+    old = list.__getitem__(psi.S, pC)
+    if isinstance(old, _LazyS):
+        old = old.values() if old.size == size else None
+    if old is None or old.size != size:
+        old = psi._one_S(size)
+    return old
+
+
 class _DeferredSchmidt:
     """The update_S calls of one variational sweep (mps.py:550-560), taken asynchronously and replayed in order at the end.
 
@@ -130,8 +175,9 @@ class _DeferredSchmidt:
     of update_S for every site in the order the reference performs it; returns max dS over the measured (left-to-right)
     half."""
 
-    def __init__(self, psi):
+    def __init__(self, psi, lazy=False):
         self.psi = psi
+        self.lazy = lazy                # last sweep the caller may make: record the centre matrices only (see _LazyS)
         self.items = []                 # (pC, measure, row index | None, host array | None, centre tensor kept alive)
         self.table = None
         self.side = None
@@ -143,6 +189,9 @@ class _DeferredSchmidt:
     def add(self, measure):
         psi = self.psi
         Cm = psi.C
+        if self.lazy:
+            psi.S[psi.pC] = _LazyS(Cm)
+            return
         if max(Cm.shape) <= 64:
             if self.table is None:
                 self.table = torch.zeros((2 * psi.L + 2, 66), dtype=torch.float64, device=Cm.device)
@@ -169,9 +218,7 @@ class _DeferredSchmidt:
                     S = ops.svdvals(Cm)          # not converged in the fused kernel: the full path (raises if that fails too)
                 else:
                     S = host[row, :k].copy()
-            if psi.S[pC].size != S.size:
-                psi.S[pC] = psi._one_S(S.size)
-            dS = float(np.sqrt(np.sum((psi.S[pC] - S) ** 2)))
+            dS = float(np.sqrt(np.sum((_previous_S(psi, pC, S.size) - S) ** 2)))
             psi.S[pC] = S
             if measure:
                 diff = max(diff, dS)
@@ -247,7 +294,7 @@ class MPS:
 
     def reset_S(self):
         """mps.py:295-299."""
-        self.S = [self._one_S(self.D[n]) for n in range(self.L + 1)]
+        self.S = _SchmidtList(self._one_S(self.D[n]) for n in range(self.L + 1))
 
     def copy(self):
         """Deep copy of the tensors (mps.py:159-173); S and ``discarded`` start fresh as in the reference."""
@@ -582,9 +629,7 @@ class MPS:
     def update_S(self):
         """Schmidt values of the centre matrix; returns ||S_old - S_new||_2 (mps.py:550-560)."""
         S = ops.svdvals(self.C)
-        if self.S[self.pC].size != S.size:
-            self.S[self.pC] = self._one_S(S.size)
-        dS = float(np.sqrt(np.sum((self.S[self.pC] - S) ** 2)))
+        dS = float(np.sqrt(np.sum((_previous_S(self, self.pC, S.size) - S) ** 2)))
         self.S[self.pC] = S
         return dS
 
@@ -599,7 +644,7 @@ class MPS:
         while diff > tol:
             if sweeps >= max_sweeps:
                 return overlap
-            pend = _DeferredSchmidt(self)
+            pend = _DeferredSchmidt(self, lazy=LAZY_SCHMIDT and sweeps + 1 >= max_sweeps)
             for n in range(self.L - 1, 0, -1):
                 self.optimise_site(phi, n)
                 if ops.FUSED_SITE:
