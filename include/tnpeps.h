@@ -101,6 +101,12 @@ int64_t tn_svd_ws_bytes(int64_t k, int64_t n, int vectors);
  * mps.py:550-560, whose results are only needed at the end of a sweep): one asynchronous launch; out66_dev (DEVICE) receives 64
  * values sorted descending (zero padded), then the executed sweeps and a convergence flag (1 = converged) as doubles. */
 int tn_svdvals_async(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, double* out66_dev, void* stream);
+/* The same for `batch` centre matrices in ONE launch (one workgroup each): the Schmidt spectra of a whole variational sweep
+ * (mps.py:550-560) are only compared at its end, so they are taken together after it.  Item i is described by 5 int64
+ * {device address of C_i, vector stride, element stride, number of vectors, vector length} with the shorter side of C_i as the
+ * vectors (k <= n: {C, crs, ccs, k, n}, else {C, ccs, crs, n, k}); desc_dev is that table on the device, desc_host the caller's
+ * host copy of it (validated here, nothing on the device is dereferenced by the host); out66_dev + 66 i receives item i. */
+int tn_svdvals_small_batched(const int64_t* desc_dev, int64_t batch, const int64_t* desc_host, double* out66_dev, void* stream);
 /* Strided batches of the two SVD entry points (item i at C + i*bsC, U + i*bsU, S + i*bsS, Vt + i*bsV; the *_host outputs are
  * arrays of `batch` entries, S_host holds batch * min(k,n) values).  Ranks and convergence are read back per item, so the items
  * are issued one after the other and share the workspace of a single problem. */

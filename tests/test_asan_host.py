@@ -45,6 +45,11 @@ expect_neg(L.tn_panel_orth(P, 4, 1, 64, 4, P, 4, 1, 2, None, None, P, 1 << 20, N
 expect_neg(L.tn_panel_orth(P, 4, 1, 64, 4, P, 4, 1, 0, None, None, P, 16, None), 'tn_panel_orth ws')
 expect_neg(L.tn_panel_orth(P, 40, 1, 64, 40, C.cast(C.byref(host, 8), C.c_void_p), 40, 1, 1, None, None, P, 1 << 22, None), 'tn_panel_orth width')
 expect_neg(L.tn_panel_stats(None, 0), 'tn_panel_stats null')
+desc = (C.c_int64 * 10)(C.cast(host, C.c_void_p).value, 64, 1, 8, 65, C.cast(host, C.c_void_p).value, 64, 1, 9, 8)
+expect_neg(L.tn_svdvals_small_batched(P, -1, desc, P, None), 'svdvals_small_batched batch')
+expect_neg(L.tn_svdvals_small_batched(P, 1, desc, P, None), 'svdvals_small_batched length')
+expect_neg(L.tn_svdvals_small_batched(P, 1, C.cast(C.byref(desc, 40), C.POINTER(C.c_int64)), P, None), 'svdvals_small_batched order')
+assert L.tn_svdvals_small_batched(None, 0, None, None, None) == 0
 expect_neg(L.tn_svd_trunc(P, 4, 1, 4, 4, 0, 0.0, P, 4, 1, P, P, 4, 1, C.byref(i64), None, None, None, P, 1 << 20, None), 'tn_svd_trunc Dmax')
 expect_neg(L.tn_svd_trunc(P, 4, 1, 4, 4, 4, 0.0, P, 4, 1, P, P, 4, 1, None, None, None, None, P, 1 << 20, None), 'tn_svd_trunc keep')
 expect_neg(L.tn_svd_trunc(P, 4, 1, 4, 4, 4, 0.0, P, 4, 1, P, P, 4, 1, C.byref(i64), None, None, None, P, 8, None), 'tn_svd_trunc ws')

@@ -34,6 +34,7 @@ SIGNATURES = {
                           _ptr]),
     'tn_svd_ws_bytes': (_i64, [_i64, _i64, _int]),
     'tn_svdvals_async': (_int, [_ptr, _i64, _i64, _i64, _i64, _ptr, _ptr]),
+    'tn_svdvals_small_batched': (_int, [_ptr, _i64, _ptr, _ptr, _ptr]),
     'tn_svd_trunc_batched': (_int, [_ptr, _i64, _i64, _i64, _i64, _i64, _f64, _ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, C.POINTER(_i64),
                              C.POINTER(_f64), C.POINTER(_int), C.POINTER(_int), _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     'tn_svdvals_batched': (_int, [_ptr, _i64, _i64, _i64, _i64, C.POINTER(_f64), C.POINTER(_int), C.POINTER(_int), _i64, _i64, _ptr, _i64,
@@ -110,7 +111,7 @@ SHORT_CALLS = ('tn_gemm', 'tn_gemm_ws_bytes', 'tn_qr_ws_bytes', 'tn_svd_ws_bytes
                'tn_balance', 'tn_svdvals_async', 'tn_rar', 'tn_rar_ws_bytes', 'tn_env_mix', 'tn_env_mix_ws_bytes',
                'tn_apply_truncation', 'tn_apply_truncation_ws_bytes', 'tn_site_qr_ws_bytes', 'tn_gram_weights', 'tn_rows_norm2', 'tn_gather_scale_rows', 'tn_peps_factor', 'tn_mpo_from_factor', 'tn_last_error')
 _lib = None
-ABI_VERSION = 3          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
+ABI_VERSION = 4          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
 
 
 def lib():

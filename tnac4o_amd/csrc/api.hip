@@ -28,6 +28,7 @@ int svd_trunc(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, in
 int svd_vals(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, double*, int*, int*, void*, int64_t);
 int64_t svd_ws_bytes(int64_t, int64_t, int);
 int svd_vals_small_async(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, double*);
+int svd_vals_small_batched(hipStream_t, const int64_t*, int64_t, double*);
 int nfactor(hipStream_t, const double*, int64_t, double*, void*);
 int scale_by(hipStream_t, double*, int64_t, const double*);
 int normalize_pow2(hipStream_t, double*, int64_t, double*, void*, int64_t);
@@ -70,7 +71,7 @@ using namespace tn;
 
 extern "C" {
 
-int tn_version(void) { return 3; }
+int tn_version(void) { return 4; }
 
 #ifndef TN_SRC_HASH
 #define TN_SRC_HASH "unknown"
@@ -194,6 +195,18 @@ int tn_svdvals_async(const double* C, int64_t crs, int64_t ccs, int64_t k, int64
     const double dm = (double)(k > n ? k : n), dn = (double)(k > n ? n : k);
     prof_note(PROF_SVDVALS_NOMINAL, 1, 4.0 * dm * dn * dn - 4.0 / 3.0 * dn * dn * dn, 8.0 * (dm * dn + dn));
     return svd_vals_small_async(ST, C, crs, ccs, k, n, out66_dev);
+}
+
+int tn_svdvals_small_batched(const int64_t* desc_dev, int64_t batch, const int64_t* desc_host, double* out66_dev, void* stream) {
+    TN_CHECK_ARG(batch >= 0, "negative batch");
+    TN_CHECK_ARG(batch == 0 || (desc_dev && desc_host && out66_dev), "null operand");
+    for (int64_t i = 0; i < batch; ++i) {            // the host copy of the descriptors is only validated
+        const int64_t* d = desc_host + 5 * i;
+        TN_CHECK_ARG(d[0] != 0, "null matrix");
+        TN_CHECK_ARG(d[3] >= 1 && d[4] >= 1 && d[3] <= d[4] && d[4] <= 64, "both dimensions must be in 1..64 (vectors <= length)");
+    }
+    ProfPhase ph(PH_SVDVALS);
+    return svd_vals_small_batched(ST, desc_dev, batch, out66_dev);
 }
 
 int tn_nfactor(const double* x, int64_t n, double* out2, void* slot8, void* stream) {

@@ -110,12 +110,9 @@ __device__ __forceinline__ void rr_pair64(int s, int a, int& p, int& q) {
     if (p > q) { const int t = p; p = q; q = t; }
 }
 
-__global__ __launch_bounds__(256) void svd_vals_small_kernel(const double* __restrict__ M, int64_t vs, int64_t es, int nv, int L,
-                                                             double* __restrict__ out) {
+__device__ __forceinline__ void svd_vals_small_body(const double* __restrict__ M, int64_t vs, int64_t es, int nv, int L,
+                                                    double* __restrict__ out, double* X, double* nrm, int* flags) {
     constexpr int NV = 64, P = 66;            // even pitch: 16-byte aligned 8-element segments
-    __shared__ double X[NV * P];
-    __shared__ double nrm[NV];
-    __shared__ int flags[2];                  // [0] rotations this sweep, [1] rotations above the convergence threshold
     const int tid = threadIdx.x, slot = tid >> 3, sub = tid & 7;
     double relevant2 = 0.0;
     {
@@ -216,6 +213,24 @@ __global__ __launch_bounds__(256) void svd_vals_small_kernel(const double* __res
         }
         if (tid == 0) { out[64] = (double)sweeps; out[65] = (double)converged; }
     }
+}
+
+__global__ __launch_bounds__(256) void svd_vals_small_kernel(const double* __restrict__ M, int64_t vs, int64_t es, int nv, int L,
+                                                             double* __restrict__ out) {
+    __shared__ double X[64 * 66];
+    __shared__ double nrm[64];
+    __shared__ int flags[2];                  // [0] rotations this sweep, [1] rotations above the convergence threshold
+    svd_vals_small_body(M, vs, es, nv, L, out, X, nrm, flags);
+}
+
+// One workgroup per item: desc[5 i .. 5 i + 4] = {device address of the matrix, vector stride, element stride, vectors, length}
+// (the orientation is resolved by the host); out + 66 i receives the item's 64 values, sweeps and convergence flag.
+__global__ __launch_bounds__(256) void svd_vals_small_batched_kernel(const int64_t* __restrict__ desc, double* __restrict__ out) {
+    __shared__ double X[64 * 66];
+    __shared__ double nrm[64];
+    __shared__ int flags[2];
+    const int64_t* d = desc + 5 * (int64_t)blockIdx.x;
+    svd_vals_small_body(reinterpret_cast<const double*>(d[0]), d[1], d[2], (int)d[3], (int)d[4], out + 66 * (int64_t)blockIdx.x, X, nrm, flags);
 }
 
 static void round_robin(int nblk, std::vector<int>& pairs) {     // (nblk-1) rounds x (nblk/2) pairs x 2
@@ -435,6 +450,17 @@ int svd_vals_small_async(hipStream_t st, const double* C, int64_t crs, int64_t c
     const int64_t vs = rows ? crs : ccs, es = rows ? ccs : crs;
     TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_vals_small_kernel, dim3(1), dim3(256), 0, st, C, vs, es, (int)nv, (int)L, out));
     TN_CHECK_LAUNCH("svd_vals_small_kernel");
+    return 0;
+}
+
+// `batch` centre matrices (both dimensions <= 64 each) in ONE launch, one workgroup per matrix: desc (DEVICE, 5 int64 per item:
+// address, vector stride, element stride, number of vectors <= length, length) as prepared by the caller from
+// tn_svdvals_small_desc; out (DEVICE, 66 doubles per item) as for svd_vals_small_async.
+int svd_vals_small_batched(hipStream_t st, const int64_t* desc, int64_t batch, double* out) {
+    TN_CHECK_ARG(batch >= 0, "negative batch");
+    if (batch == 0) return 0;
+    TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_vals_small_batched_kernel, dim3((unsigned)batch), dim3(256), 0, st, desc, out));
+    TN_CHECK_LAUNCH("svd_vals_small_batched_kernel");
     return 0;
 }
 

@@ -19,6 +19,7 @@ PASS1_ACCEPT = 2.0 ** -56        # accepted a-posteriori bound on the relative c
 PASS1_FLOOR = 1e-14              # squared weights are floored at this fraction of the largest (what fp64 Gram sums resolve)
 PASS1_MIN_BOND = 256             # bonds narrower than this are factored in full (nothing to gain)
 LAZY_SCHMIDT = os.environ.get('TN_LAZY_SCHMIDT', '1') != '0'              # see _LazyS
+BATCHED_SCHMIDT = os.environ.get('TN_BATCHED_SCHMIDT', '1') != '0'        # small centre matrices of a sweep in one launch
 PASS1_STRUCTURED = os.environ.get('TN_PASS1_STRUCTURED', '1') != '0'     # Gram recursion through the MPS (x) MPO structure
 
 
@@ -168,17 +169,18 @@ def _previous_S(psi, pC, size):
 class _DeferredSchmidt:
     """The update_S calls of one variational sweep (mps.py:550-560), taken asynchronously and replayed in order at the end.
 
-    add(): the current centre matrix psi.C at bond psi.pC.  Up to 64 x 64 its singular values are computed by one
-    asynchronous launch (tn_svdvals_async) into a row of a device table -- on the side stream paired with the chain's stream
-    when the chain runs on a stream of its own, so that the launch is off the chain's critical path; larger centre matrices
-    go through the synchronous block-Jacobi path at once.  finish(): one device-to-host copy, then exactly the bookkeeping
-    of update_S for every site in the order the reference performs it; returns max dS over the measured (left-to-right)
-    half."""
+    add(): the current centre matrix psi.C at bond psi.pC.  Up to 64 x 64 it is only kept: finish() decomposes all of them
+    in ONE launch, one workgroup per matrix (tn_svdvals_small_batched; a launch per site cost the chain 130 us each --
+    TN_BATCHED_SCHMIDT=0 restores that form, tn_svdvals_async into a device table); larger centre matrices go through the
+    synchronous block-Jacobi path at once.  finish(): that launch, one device-to-host copy, then exactly the bookkeeping of
+    update_S for every site in the order the reference performs it; returns max dS over the measured (left-to-right) half.
+    lazy: see _LazyS."""
 
     def __init__(self, psi, lazy=False):
         self.psi = psi
         self.lazy = lazy                # last sweep the caller may make: record the centre matrices only (see _LazyS)
         self.items = []                 # (pC, measure, row index | None, host array | None, centre tensor kept alive)
+        self.small = []                 # centre matrices up to 64 x 64 of this sweep, decomposed together in finish()
         self.table = None
         self.side = None
         cur = torch.cuda.current_stream()
@@ -193,6 +195,10 @@ class _DeferredSchmidt:
             psi.S[psi.pC] = _LazyS(Cm)
             return
         if max(Cm.shape) <= 64:
+            if BATCHED_SCHMIDT:                            # kept until finish(): one launch for the whole sweep
+                self.items.append((psi.pC, measure, len(self.small), None, Cm))
+                self.small.append(Cm)
+                return
             if self.table is None:
                 self.table = torch.zeros((2 * psi.L + 2, 66), dtype=torch.float64, device=Cm.device)
             row = sum(1 for it in self.items if it[2] is not None)
@@ -206,7 +212,10 @@ class _DeferredSchmidt:
     def finish(self):
         psi = self.psi
         host = None
-        if self.table is not None:
+        if self.small:
+            host = ops.svdvals_small_batched(self.small).cpu().numpy()
+            self.small = []
+        elif self.table is not None:
             if self.side is not None:
                 self.cur.wait_stream(self.side)
             host = self.table.cpu().numpy()

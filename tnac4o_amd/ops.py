@@ -345,6 +345,22 @@ def svdvals_async(Cm, out66, stream=None):
     check(lib().tn_svdvals_async(Cm.data_ptr(), Cm.stride(0), Cm.stride(1), k, n, out66.data_ptr(), st))
 
 
+def svdvals_small_batched(mats):
+    """Schmidt values of several centre matrices (both dimensions <= 64 each) in one launch (tn_svdvals_small_batched).  Returns the
+    device table (len(mats), 66): 64 values sorted descending, sweeps, converged flag per row; no synchronisation."""
+    n = len(mats)
+    desc = np.empty((n, 5), dtype=np.int64)
+    for i, Cm in enumerate(mats):
+        _need_gpu(Cm)
+        k, m = Cm.shape
+        desc[i] = (Cm.data_ptr(), Cm.stride(0), Cm.stride(1), k, m) if k <= m else (Cm.data_ptr(), Cm.stride(1), Cm.stride(0), m, k)
+    dev = mats[0].device
+    ddesc = torch.from_numpy(desc).to(dev)
+    out = torch.empty((n, 66), dtype=torch.float64, device=dev)
+    check(lib().tn_svdvals_small_batched(ddesc.data_ptr(), n, desc.ctypes.data_as(C.c_void_p), out.data_ptr(), _stream()))
+    return out
+
+
 # ---- fused site steps (csrc/site.hip) ------------------------------------------------------------------------------------
 FUSED_SITE = os.environ.get('TN_FUSED_SITE', '1') != '0'
 PASS1_WEIGHTED = os.environ.get('TN_PASS1_WEIGHTED', '1') != '0'     # weighted rank-revealing first canonisation pass (mps.py)
