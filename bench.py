@@ -351,8 +351,8 @@ def main():
                          'algorithmic_bytes_per_launch': d['bytes'] / max(1, d['calls'])})
             if dom in SERIAL_FAM:
                 _, what, nser = SERIAL_FAM[dom]
-                roof['limited_by'] = ('latency: a column-serial single-workgroup kernel (its bytes are its algorithmic minimum, '
-                                      'see traffic); figure of merit = time per serial step')
+                roof['limited_by'] = ('latency: serial steps of a single workgroup / dependent memory round trips (the bytes moved are '
+                                      'close to the algorithmic minimum, see traffic); figure of merit = time per serial step')
                 roof['us_per_serial_step'] = 1e3 * avg_ms / nser
                 roof['serial_step'] = '%s, %d per launch' % (what, nser)
             fam = (pmc or {}).get('families', {}).get(d['kernel']) if pmc else None
