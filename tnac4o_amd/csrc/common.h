@@ -30,6 +30,12 @@ inline int hip_fail(hipError_t e, const char* what) {
         if (e__ != hipSuccess) return tn::hip_fail(e__, what); \
     } while (0)
 
+// Thread-local page-locked host buffers for the small read-backs / uploads around host decisions (slot 0..3, grown on demand,
+// released when the thread exits).  A copy into pageable memory makes hipMemcpyAsync drain the stream on the host first and only
+// then enqueue the transfer (15-20 us of idle device per read-back, 15 k read-backs per sweep); with page-locked memory the
+// transfer is queued right behind the producing kernel.  Returns nullptr if the allocation fails (callers fall back to pageable).
+void* pinned_host(size_t bytes, int slot);
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
 

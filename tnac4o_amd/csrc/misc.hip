@@ -4,6 +4,25 @@
 
 namespace tn {
 
+struct PinnedSlot {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~PinnedSlot() { if (p) (void)hipHostFree(p); }
+};
+void* pinned_host(size_t bytes, int slot) {
+    thread_local PinnedSlot slots[4];
+    if (slot < 0 || slot > 3) return nullptr;
+    PinnedSlot& s = slots[slot];
+    if (s.cap < bytes) {
+        if (s.p) { (void)hipHostFree(s.p); s.p = nullptr; s.cap = 0; }
+        const size_t cap = bytes * 2 > 65536 ? bytes * 2 : 65536;
+        if (hipHostMalloc(&s.p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); s.p = nullptr; return nullptr; }
+        s.cap = cap;
+    }
+    return s.p;
+}
+
+
 // max |x| via atomicMax on the bit pattern (non-negative doubles order like unsigned integers)
 __global__ __launch_bounds__(256) void absmax_bits_kernel(const double* __restrict__ x, int64_t n,
                                                           unsigned long long* __restrict__ slot) {

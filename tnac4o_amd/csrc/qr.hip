@@ -866,8 +866,10 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         if (pivot) {
             TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_kernel, dim3((unsigned)ntr), dim3(256), 0, st, Ap.p, rs, cs, mp, ntr, w.cn));
             TN_CHECK_LAUNCH("colnorm2_kernel");
-            std::vector<double> hcn((size_t)ntr);
-            if ((he = hipMemcpyAsync(hcn.data(), w.cn, (size_t)ntr * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(he, "memcpy norms");
+            std::vector<double> hcn_pageable;
+            double* hcn = (double*)pinned_host((size_t)ntr * 8, 0);
+            if (!hcn) { hcn_pageable.resize((size_t)ntr); hcn = hcn_pageable.data(); }
+            if ((he = hipMemcpyAsync(hcn, w.cn, (size_t)ntr * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(he, "memcpy norms");
             if ((he = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(he, "sync norms");
             double fro2 = 0.0;
             for (int64_t j = 0; j < ntr; ++j) fro2 += hcn[j];
@@ -878,19 +880,38 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
                 P = p;
                 break;
             }
-            thread_local std::vector<int> pairs;              // outlives the asynchronous upload below
-            pairs.assign((size_t)2 * b, 0);
-            for (int t = 0; t < b; ++t) {                            // selection of the b largest residuals by successive swaps
-                int64_t arg = t;
-                for (int64_t j = t + 1; j < ntr; ++j)
-                    if (hcn[j] > hcn[arg]) arg = j;
-                std::swap(hcn[t], hcn[arg]);
-                std::swap(pivot_perm_host[j0 + t], pivot_perm_host[j0 + arg]);
-                pairs[2 * t] = (int)(j0 + t);
-                pairs[2 * t + 1] = (int)(j0 + arg);
+            thread_local std::vector<int> pairs_pageable;      // outlives the asynchronous upload below
+            int* pairs = (int*)pinned_host((size_t)2 * nb * sizeof(int), 1);
+            if (!pairs) { pairs_pageable.assign((size_t)2 * nb, 0); pairs = pairs_pageable.data(); }
+            {   // Selection of the b largest residuals by successive swaps (step t: the first maximum of positions t .. ntr-1 goes to
+                // position t), through a tournament tree over the positions instead of b linear scans (the scans cost 30 us of host
+                // time per panel with the device idle): leaf i = position i, a node keeps the position of the larger value, the
+                // left one on ties (= the first maximum of a scan); a placed position is retired with -infinity.
+                int sz = 1;
+                while (sz < ntr) sz <<= 1;
+                thread_local std::vector<int> tree;
+                thread_local std::vector<double> val;
+                tree.assign((size_t)2 * sz, -1);
+                val.assign((size_t)sz, -1.0);                   // squared norms are >= 0: -1 never wins
+                for (int64_t j = 0; j < ntr; ++j) { val[j] = (hcn[j] == hcn[j]) ? hcn[j] : -1.0; tree[sz + j] = (int)j; }   // NaN never wins (as in a scan)
+                auto better = [&](int a, int c) { return (a >= 0 && (c < 0 || val[a] >= val[c])) ? a : c; };
+                for (int i = sz - 1; i >= 1; --i) tree[i] = better(tree[2 * i], tree[2 * i + 1]);
+                auto update = [&](int pos) { for (int i = (sz + pos) >> 1; i >= 1; i >>= 1) tree[i] = better(tree[2 * i], tree[2 * i + 1]); };
+                for (int t = 0; t < b; ++t) {
+                    int arg = tree[1];                            // leftmost maximum of the live positions t .. ntr-1
+                    if (arg < 0) arg = t;
+                    std::swap(hcn[t], hcn[arg]);
+                    std::swap(pivot_perm_host[j0 + t], pivot_perm_host[j0 + arg]);
+                    pairs[2 * t] = (int)(j0 + t);
+                    pairs[2 * t + 1] = (int)(j0 + arg);
+                    if (arg != t) { val[arg] = (hcn[arg] == hcn[arg]) ? hcn[arg] : -1.0; update(arg); }
+                    val[t] = -2.0;                                // position t is placed
+                    tree[sz + t] = -1;
+                    update(t);
+                }
             }
             int* dpairs = (int*)(w.cn + 2 * n) - 2 * nb;                 // the tail of the norms buffer (2n doubles) is free here
-            if ((he = hipMemcpyAsync(dpairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(he, "memcpy pairs");
+            if ((he = hipMemcpyAsync(dpairs, pairs, (size_t)2 * b * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(he, "memcpy pairs");
             TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(swap_columns_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, A, rs, cs, m, dpairs, b));
             TN_CHECK_LAUNCH("swap_columns_kernel");
         }
@@ -978,17 +999,20 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
                                nt, w.cn + n));
             TN_CHECK_LAUNCH("colnorm2_kernel");
             // one read-back: the trailing norms, and (first check only) the input norms stored in front of them
-            std::vector<double> hcn((size_t)(scale2 < 0.0 ? n + nt : nt));
+            const size_t nread = (size_t)(scale2 < 0.0 ? n + nt : nt);
+            std::vector<double> hcn_pageable;
+            double* hcn = (double*)pinned_host(nread * 8, 0);
+            if (!hcn) { hcn_pageable.resize(nread); hcn = hcn_pageable.data(); }
             hipError_t e;
-            if ((e = hipMemcpyAsync(hcn.data(), scale2 < 0.0 ? w.cn : w.cn + n, hcn.size() * 8, hipMemcpyDeviceToHost, st)) != hipSuccess)
+            if ((e = hipMemcpyAsync(hcn, scale2 < 0.0 ? w.cn : w.cn + n, nread * 8, hipMemcpyDeviceToHost, st)) != hipSuccess)
                 return hip_fail(e, "memcpy norms");
             if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync norms");
-            const double* tr2 = hcn.data();
+            const double* tr2 = hcn;
             // measure of "what is left" against the input: largest column norm (default) or, frob_exit, the Frobenius norm
             if (scale2 < 0.0) {
                 scale2 = 0.0;
                 for (int64_t j = 0; j < n; ++j) scale2 = frob_exit ? scale2 + hcn[j] : std::max(scale2, hcn[j]);
-                tr2 = hcn.data() + n;
+                tr2 = hcn + n;
             }
             double h[2] = {scale2, 0.0};
             for (int64_t j = 0; j < nt; ++j) h[1] = frob_exit ? h[1] + tr2[j] : std::max(h[1], tr2[j]);

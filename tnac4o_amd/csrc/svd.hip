@@ -299,8 +299,12 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nv), dim3(256), 0, st, M, vs, es, L, w.norms));
     TN_CHECK_LAUNCH("vec_norm2_kernel");
     std::vector<double> hn(nv);
-    if ((e = hipMemcpyAsync(hn.data(), w.norms, nv * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy norms");
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync norms");
+    {   // read-backs go through a page-locked staging buffer (see pinned_host): queued right behind the producing kernel
+        double* stage = (double*)pinned_host((size_t)nv * 8, 2);
+        if ((e = hipMemcpyAsync(stage ? stage : hn.data(), w.norms, nv * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy norms");
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync norms");
+        if (stage) std::memcpy(hn.data(), stage, (size_t)nv * 8);
+    }
     double nmax = 0.0;
     for (int64_t i = 0; i < nv; ++i) {
         if (!(hn[i] == hn[i]) || hn[i] > 1.7e308) { set_error("svd: non-finite input"); return -2; }
@@ -327,7 +331,11 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     std::vector<int> hinit(gap + pairs.size(), 0);
     std::copy(live.begin(), live.end(), hinit.begin());
     std::copy(pairs.begin(), pairs.end(), hinit.begin() + gap);
-    if ((e = hipMemcpyAsync(w.live, hinit.data(), hinit.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy init");
+    {
+        int* stage = (int*)pinned_host(hinit.size() * 4, 3);
+        if (stage) std::memcpy(stage, hinit.data(), hinit.size() * 4);
+        if ((e = hipMemcpyAsync(w.live, stage ? stage : hinit.data(), hinit.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy init");
+    }
     const int64_t pitch = L + (vectors ? nv : 0);
     TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_init_kernel, dim3((unsigned)nvp), dim3(256), 0, st, M, vs, es, L, nv, w.live, nvl, w.X,
                        vectors ? w.P : nullptr, pitch));
@@ -370,8 +378,12 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
                 return rc;
         }
         ++sweeps;
-        if ((e = hipMemcpyAsync(hoff.data(), w.maxoff, hoff.size() * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy maxoff");
-        if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync sweep");
+        {
+            double* stage = (double*)pinned_host(hoff.size() * 8, 2);
+            if ((e = hipMemcpyAsync(stage ? stage : hoff.data(), w.maxoff, hoff.size() * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy maxoff");
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync sweep");
+            if (stage) std::memcpy(hoff.data(), stage, hoff.size() * 8);
+        }
         double worst = 0.0;
         for (double v : hoff) worst = std::max(worst, v);
         static const bool trace = [] { const char* e = getenv("TN_SVD_TRACE"); return e && e[0] == '1'; }();
@@ -383,8 +395,12 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nvp), dim3(256), 0, st, w.X, pitch, 1, L, w.norms));
     TN_CHECK_LAUNCH("vec_norm2_kernel");
     std::vector<double> hs(nvp);
-    if ((e = hipMemcpyAsync(hs.data(), w.norms, nvp * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy S");
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync S");
+    {
+        double* stage = (double*)pinned_host((size_t)nvp * 8, 2);
+        if ((e = hipMemcpyAsync(stage ? stage : hs.data(), w.norms, nvp * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy S");
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync S");
+        if (stage) std::memcpy(hs.data(), stage, (size_t)nvp * 8);
+    }
     hostOrder.resize(nvp);
     for (int i = 0; i < nvp; ++i) hostOrder[i] = i;
     std::stable_sort(hostOrder.begin(), hostOrder.end(), [&](int a, int b) { return hs[a] > hs[b]; });
@@ -428,7 +444,9 @@ int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t
     std::memcpy(hpack.data() + (size_t)keep * 8, hO.data(), (size_t)keep * 4);
     double* dS = w.norms;
     const int* dO = (const int*)((const char*)w.norms + (size_t)keep * 8);
-    if ((e = hipMemcpyAsync(w.norms, hpack.data(), hpack.size(), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy S/order");
+    char* stage = (char*)pinned_host(hpack.size(), 3);         // (the schedule uploaded from this slot completed several synchronisations ago)
+    if (stage) std::memcpy(stage, hpack.data(), hpack.size());
+    if ((e = hipMemcpyAsync(w.norms, stage ? stage : hpack.data(), hpack.size(), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy S/order");
     // rows: left = U (k x keep), right = Vt.  columns (C^T was factored): left = Vt^T, right = U^T.
     if (rows)
         TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, dO, dS, S,
@@ -437,7 +455,9 @@ int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t
         TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, dO, dS, S,
                            Vt, vcs, vrs, U, ucs, urs));
     TN_CHECK_LAUNCH("svd_gather_kernel");
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync gather");   // hS/hO go out of scope
+    // the upload above reads the thread's page-locked slot, which is not rewritten before the next call's first synchronisation;
+    // only a pageable source (allocation failure) has to outlive the copy
+    if (!stage && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync gather");
     return 0;
 }
 
@@ -478,8 +498,10 @@ int svd_vals(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t 
         TN_CHECK_LAUNCH("svd_vals_small_kernel");
         double h[66];
         hipError_t e;
-        if ((e = hipMemcpyAsync(h, dout, sizeof(h), hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy S");
+        double* stage = (double*)pinned_host(sizeof(h), 2);
+        if ((e = hipMemcpyAsync(stage ? stage : h, dout, sizeof(h), hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy S");
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync S");
+        if (stage) std::memcpy(h, stage, sizeof(h));
         for (int64_t i = 0; i < nv; ++i) {
             if (!(h[i] == h[i]) || h[i] > 1.7e308) { set_error("svd: non-finite input"); return -2; }
             hostS[i] = h[i];
