@@ -370,9 +370,9 @@ __device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, i
 // Tail of a launch, run by the last workgroup to arrive: sum the partial Gram matrices (block order, optional per-block
 // power-of-two weights), measure the distance from the identity, decide, and factor G = R^T R with deferral (wave 0).
 // Gs: LDS 32 x 33, Rs: LDS 32 x 32 (16-byte aligned).  pass = number of passes applied to the panel whose Gram matrix this is.  Returns 1 when the caller
-// has to run the Householder fallback (all threads get the same value).
+// decision (0: factor again, 1: converged, 2: out of passes; all threads get the same value).
 __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int nblk, int b, int pass, CqState* stt, double* Rg, double* Gs,
-                                       double* Rs, double* lu, double* Tp, double* scr, int maxpass, int tid) {
+                                       double* Rs, int maxpass, int tid) {
     __shared__ int s_dec;
     const int lane = tid & 63;
     // exponents of pass 0: block weights 4^(e_blk - emax); every wave finds emax itself (no barrier)
@@ -502,9 +502,7 @@ __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int 
         }
     }
     __syncthreads();
-    const int dec_all = s_dec;
-    if (dec_all == 1 && lu) cq_lu(lu + CQ_LU_YTOP, true, b, lu, Tp, scr, tid);      // converged: reconstruct the reflectors right here
-    return dec_all == 2 ? 1 : 0;
+    return s_dec;                                          // 0: another pass, 1: converged, 2: fallback flagged
 }
 
 // ---- pass 0: Gram matrix of the input panel -------------------------------------------------------------------------
@@ -562,7 +560,7 @@ __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__
     __threadfence();
     if (tid == 0) { stt->counter = 0; stt->done = 0; stt->pass = 0; stt->ndefer_total = 0; stt->nrefill_total = 0; stt->fallback = 0; }
     __syncthreads();
-    cq_tail(part, bexp, nblk, b, 0, stt, Rg, Gs, Rs, nullptr, nullptr, T, CQ_MAXPASS, tid);
+    cq_tail(part, bexp, nblk, b, 0, stt, Rg, Gs, Rs, CQ_MAXPASS, tid);
 }
 
 // ---- pass t >= 1: X <- X R^-1, then the Gram matrix of the new panel -----------------------------------------------
@@ -572,7 +570,7 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
                                                       double* Rg, uint64_t seed, double* lu, double* Tp, int maxpass) {
     __shared__ double T[CQ_RB * CQ_P];
     __shared__ double Gs[32 * CQ_P];
-    __shared__ __attribute__((aligned(16))) double Rs[32 * 32 + 32];
+    __shared__ __attribute__((aligned(16))) double Rs[32 * 32 + 32 + 32 * 32];      // factor + reciprocals | Cholesky rows of the tail
     __shared__ int s_ticket;
     __shared__ int s_st[4];
     const int tid = threadIdx.x, blk = blockIdx.x;
@@ -678,11 +676,15 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
             }
         }
     }
-    if (lu && blk == 0) {                                 // the top block, for the reconstruction by the last workgroup
+    // The Householder reconstruction only needs the top block of the panel, which workgroup 0 owns: it keeps a copy (Rs is free
+    // after the substitution) and reconstructs after it has taken its ticket -- speculatively, while the last workgroup is still
+    // reducing and deciding; if the panel turns out not to be converged the next pass simply overwrites what it wrote.
+    const bool recon = (lu != nullptr) && (blk == 0);
+    if (recon) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 256 * u;
-            cq_st(lu + CQ_LU_YTOP + e, T[(e >> 5) * CQ_P + (e & 31)]);
+            Rs[e] = T[(e >> 5) * CQ_P + (e & 31)];
         }
     }
     if (!fin) cq_block_gram(T, part + (int64_t)blk * CQ_PART, tid);      // (its first barrier follows its reads of T)
@@ -693,23 +695,27 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
     if (tid == 0) s_ticket = atomicAdd(&stt->counter, 1);
     __syncthreads();
     CQ_CLK(5);
-    if (s_ticket != nblk - 1) return;
+    if (s_ticket != nblk - 1) {
+        if (recon) cq_lu(Rs, false, b, lu, Tp, T, tid);
+        return;
+    }
     __threadfence();
     CQ_CLK(6);
     if (tid == 0) { stt->counter = 0; stt->pass = launch_no; }
+    int dec = 1;
     if (fin) {
         if (tid == 0) {
             stt->done = 1; stt->final_next = 0; stt->dead = 0u;
             cq_count(launch_no, stt->ndefer_total, stt->nrefill_total, false);
         }
         __syncthreads();
-        if (lu) cq_lu(lu + CQ_LU_YTOP, true, b, lu, Tp, T, tid);
-        return;
+    } else {
+        __syncthreads();
+        dec = cq_tail(part, nullptr, nblk, b, launch_no, stt, Rg, Gs, Rs + 1056, maxpass, tid);
     }
-    __syncthreads();
-    cq_tail(part, nullptr, nblk, b, launch_no, stt, Rg, Gs, Rs, lu, Tp, T, maxpass, tid);
     CQ_CLK(7);
     if (launch_no <= 2) CQ_CLK_DUMP(12 * (launch_no - 1));
+    if (recon && dec == 1) cq_lu(Rs, false, b, lu, Tp, T, tid);          // workgroup 0 arrived last: reconstruct now
 }
 
 // ---- post-processing: the reflector panels from the orthonormal one ---------------------------------------------------
