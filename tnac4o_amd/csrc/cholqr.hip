@@ -505,18 +505,11 @@ __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int 
     return s_dec;                                          // 0: another pass, 1: converged, 2: fallback flagged
 }
 
-// ---- pass 0: Gram matrix of the input panel -------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__ X, int64_t rs, int64_t cs, int64_t nrows, int b, int nblk,
-                                                      double* part, int* bexp, CqState* stt, double* Rg) {
-    __shared__ double T[CQ_RB * CQ_P];
-    __shared__ double Gs[32 * CQ_P];
-    __shared__ __attribute__((aligned(16))) double Rs[32 * 32];
-    __shared__ double red[4];
-    __shared__ int s_ticket;
-    const int tid = threadIdx.x, blk = blockIdx.x;
-    int64_t r0;
-    int nr;
-    cq_block_rows(nrows, nblk, blk, r0, nr);
+// Pass 0: rows r0 .. r0+nr-1 of the panel into the LDS tile T (zero padded), scaled by the power of two that brings the tile's
+// largest entry into [0.5, 1) so that squares neither overflow nor underflow whatever the input scale; returns that exponent
+// (-2000 for an all-zero tile, which then weighs nothing).  red: LDS, 4 doubles.  Ends with a barrier.
+__device__ __forceinline__ int cq_load_scaled_tile(const double* __restrict__ X, int64_t rs, int64_t cs, int64_t r0, int nr, int b, double* T,
+                                                   double* red, int tid) {
     const bool colfast = (cs == 1);
     double amax = 0.0;
     {
@@ -550,6 +543,22 @@ __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__
         T[(e >> 5) * CQ_P + (e & 31)] *= scl;
     }
     __syncthreads();
+    return ex;
+}
+
+// ---- pass 0: Gram matrix of the input panel -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__ X, int64_t rs, int64_t cs, int64_t nrows, int b, int nblk,
+                                                      double* part, int* bexp, CqState* stt, double* Rg) {
+    __shared__ double T[CQ_RB * CQ_P];
+    __shared__ double Gs[32 * CQ_P];
+    __shared__ __attribute__((aligned(16))) double Rs[32 * 32];
+    __shared__ double red[4];
+    __shared__ int s_ticket;
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    int64_t r0;
+    int nr;
+    cq_block_rows(nrows, nblk, blk, r0, nr);
+    const int ex = cq_load_scaled_tile(X, rs, cs, r0, nr, b, T, red, tid);
     cq_block_gram(T, part + (int64_t)blk * CQ_PART, tid);
     if (tid == 0) cq_sti(bexp + blk, ex);
     cq_publish_wait();
@@ -561,6 +570,75 @@ __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__
     if (tid == 0) { stt->counter = 0; stt->done = 0; stt->pass = 0; stt->ndefer_total = 0; stt->nrefill_total = 0; stt->fallback = 0; }
     __syncthreads();
     cq_tail(part, bexp, nblk, b, 0, stt, Rg, Gs, Rs, CQ_MAXPASS, tid);
+}
+
+// X <- X R^-1 on the 256-row tile T (LDS), row tid; Rs (LDS, 16-byte aligned): R row-major (1024) + reciprocal diagonal (32).
+// Columns flagged in deadmask (exactly zero before this pass) are refilled with hash noise.
+__device__ __forceinline__ void cq_substitute(double* T, const double* Rs, int tid, unsigned deadmask, uint64_t seed, int64_t r0, int nr) {
+    {   // substitution on row tid (right-looking: after step j all later columns are independent updates).  The multipliers
+        // of step j+1 are fetched from LDS (broadcast reads) while step j computes; the scheduling barriers keep the compiler
+        // from hoisting all 250 reads to the top (512 VGPRs and spills otherwise).
+        double x[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) x[j] = T[tid * CQ_P + j];
+        double2 mc[16], mn[16];
+        double dc = Rs[1024], dn = 0.0, sc = Rs[1], sn = 0.0;      // reciprocal diagonal, the odd first multiplier
+#pragma unroll
+        for (int q = 1; q < 16; ++q) mc[q] = *reinterpret_cast<const double2*>(&Rs[2 * q]);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (j < 31) {                                 // prefetch step j+1
+                dn = Rs[1024 + j + 1];
+                if (j + 2 < 32 && ((j + 2) & 1)) sn = Rs[(j + 1) * 32 + j + 2];
+#pragma unroll
+                for (int q = (j + 3) >> 1; q < 16; ++q) mn[q] = *reinterpret_cast<const double2*>(&Rs[(j + 1) * 32 + 2 * q]);
+            }
+            const double xj = x[j] * dc;
+            x[j] = xj;
+            if (j < 31) {
+                if ((j + 1) & 1) cq_fnma(x[j + 1], xj, sc);
+#pragma unroll
+                for (int q = (j + 2) >> 1; q < 16; ++q) {
+                    cq_fnma(x[2 * q], xj, mc[q].x);
+                    cq_fnma(x[2 * q + 1], xj, mc[q].y);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dc = dn; sc = sn;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) mc[q] = mn[q];
+        }
+        if (deadmask) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if ((deadmask >> j) & 1u) x[j] = (tid < nr) ? cq_hash_unit(seed + (uint64_t)(r0 + tid) * 64 + j) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) T[tid * CQ_P + j] = x[j];
+    }
+}
+
+// the tile back to global memory, coalesced whatever the layout
+__device__ __forceinline__ void cq_store_tile(const double* T, double* Y, int64_t rs, int64_t cs, int64_t r0, int nr, int b, int tid) {
+    {   // coalesced store of the tile
+        const bool ofast = (cs == 1);
+#pragma unroll
+        for (int u0 = 0; u0 < 32; u0 += 8) {
+            double ov[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * (u0 + u);
+                const int i = ofast ? e >> 5 : e & 255, j = ofast ? e & 31 : e >> 8;
+                ov[u] = T[i * CQ_P + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * (u0 + u);
+                const int i = ofast ? e >> 5 : e & 255, j = ofast ? e & 31 : e >> 8;
+                if (i < nr && j < b) Y[(r0 + i) * rs + j * cs] = ov[u];
+            }
+        }
+    }
 }
 
 // ---- pass t >= 1: X <- X R^-1, then the Gram matrix of the new panel -----------------------------------------------
@@ -614,68 +692,10 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
     const unsigned deadmask = (unsigned)s_st[3];
     __syncthreads();
     CQ_CLK(1);
-    {   // substitution on row tid (right-looking: after step j all later columns are independent updates).  The multipliers
-        // of step j+1 are fetched from LDS (broadcast reads) while step j computes; the scheduling barriers keep the compiler
-        // from hoisting all 250 reads to the top (512 VGPRs and spills otherwise).
-        double x[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) x[j] = T[tid * CQ_P + j];
-        double2 mc[16], mn[16];
-        double dc = Rs[1024], dn = 0.0, sc = Rs[1], sn = 0.0;      // reciprocal diagonal, the odd first multiplier
-#pragma unroll
-        for (int q = 1; q < 16; ++q) mc[q] = *reinterpret_cast<const double2*>(&Rs[2 * q]);
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            if (j < 31) {                                 // prefetch step j+1
-                dn = Rs[1024 + j + 1];
-                if (j + 2 < 32 && ((j + 2) & 1)) sn = Rs[(j + 1) * 32 + j + 2];
-#pragma unroll
-                for (int q = (j + 3) >> 1; q < 16; ++q) mn[q] = *reinterpret_cast<const double2*>(&Rs[(j + 1) * 32 + 2 * q]);
-            }
-            const double xj = x[j] * dc;
-            x[j] = xj;
-            if (j < 31) {
-                if ((j + 1) & 1) cq_fnma(x[j + 1], xj, sc);
-#pragma unroll
-                for (int q = (j + 2) >> 1; q < 16; ++q) {
-                    cq_fnma(x[2 * q], xj, mc[q].x);
-                    cq_fnma(x[2 * q + 1], xj, mc[q].y);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            dc = dn; sc = sn;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) mc[q] = mn[q];
-        }
-        if (deadmask) {
-#pragma unroll
-            for (int j = 0; j < 32; ++j)
-                if ((deadmask >> j) & 1u) x[j] = (tid < nr) ? cq_hash_unit(seed + (uint64_t)(r0 + tid) * 64 + j) : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 32; ++j) T[tid * CQ_P + j] = x[j];
-    }
+    cq_substitute(T, Rs, tid, deadmask, seed, r0, nr);
     __syncthreads();
     CQ_CLK(2);
-    {   // coalesced store of the tile
-        const bool ofast = (cs == 1);
-#pragma unroll
-        for (int u0 = 0; u0 < 32; u0 += 8) {
-            double ov[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + 256 * (u0 + u);
-                const int i = ofast ? e >> 5 : e & 255, j = ofast ? e & 31 : e >> 8;
-                ov[u] = T[i * CQ_P + j];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + 256 * (u0 + u);
-                const int i = ofast ? e >> 5 : e & 255, j = ofast ? e & 31 : e >> 8;
-                if (i < nr && j < b) Y[(r0 + i) * rs + j * cs] = ov[u];
-            }
-        }
-    }
+    cq_store_tile(T, Y, rs, cs, r0, nr, b, tid);
     // The Householder reconstruction only needs the top block of the panel, which workgroup 0 owns: it keeps a copy (Rs is free
     // after the substitution) and reconstructs after it has taken its ticket -- speculatively, while the last workgroup is still
     // reducing and deciding; if the panel turns out not to be converged the next pass simply overwrites what it wrote.
@@ -881,12 +901,12 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
     double* part = (double*)p; p += align_up((int64_t)nblk * CQ_PART * 8, 256);
     int* bexp = (int*)p; p += align_up((int64_t)nblk * 4, 256);
     double* lu = reconstruct ? (double*)p : nullptr;
+    // TN_PANEL_MAXPASS (1 .. CQ_MAXPASS): fewer substitution passes, to drive the Householder fallback in tests
+    static const int maxpass = [] { const char* e = getenv("TN_PANEL_MAXPASS"); const int v = e ? atoi(e) : CQ_MAXPASS; return v >= 1 && v <= CQ_MAXPASS ? v : CQ_MAXPASS; }();
     prof_begin(st, PROF_TSQR);
     hipLaunchKernelGGL(cq_gram_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, nrows, b, nblk, part, bexp, stt, Rg);
     TN_CHECK_LAUNCH("cq_gram_kernel");
     prof_end(st, PROF_TSQR, 2.0 * nrows * b * b, 8.0 * nrows * b);
-    // TN_PANEL_MAXPASS (1 .. CQ_MAXPASS): fewer substitution passes, to drive the Householder fallback in tests
-    static const int maxpass = [] { const char* e = getenv("TN_PANEL_MAXPASS"); const int v = e ? atoi(e) : CQ_MAXPASS; return v >= 1 && v <= CQ_MAXPASS ? v : CQ_MAXPASS; }();
     for (int t = 1; t <= maxpass; ++t) {
         prof_begin(st, PROF_TSQR);
         hipLaunchKernelGGL(cq_pass_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, t == 1 ? 1 : 0, t, part, stt,
