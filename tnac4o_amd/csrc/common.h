@@ -144,7 +144,7 @@ int gram_nchunk(int64_t L);
 //         relative off-diagonal seen before rotating.
 // relevant2 (mode 2): vectors with squared norm <= relevant2 are left out of the convergence measure maxoff.
 int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngroups, int mode, int max_sweeps,
-              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2 = 0.0, double bip_thr = 0.0);
+              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2 = 0.0);
 
 // In place:  X(r, 0:b) <- X(r, 0:b) * S   for r < nrows  (S is b x b row-major in global memory).
 int rows_times_small(hipStream_t st, double* X, int64_t rs, int64_t cs, int64_t nrows, int b, const double* S);

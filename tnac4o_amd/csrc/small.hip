@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                                                         int max_sweeps, double dead_thresh,
                                                         double* __restrict__ out, int* __restrict__ dead,
                                                         int* __restrict__ nrot_out, double* __restrict__ maxoff_out,
-                                                        double relevant2, double bip_thr) {
+                                                        double relevant2) {
     constexpr int P = NB + 1;
     __shared__ double G[NB * P];
     __shared__ double J[NB * P];
@@ -172,24 +172,21 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
             rdg[tid] = (gii > relevant2 && tid < nvec) ? fast_rcp(gii) : 0.0;
         }
         __syncthreads();
-        double m = 0.0, mw = 0.0;                          // all pairs / pairs inside one half (one block of the SVD's pair)
+        double m = 0.0;
 #pragma unroll
         for (int t = 0; t < NB * NB / 256; ++t) {
             const int e = tid + 256 * t, i = e / NB, j = e % NB;
             const double g = G[i * P + j];
             const double r2 = (i < j) ? g * g * rdg[i] * rdg[j] : 0.0;
             m = r2 > m ? r2 : m;
-            if ((i < NB / 2) == (j < NB / 2)) mw = r2 > mw ? r2 : mw;
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o, 64)); mw = fmax(mw, __shfl_xor(mw, o, 64)); }
-        if ((tid & 63) == 0) { red[tid >> 6] = m; red[8 + (tid >> 6)] = mw; }
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = m;
         __syncthreads();
         if (tid == 0) {
             const double mm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-            const double mmw = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
             red[0] = sqrt(mm);
-            red[4] = sqrt(mmw);
             if (maxoff_out) maxoff_out[grp] = red[0];
         }
         __syncthreads();
@@ -199,30 +196,54 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
     // so they never rotate).  Trip counts are compile-time so that each phase issues all of its LDS loads at once.
     const bool need = (mode != 1) && (nvec >= 2) && (red[0] > 8.881784197001252e-16);
     if (need) {
-        // Each step of the round-robin tournament applies NB/2 disjoint plane rotations R: G <- R^T G R as independent 2 x 2
-        // blocks (rotation a x rotation b), J <- J R as (row i, rotation b).  A thread keeps the same rotation slots for the
-        // whole sweep and derives their index pairs arithmetically, so a step costs it one 16-byte read per coefficient pair
-        // plus the data itself (the first version fetched indices and coefficients separately for every element: twice as
-        // many LDS instructions as data accesses, and the step is LDS-bound).
-        constexpr int HP = NB / 2, GB = HP * HP / 256, JB = NB * HP / 256;
-        __shared__ __attribute__((aligned(16))) double cs2[HP * 2];      // (c, s) of slot a
+        // Each step of the round-robin tournament applies NB/2 disjoint plane rotations R:  G <- R^T G R  and  J <- J R.
+        //  * G lives in LDS and is updated as independent 2 x 2 blocks (rotation a x rotation b) by all 256 threads.  A thread
+        //    keeps the same rotation slots for the whole sweep and derives their index pairs arithmetically; the HP lanes that
+        //    share a row read HP distinct columns of it (no bank conflicts).
+        //  * J never touches LDS during the sweeps (it was half of the traffic of an LDS-bound step): lane i of wave 3 holds
+        //    ROW i of J in registers, so a rotation of columns (p, q) mixes two registers of the same lane.  Register indices
+        //    must be compile-time constants, so the row is kept in a frame that turns with the tournament: in step s position f
+        //    holds column (f + s) mod (NB-1) (position NB-1 holds column NB-1), which makes the pairs of every step the fixed
+        //    positions (a, NB-1-a) and (0, NB-1); after the rotations the frame advances by one position (NB-2 register moves).
+        //    A sweep has NB-1 steps, so the frame is back in place at its end.  J only follows the rotations, nothing of a
+        //    later step depends on it: wave 3 applies step s-1 while wave 0 decides the rotations of step s.
+        constexpr int HP = NB / 2, GB = HP * HP / 256;
+        __shared__ __attribute__((aligned(16))) double cs2[2][HP * 2];      // (c, s) of slot a, double-buffered over the steps
+        __shared__ __attribute__((aligned(16))) double csj[2][HP * 2];      // (c, +-s): the same rotation as seen from J's frame
         const double tol = 8.881784197001252e-16;      // 2^-50
-        // thread -> (rotation b = tid % HP on the column side, rotations / rows tid / HP + (256 / HP) k on the row side): the HP
-        // lanes that share a row read HP distinct columns of it (no bank conflicts), and b is the same for all of a thread's work
         const int tb = tid % HP, t0 = tid / HP;
         constexpr int TS = 256 / HP;
-        // Bipartite sweeps (SVD pair step): when the two halves are each orthogonal already -- every block leaves its previous
-        // visit that way -- and the coupling between them is small, only the NB/2 x NB/2 cross pairs are rotated: NB/2 steps
-        // (slot a pairs a with NB/2 + (a + s) mod NB/2) instead of NB - 1.  What a cross rotation of angle t re-creates inside
-        // a half is O(t^2), the same order a cyclic sweep leaves behind, so the quadratic convergence of the outer block Jacobi
-        // is kept at half the steps; a pair that does not qualify (first visits, large angles) gets the cyclic sweep.
-        const bool bip = (bip_thr > 0.0) && (mode == 2) && (nvec == NB) && (red[0] <= bip_thr) && (red[4] <= 0.1 * red[0]);
-        const int nsteps = bip ? HP : NB - 1;
-        auto slot_pair = [bip](int s, int a, int& p, int& q) {
-            if (bip) { p = a; q = HP + ((a + s) & (HP - 1)); return; }
+        constexpr int nsteps = NB - 1;
+        auto slot_pair = [](int s, int a, int& p, int& q) {
             if (a == 0) { p = NB - 1; q = s; }
             else { p = s + a; p -= (p >= NB - 1) ? NB - 1 : 0; q = s - a; q += (q < 0) ? NB - 1 : 0; }
             if (p > q) { const int t = p; p = q; q = t; }
+        };
+        const bool jwave = (tid >= 192);                   // wave 3
+        double jr[NB];                                     // (wave 3) row `tid - 192` of J in the turning frame
+#pragma unroll
+        for (int k = 0; k < NB; ++k) jr[k] = (k == tid - 192) ? 1.0 : 0.0;
+        auto apply_j = [&](int t) {                        // rotations of step t on the register row, then advance the frame
+            if (stepflag[t & 1]) {
+                double2 r[HP];
+#pragma unroll
+                for (int a = 0; a < HP; ++a) r[a] = *reinterpret_cast<const double2*>(&csj[t & 1][2 * a]);      // all reads in flight
+                {   // slot 0: positions (0, NB-1)
+                    const double x = jr[0], y = jr[NB - 1];
+                    jr[0] = r[0].x * x - r[0].y * y;
+                    jr[NB - 1] = r[0].y * x + r[0].x * y;
+                }
+#pragma unroll
+                for (int a = 1; a < HP; ++a) {             // positions (a, NB-1-a)
+                    const double x = jr[a], y = jr[NB - 1 - a];
+                    jr[a] = r[a].x * x - r[a].y * y;
+                    jr[NB - 1 - a] = r[a].y * x + r[a].x * y;
+                }
+            }
+            const double first = jr[0];
+#pragma unroll
+            for (int f = 0; f < NB - 2; ++f) jr[f] = jr[f + 1];
+            jr[NB - 2] = first;
         };
         for (int sweep = 0; sweep < max_sweeps; ++sweep) {
             if (tid == 0) cnt = 0;
@@ -253,17 +274,24 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                                 rot = true;
                             }
                         }
-                        *reinterpret_cast<double2*>(&cs2[2 * tid]) = make_double2(c, sn);
+                        *reinterpret_cast<double2*>(&cs2[s & 1][2 * tid]) = make_double2(c, sn);
+                        // J's frame holds the pair as (column (s + a) mod (NB-1), column (s - a) mod (NB-1)), slot 0 as (s, NB-1);
+                        // the rotation is defined on (smaller, larger) column: flip the sine where the frame has them the other way
+                        int up = s + tid; up -= (up >= NB - 1) ? NB - 1 : 0;
+                        const bool flipped = (tid > 0) && (up != p);
+                        *reinterpret_cast<double2*>(&csj[s & 1][2 * tid]) = make_double2(c, flipped ? -sn : sn);
                     }
                     const unsigned long long any = __ballot(rot);
                     if (tid == 0) stepflag[s & 1] = (any != 0ull) ? 1 : 0;
+                } else if (jwave && s > 0) {
+                    apply_j(s - 1);                        // (reads the other halves of cs2 / stepflag)
                 }
                 __syncthreads();
                 if (stepflag[s & 1] == 0) continue;                // uniform: nothing to rotate in this step
                 {
                     int pb, qb;
                     slot_pair(s, tb, pb, qb);
-                    const double2 rb = *reinterpret_cast<const double2*>(&cs2[2 * tb]);
+                    const double2 rb = *reinterpret_cast<const double2*>(&cs2[s & 1][2 * tb]);
                     const double cb = rb.x, sb = rb.y;
                     double g00[GB], g01[GB], g10[GB], g11[GB];
                     int pa[GB], qa[GB];
@@ -271,15 +299,9 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
 #pragma unroll
                     for (int k = 0; k < GB; ++k) {
                         slot_pair(s, t0 + TS * k, pa[k], qa[k]);
-                        ra[k] = *reinterpret_cast<const double2*>(&cs2[2 * (t0 + TS * k)]);
+                        ra[k] = *reinterpret_cast<const double2*>(&cs2[s & 1][2 * (t0 + TS * k)]);
                         g00[k] = G[pa[k] * P + pb]; g01[k] = G[pa[k] * P + qb];
                         g10[k] = G[qa[k] * P + pb]; g11[k] = G[qa[k] * P + qb];
-                    }
-                    double jp[JB], jq[JB];
-#pragma unroll
-                    for (int k = 0; k < JB; ++k) {
-                        jp[k] = J[(t0 + TS * k) * P + pb];
-                        jq[k] = J[(t0 + TS * k) * P + qb];
                     }
 #pragma unroll
                     for (int k = 0; k < GB; ++k) {
@@ -289,14 +311,10 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
                         G[pa[k] * P + pb] = cb * t00 - sb * t01; G[pa[k] * P + qb] = sb * t00 + cb * t01;
                         G[qa[k] * P + pb] = cb * t10 - sb * t11; G[qa[k] * P + qb] = sb * t10 + cb * t11;
                     }
-#pragma unroll
-                    for (int k = 0; k < JB; ++k) {
-                        J[(t0 + TS * k) * P + pb] = cb * jp[k] - sb * jq[k];
-                        J[(t0 + TS * k) * P + qb] = sb * jp[k] + cb * jq[k];
-                    }
                 }
                 __syncthreads();
             }
+            if (jwave) apply_j(nsteps - 1);                // the last step of the sweep: the frame is back in place
             if (mine) atomicAdd(&cnt, mine);               // once per sweep, off the per-step critical path
             __syncthreads();
             if (tid == 0) total += cnt;
@@ -304,6 +322,11 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
             __syncthreads();
             if (done) break;
         }
+        if (jwave && tid - 192 < NB) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) J[(tid - 192) * P + k] = jr[k];
+        }
+        __syncthreads();
     }
     if (tid == 0 && nrot_out) nrot_out[grp] = total;
     if (mode != 1 && total > 0) {
@@ -372,16 +395,16 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
 }
 
 int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngroups, int mode, int max_sweeps,
-              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2, double bip_thr) {
+              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2) {
     TN_CHECK_ARG(nvec >= 1 && nvec <= NBMAX, "nvec out of range");
     if (ngroups <= 0) return 0;
     prof_begin(st, PROF_EIG);
     if (nvec <= 32)
         hipLaunchKernelGGL((eig_small_kernel<32>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,
-                           dead_thresh, out, dead, nrot, maxoff, relevant2, bip_thr);
+                           dead_thresh, out, dead, nrot, maxoff, relevant2);
     else
         hipLaunchKernelGGL((eig_small_kernel<64>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,
-                           dead_thresh, out, dead, nrot, maxoff, relevant2, bip_thr);
+                           dead_thresh, out, dead, nrot, maxoff, relevant2);
     TN_CHECK_LAUNCH("eig_small_kernel");
     prof_end(st, PROF_EIG, 0.0, 8.0 * ngroups * ((double)nchunk + 1.0) * nvec * nvec);
     return 0;

@@ -349,10 +349,6 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     static const int inner_env = [] { const char* e = getenv("TN_SVD_INNER"); return e ? atoi(e) : 2; }();
     const int inner_sweeps = (ng == 1) ? 12 : inner_env;
     static const bool restrict_conv = [] { const char* e = getenv("TN_SVD_RELEVANT"); return !(e && e[0] == '0'); }();
-    // bipartite inner sweeps for pairs whose halves are orthogonal and whose coupling is below TN_EIG_BIP (off by default:
-    // measured -4 % eig_small time at +2 % outer sweeps on the L = 2048 sweep -- the time is in the first visits, which need
-    // the cyclic sweep)
-    static const double bip_thr = [] { const char* e = getenv("TN_EIG_BIP"); return e ? atof(e) : 0.0; }();
     const double rel4 = 0.25 * rel_tol;
     const double relevant2 = restrict_conv ? nmax * rel4 * rel4 : 0.0;
     int sweeps = 0;
@@ -369,7 +365,7 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
             if ((rc = gemm_ex(st, nvec, nvec, L, 1.0, w.X, pitch, 1, w.X, 1, pitch, 0.0, nullptr, 0, 0, ng, 0, 0, 0, w.part,
                               (int64_t)ng * nchunk * nvec * nvec * 8, &xg)))
                 return rc;
-            if ((rc = eig_small(st, w.part, used, nvec, ng, 2, inner_sweeps, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng, relevant2, bip_thr)))
+            if ((rc = eig_small(st, w.part, used, nvec, ng, 2, inner_sweeps, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng, relevant2)))
                 return rc;
             GemmExtra xa;
             xa.pairs = pr; xa.pw = SVD_W; xa.mapB = 1; xa.mapC = 1; xa.skip = w.nrot;
