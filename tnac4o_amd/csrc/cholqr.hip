@@ -660,6 +660,12 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
     const double* src = first ? Xsrc : Y;
     const int64_t xrs = first ? srs : rs, xcs = first ? scs : cs;
     const bool colfast = (xcs == 1);
+    if (launch_no >= 3) {                                 // 94 % of the third and 99.8 % of the fourth passes find the panel converged:
+        if (tid == 0) s_st[0] = cq_ldi(&stt->done);       // look before fetching the tile
+        __syncthreads();
+        if (s_st[0]) return;
+        __syncthreads();
+    }
     {   // the state, the tile and the triangular factor in one memory round trip (a launch that finds the panel converged
         // throws the tile away)
         double xv[32], rv[5];

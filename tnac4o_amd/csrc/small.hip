@@ -4,6 +4,8 @@
 //   rows_times_small    X[r, :b] <- X[r, :b] . S      (tall panel times small matrix, in place)
 //   small_t_times_vecs  vecs <- S^T . vecs            (small matrix times a bundle of long vectors, in place)
 // All are HBM/LDS-streaming VALU kernels; the flops that matter live in gemm_f64.hip.
+#include <type_traits>
+
 #include "common.h"
 
 namespace tn {
@@ -223,98 +225,133 @@ __global__ __launch_bounds__(256) void eig_small_kernel(const double* __restrict
         double jr[NB];                                     // (wave 3) row `tid - 192` of J in the turning frame
 #pragma unroll
         for (int k = 0; k < NB; ++k) jr[k] = (k == tid - 192) ? 1.0 : 0.0;
-        auto apply_j = [&](int t) {                        // rotations of step t on the register row, then advance the frame
+        // The frame is advanced once per group of FU steps (FU divides NB-1), so that the register moves are amortised: within
+        // a group, step s = s0 + u finds column (s + a) at position (u + a) mod (NB-1) and column (s - a) at (u - a) mod (NB-1),
+        // column s itself (slot 0) at position u -- all compile-time constants once the loop over u is unrolled.
+        constexpr int FU = (NB == 64) ? 7 : ((NB == 32) ? 1 : 1);      // 63 = 9 x 7; 31 is prime (one step per group)
+        static_assert((NB - 1) % FU == 0, "group length must divide the sweep");
+        auto apply_j = [&](int t, auto uc) {               // rotations of step t (position offset u) on the register row
+            constexpr int u = decltype(uc)::value;
             if (stepflag[t & 1]) {
                 double2 r[HP];
 #pragma unroll
                 for (int a = 0; a < HP; ++a) r[a] = *reinterpret_cast<const double2*>(&csj[t & 1][2 * a]);      // all reads in flight
-                {   // slot 0: positions (0, NB-1)
-                    const double x = jr[0], y = jr[NB - 1];
-                    jr[0] = r[0].x * x - r[0].y * y;
+                {   // slot 0: (column s at position u, column NB-1 at position NB-1)
+                    const double x = jr[u], y = jr[NB - 1];
+                    jr[u] = r[0].x * x - r[0].y * y;
                     jr[NB - 1] = r[0].y * x + r[0].x * y;
                 }
 #pragma unroll
-                for (int a = 1; a < HP; ++a) {             // positions (a, NB-1-a)
-                    const double x = jr[a], y = jr[NB - 1 - a];
-                    jr[a] = r[a].x * x - r[a].y * y;
-                    jr[NB - 1 - a] = r[a].y * x + r[a].x * y;
+                for (int a = 1; a < HP; ++a) {
+                    constexpr int M = NB - 1;
+                    const int px = (u + a) % M, py = (u - a + M) % M;
+                    const double x = jr[px], y = jr[py];
+                    jr[px] = r[a].x * x - r[a].y * y;
+                    jr[py] = r[a].y * x + r[a].x * y;
                 }
             }
-            const double first = jr[0];
+        };
+        auto advance_frame = [&]() {                       // position f <- position (f + FU) mod (NB-1)
+            double tmp[FU];
 #pragma unroll
-            for (int f = 0; f < NB - 2; ++f) jr[f] = jr[f + 1];
-            jr[NB - 2] = first;
+            for (int f = 0; f < FU; ++f) tmp[f] = jr[f];
+#pragma unroll
+            for (int f = 0; f < NB - 1 - FU; ++f) jr[f] = jr[f + FU];
+#pragma unroll
+            for (int f = 0; f < FU; ++f) jr[NB - 1 - FU + f] = tmp[f];
+        };
+        auto step = [&](int s, auto uc, int& mine) -> void {     // one step of the tournament; u = s mod FU
+            constexpr int u = decltype(uc)::value;
+            if (tid < 64) {                                // wave 0 decides the rotations of this step
+                bool rot = false;
+                if (tid < HP) {
+                    int p, q;
+                    slot_pair(s, tid, p, q);
+                    const double gpq = G[p * P + q], gpp = G[p * P + p], gqq = G[q * P + q];
+                    double c = 1.0, sn = 0.0;
+                    // rotate iff |g_pq| > tol sqrt(g_pp g_qq), tested on the squares (no square root on the critical path)
+                    const double g2 = gpq * gpq;
+                    if (g2 > tol * tol * fabs(gpp * gqq)) {
+                        // smaller-angle rotation from the double angle: cos 2t = |d| / hyp, d = g_qq - g_pp,
+                        // hyp^2 = d^2 + 4 g_pq^2;  c^2 = (1 + cos 2t) / 2,  s = g_pq / (hyp c) with the sign of d g_pq
+                        const double d = gqq - gpp;
+                        const double rh = fast_rsqrt(d * d + 4.0 * g2);
+                        const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+                        const double rcv = fast_rsqrt(c2);
+                        const double sabs = fabs(gpq) * rh * rcv;
+                        if (sabs <= 1.0 && c2 <= 1.0000000000000002) {     // (fails for non-finite intermediates: no rotation)
+                            c = c2 * rcv;
+                            sn = ((d >= 0.0) == (gpq >= 0.0)) ? sabs : -sabs;
+                            ++mine;
+                            rot = true;
+                        }
+                    }
+                    *reinterpret_cast<double2*>(&cs2[s & 1][2 * tid]) = make_double2(c, sn);
+                    // J's frame holds the pair as (column (s + a) mod (NB-1), column (s - a) mod (NB-1)), slot 0 as (s, NB-1);
+                    // the rotation is defined on (smaller, larger) column: flip the sine where the frame has them the other way
+                    int up = s + tid; up -= (up >= NB - 1) ? NB - 1 : 0;
+                    const bool flipped = (tid > 0) && (up != p);
+                    *reinterpret_cast<double2*>(&csj[s & 1][2 * tid]) = make_double2(c, flipped ? -sn : sn);
+                }
+                const unsigned long long any = __ballot(rot);
+                if (tid == 0) stepflag[s & 1] = (any != 0ull) ? 1 : 0;
+            } else if (jwave && s > 0) {                   // J follows one step behind (reads the other halves of csj / stepflag)
+                if constexpr (u == 0) {
+                    apply_j(s - 1, std::integral_constant<int, FU - 1>{});
+                    advance_frame();
+                } else {
+                    apply_j(s - 1, std::integral_constant<int, u - 1>{});
+                }
+            }
+            __syncthreads();
+            if (stepflag[s & 1] == 0) return;              // uniform: nothing to rotate in this step
+            {
+                int pb, qb;
+                slot_pair(s, tb, pb, qb);
+                const double2 rb = *reinterpret_cast<const double2*>(&cs2[s & 1][2 * tb]);
+                const double cb = rb.x, sb = rb.y;
+                double g00[GB], g01[GB], g10[GB], g11[GB];
+                int pa[GB], qa[GB];
+                double2 ra[GB];
+#pragma unroll
+                for (int k = 0; k < GB; ++k) {
+                    slot_pair(s, t0 + TS * k, pa[k], qa[k]);
+                    ra[k] = *reinterpret_cast<const double2*>(&cs2[s & 1][2 * (t0 + TS * k)]);
+                    g00[k] = G[pa[k] * P + pb]; g01[k] = G[pa[k] * P + qb];
+                    g10[k] = G[qa[k] * P + pb]; g11[k] = G[qa[k] * P + qb];
+                }
+#pragma unroll
+                for (int k = 0; k < GB; ++k) {
+                    const double ca = ra[k].x, sa = ra[k].y;
+                    const double t00 = ca * g00[k] - sa * g10[k], t01 = ca * g01[k] - sa * g11[k];
+                    const double t10 = sa * g00[k] + ca * g10[k], t11 = sa * g01[k] + ca * g11[k];
+                    G[pa[k] * P + pb] = cb * t00 - sb * t01; G[pa[k] * P + qb] = sb * t00 + cb * t01;
+                    G[qa[k] * P + pb] = cb * t10 - sb * t11; G[qa[k] * P + qb] = sb * t10 + cb * t11;
+                }
+            }
+            __syncthreads();
         };
         for (int sweep = 0; sweep < max_sweeps; ++sweep) {
             if (tid == 0) cnt = 0;
             int mine = 0;                                  // rotations decided by this thread in this sweep
             __syncthreads();
-            for (int s = 0; s < nsteps; ++s) {
-                if (tid < 64) {                            // wave 0 decides the rotations of this step
-                    bool rot = false;
-                    if (tid < HP) {
-                        int p, q;
-                        slot_pair(s, tid, p, q);
-                        const double gpq = G[p * P + q], gpp = G[p * P + p], gqq = G[q * P + q];
-                        double c = 1.0, sn = 0.0;
-                        // rotate iff |g_pq| > tol sqrt(g_pp g_qq), tested on the squares (no square root on the critical path)
-                        const double g2 = gpq * gpq;
-                        if (g2 > tol * tol * fabs(gpp * gqq)) {
-                            // smaller-angle rotation from the double angle: cos 2t = |d| / hyp, d = g_qq - g_pp,
-                            // hyp^2 = d^2 + 4 g_pq^2;  c^2 = (1 + cos 2t) / 2,  s = g_pq / (hyp c) with the sign of d g_pq
-                            const double d = gqq - gpp;
-                            const double rh = fast_rsqrt(d * d + 4.0 * g2);
-                            const double c2 = 0.5 + 0.5 * fabs(d) * rh;
-                            const double rcv = fast_rsqrt(c2);
-                            const double sabs = fabs(gpq) * rh * rcv;
-                            if (sabs <= 1.0 && c2 <= 1.0000000000000002) {     // (fails for non-finite intermediates: no rotation)
-                                c = c2 * rcv;
-                                sn = ((d >= 0.0) == (gpq >= 0.0)) ? sabs : -sabs;
-                                ++mine;
-                                rot = true;
-                            }
-                        }
-                        *reinterpret_cast<double2*>(&cs2[s & 1][2 * tid]) = make_double2(c, sn);
-                        // J's frame holds the pair as (column (s + a) mod (NB-1), column (s - a) mod (NB-1)), slot 0 as (s, NB-1);
-                        // the rotation is defined on (smaller, larger) column: flip the sine where the frame has them the other way
-                        int up = s + tid; up -= (up >= NB - 1) ? NB - 1 : 0;
-                        const bool flipped = (tid > 0) && (up != p);
-                        *reinterpret_cast<double2*>(&csj[s & 1][2 * tid]) = make_double2(c, flipped ? -sn : sn);
-                    }
-                    const unsigned long long any = __ballot(rot);
-                    if (tid == 0) stepflag[s & 1] = (any != 0ull) ? 1 : 0;
-                } else if (jwave && s > 0) {
-                    apply_j(s - 1);                        // (reads the other halves of cs2 / stepflag)
+            for (int s0 = 0; s0 < nsteps; s0 += FU) {
+                if constexpr (FU == 7) {
+                    step(s0 + 0, std::integral_constant<int, 0>{}, mine);
+                    step(s0 + 1, std::integral_constant<int, 1>{}, mine);
+                    step(s0 + 2, std::integral_constant<int, 2>{}, mine);
+                    step(s0 + 3, std::integral_constant<int, 3>{}, mine);
+                    step(s0 + 4, std::integral_constant<int, 4>{}, mine);
+                    step(s0 + 5, std::integral_constant<int, 5>{}, mine);
+                    step(s0 + 6, std::integral_constant<int, 6>{}, mine);
+                } else {
+                    step(s0, std::integral_constant<int, 0>{}, mine);
                 }
-                __syncthreads();
-                if (stepflag[s & 1] == 0) continue;                // uniform: nothing to rotate in this step
-                {
-                    int pb, qb;
-                    slot_pair(s, tb, pb, qb);
-                    const double2 rb = *reinterpret_cast<const double2*>(&cs2[s & 1][2 * tb]);
-                    const double cb = rb.x, sb = rb.y;
-                    double g00[GB], g01[GB], g10[GB], g11[GB];
-                    int pa[GB], qa[GB];
-                    double2 ra[GB];
-#pragma unroll
-                    for (int k = 0; k < GB; ++k) {
-                        slot_pair(s, t0 + TS * k, pa[k], qa[k]);
-                        ra[k] = *reinterpret_cast<const double2*>(&cs2[s & 1][2 * (t0 + TS * k)]);
-                        g00[k] = G[pa[k] * P + pb]; g01[k] = G[pa[k] * P + qb];
-                        g10[k] = G[qa[k] * P + pb]; g11[k] = G[qa[k] * P + qb];
-                    }
-#pragma unroll
-                    for (int k = 0; k < GB; ++k) {
-                        const double ca = ra[k].x, sa = ra[k].y;
-                        const double t00 = ca * g00[k] - sa * g10[k], t01 = ca * g01[k] - sa * g11[k];
-                        const double t10 = sa * g00[k] + ca * g10[k], t11 = sa * g01[k] + ca * g11[k];
-                        G[pa[k] * P + pb] = cb * t00 - sb * t01; G[pa[k] * P + qb] = sb * t00 + cb * t01;
-                        G[qa[k] * P + pb] = cb * t10 - sb * t11; G[qa[k] * P + qb] = sb * t10 + cb * t11;
-                    }
-                }
-                __syncthreads();
             }
-            if (jwave) apply_j(nsteps - 1);                // the last step of the sweep: the frame is back in place
+            if (jwave) {                                   // the last step of the sweep; the frame is back in place afterwards
+                apply_j(nsteps - 1, std::integral_constant<int, FU - 1>{});
+                advance_frame();
+            }
             if (mine) atomicAdd(&cnt, mine);               // once per sweep, off the per-step critical path
             __syncthreads();
             if (tid == 0) total += cnt;
