@@ -294,3 +294,40 @@ def test_decode_spectrum_file_saved_by_reference():
     np.testing.assert_allclose(ins.energy, g[tag + '_energy'], rtol=0, atol=1e-12)
     assert sorted(map(bytes, np.asarray(ins.binary_states(), dtype=np.int16))) == \
         sorted(map(bytes, np.asarray(g[tag + '_bits'], dtype=np.int16)))
+
+
+def test_lazy_schmidt_values_are_evaluated_only_when_the_bond_keeps_its_dimension(monkeypatch):
+    """mps._LazyS / _SchmidtList / _previous_S (the update_S bookkeeping of mps.py:550-560 with deferred evaluation): a recorded
+    centre matrix is decomposed when the next update_S at that bond has the same length or when psi.S is read, and dropped
+    unevaluated when the length differs -- in every case the numbers are the ones the eager evaluation would have stored."""
+    import numpy as np
+    from tnac4o_amd import mps
+
+    calls = []
+
+    class FakeC:
+        def __init__(self, vals):
+            self.vals = np.asarray(vals, dtype=float)
+            self.shape = (len(vals), len(vals) + 3)
+
+    monkeypatch.setattr(mps._LazyS, 'values', lambda self: (calls.append(self.size), self.Cm.vals.copy())[1])
+
+    class Psi:
+        _one_S = staticmethod(lambda D: np.concatenate([[1.0], np.zeros(D - 1)]))
+
+    psi = Psi()
+    psi.S = mps._SchmidtList([Psi._one_S(2), Psi._one_S(2), Psi._one_S(2)])
+    psi.S[0] = mps._LazyS(FakeC([0.8, 0.6]))
+    psi.S[1] = mps._LazyS(FakeC([0.9, 0.3, 0.1]))
+    psi.S[2] = mps._LazyS(FakeC([0.5, 0.5]))
+    # same length: evaluated, and what comes back is the recorded spectrum
+    assert np.array_equal(mps._previous_S(psi, 0, 2), [0.8, 0.6]) and calls == [2]
+    # different length: dropped without evaluation, the reference's reset value is used
+    assert np.array_equal(mps._previous_S(psi, 1, 2), [1.0, 0.0]) and calls == [2]
+    # a plain array of the wrong length is reset as well (mps.py:555-556)
+    psi.S[1] = np.array([0.7, 0.2, 0.1])
+    assert np.array_equal(mps._previous_S(psi, 1, 4), [1.0, 0.0, 0.0, 0.0])
+    # reading the attribute evaluates (once) and yields plain arrays
+    assert np.array_equal(psi.S[2], [0.5, 0.5]) and calls == [2, 2]
+    assert np.array_equal(psi.S[2], [0.5, 0.5]) and calls == [2, 2]
+    assert all(isinstance(x, np.ndarray) for x in psi.S)
