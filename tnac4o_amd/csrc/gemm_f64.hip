@@ -10,6 +10,14 @@
 // stores of k-contiguous operands bank-conflict free.  The next K-tile is prefetched into registers while
 // the current one is multiplied.  MFMA f64 lane maps (cdna_hip_programming.md §3): A[l&15][l>>4],
 // B[l>>4][l&15], D reg r -> row (l>>4)+4r, col l&15.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
 #include "common.h"
 
 namespace tn {
@@ -243,9 +251,62 @@ int gemm(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const do
     return gemm_ex(st, M, N, K, alpha, A, rsa, csa, B, rsb, csb, beta, C, rsc, csc, batch, bsa, bsb, bsc, ws, ws_bytes, nullptr);
 }
 
+// TN_GEMM_TRACE=1 (diagnostics): every call is timed synchronously with a pair of events and booked under its shape; the table of
+// the most expensive shapes is printed when the process exits.  Perturbs the run (one synchronisation per GEMM).
+namespace {
+struct ShapeStat { double ms = 0.0; long calls = 0; };
+struct GemmTrace {
+    bool on;
+    std::mutex mu;
+    std::map<std::tuple<int64_t, int64_t, int64_t, int64_t, int, int, int>, ShapeStat> tab;
+    GemmTrace() { const char* e = getenv("TN_GEMM_TRACE"); on = e && e[0] == '1'; }
+    ~GemmTrace() {
+        if (!on || tab.empty()) return;
+        std::vector<std::pair<double, std::tuple<int64_t, int64_t, int64_t, int64_t, int, int, int>>> v;
+        double tot = 0.0;
+        for (auto& kv : tab) { v.push_back({kv.second.ms, kv.first}); tot += kv.second.ms; }
+        std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first > b.first; });
+        fprintf(stderr, "[tn_gemm trace] %zu shapes, %.1f ms in total; M N K batch transA transB splitk : calls, ms, us/call, TFLOP/s\n", v.size(), tot);
+        for (size_t i = 0; i < v.size() && i < 40; ++i) {
+            auto& k = v[i].second;
+            const ShapeStat& st = tab[k];
+            const double fl = 2.0 * std::get<0>(k) * std::get<1>(k) * std::get<2>(k) * std::get<3>(k) * st.calls;
+            fprintf(stderr, "  %6lld %6lld %6lld %5lld  %d %d %3d : %6ld  %8.2f  %8.2f  %6.2f\n", (long long)std::get<0>(k), (long long)std::get<1>(k),
+                    (long long)std::get<2>(k), (long long)std::get<3>(k), std::get<4>(k), std::get<5>(k), std::get<6>(k), st.calls, st.ms,
+                    1e3 * st.ms / st.calls, fl / (st.ms * 1e-3) / 1e12);
+        }
+    }
+};
+GemmTrace g_trace;
+}  // namespace
+
+static int gemm_ex_impl(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
+                        const double* B, int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc, int64_t batch,
+                        int64_t bsa, int64_t bsb, int64_t bsc, double* ws, int64_t ws_bytes, const GemmExtra* x);
+
 int gemm_ex(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
             const double* B, int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc, int64_t batch,
             int64_t bsa, int64_t bsb, int64_t bsc, double* ws, int64_t ws_bytes, const GemmExtra* x) {
+    if (!g_trace.on) return gemm_ex_impl(st, M, N, K, alpha, A, rsa, csa, B, rsb, csb, beta, C, rsc, csc, batch, bsa, bsb, bsc, ws, ws_bytes, x);
+    thread_local hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!e0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+    (void)hipEventRecord(e0, st);
+    const int rc = gemm_ex_impl(st, M, N, K, alpha, A, rsa, csa, B, rsb, csb, beta, C, rsc, csc, batch, bsa, bsb, bsc, ws, ws_bytes, x);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const int sk = (x && x->force_splitk > 0) ? x->force_splitk : pick_splitk(M, N, K, batch);
+    std::lock_guard<std::mutex> lk(g_trace.mu);
+    ShapeStat& ss = g_trace.tab[std::make_tuple(M, N, K, batch, (csa == 1 && rsa != 1) ? 1 : 0, (rsb == 1 && csb != 1) ? 1 : 0, (x && x->pairs) ? -sk : sk)];
+    ss.ms += ms;
+    ss.calls += 1;
+    return rc;
+}
+
+static int gemm_ex_impl(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
+                        const double* B, int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc, int64_t batch,
+                        int64_t bsa, int64_t bsb, int64_t bsc, double* ws, int64_t ws_bytes, const GemmExtra* x) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     TN_CHECK_ARG(K >= 0, "negative K");
     GemmP g;
@@ -272,8 +333,8 @@ int gemm_ex(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const
         const int64_t cb = 65535 / s;
         for (int64_t b0 = 0; b0 < batch; b0 += cb) {
             const int64_t nbt = batch - b0 < cb ? batch - b0 : cb;
-            const int rc = gemm_ex(st, M, N, K, alpha, A + b0 * bsa, rsa, csa, B + b0 * bsb, rsb, csb, beta, C + b0 * bsc, rsc, csc,
-                                   nbt, bsa, bsb, bsc, ws, ws_bytes, nullptr);
+            const int rc = gemm_ex_impl(st, M, N, K, alpha, A + b0 * bsa, rsa, csa, B + b0 * bsb, rsb, csb, beta, C + b0 * bsc, rsc, csc,
+                                        nbt, bsa, bsb, bsc, ws, ws_bytes, nullptr);
             if (rc) return rc;
         }
         return 0;
