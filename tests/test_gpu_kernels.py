@@ -621,3 +621,102 @@ def test_qr_fused_panel_matches_tsqr_panel(ops):
             os.environ.pop('TN_PANEL', None)
         else:
             os.environ['TN_PANEL'] = saved
+
+
+def _with_env(name, value, fn):
+    saved = os.environ.get(name)
+    try:
+        os.environ[name] = value
+        return fn()
+    finally:
+        if saved is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = saved
+
+
+def test_panel_single_launch_bit_identical_to_chain(ops):
+    """The single-launch panel step (cq_fused_kernel: <= 16 workgroups meeting at in-kernel barriers, every workgroup reducing /
+    factoring redundantly) against the six-launch chain (TN_PANEL_FUSED=0) on every panel case of up to 4096 rows: the same basis
+    bit for bit, the same pass / deferral / refill record."""
+    n = 0
+    for name, X in _panel_cases():
+        if X.shape[0] > 4096:
+            continue
+        Y1, st1, dev1 = _with_env('TN_PANEL_FUSED', '1', lambda: ops.panel_orth(X, 0, state=True))
+        Y0, st0, dev0 = _with_env('TN_PANEL_FUSED', '0', lambda: ops.panel_orth(X, 0, state=True))
+        assert torch.equal(Y0, Y1), name
+        assert st0[1] == st1[1] == 1 and st0[3] == st1[3] and st0[6:9] == st1[6:9], (name, st0, st1)
+        assert dev0[:st0[3] + 1] == dev1[:st1[3] + 1], (name, dev0, dev1)
+        n += 1
+    assert n >= 12
+
+
+def test_qr_single_launch_panels_bit_identical_to_chain(ops):
+    """tn_qr with the single-launch panel step (orthonormalisation + Householder reconstruction + reflector products in ONE
+    kernel per panel) against the six-launch chain: Q and R bit-identical on tall, wide, ragged, rank-deficient and graded
+    matrices, plain and with the rank-revealing early exit; also through the Householder fallback (TN_PANEL_MAXPASS is read once
+    per process, so that path is covered by the dedicated fallback test below when the variable is set)."""
+    g = torch.Generator(device='cpu').manual_seed(23)
+    rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g).cuda()
+    A = (rn(4096, 256) * torch.logspace(0, -20, 256, dtype=torch.float64).cuda()[None, :]) @ torch.linalg.qr(rn(256, 256))[0]
+    mats = [rn(4096, 256), rn(300, 1000).t(), rn(300, 1000), rn(50, 7), rn(4096, 64) @ rn(64, 512), A, rn(2048, 1024), rn(33, 33),
+            rn(1500, 700), torch.zeros(512, 64, dtype=torch.float64).cuda()]
+    for T in mats:
+        for tol in (0.0, 2.0 ** -56):
+            def run():
+                m, nn = T.shape
+                k = min(m, nn)
+                Q = torch.zeros((m, k), dtype=torch.float64, device='cuda')
+                R = torch.zeros((k, nn), dtype=torch.float64, device='cuda')
+                _, _, ke = ops.qr_into(T, Q, R, rank_tol=tol)
+                return Q[:, :ke].clone(), R[:ke].clone(), ke
+            Q1, R1, k1 = _with_env('TN_PANEL_FUSED', '1', run)
+            Q0, R0, k0 = _with_env('TN_PANEL_FUSED', '0', run)
+            assert k0 == k1 and torch.equal(Q0, Q1) and torch.equal(R0, R1), (tuple(T.shape), tol, k0, k1)
+            if float(T.abs().max()) > 0:
+                rel = ((Q1 @ R1 - T).norm(dim=0) / T.norm(dim=0).clamp_min(1e-300)).max().item()
+                assert rel < 1e-13 or tol > 0, (tuple(T.shape), rel)
+
+
+def test_qr_single_launch_panels_under_uneven_load(ops):
+    """The in-kernel barriers of the single-launch panel step under uneven load: four chains factor different matrices on four
+    streams while a fifth stream keeps the device full of large GEMMs; every result equals the one obtained alone (bit for bit).
+    (Guideline 16 of the MI355X guide: hand-offs must be tested with busy, L1-warm consumers.)"""
+    import threading
+    g = torch.Generator(device='cpu').manual_seed(29)
+    rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g).cuda()
+    mats = [rn(4096, 384), rn(3000, 256), rn(2048, 512), rn(1024, 1024)]
+    ref = [ops.qr(T) for T in mats]
+    torch.cuda.synchronize()
+    big_a, big_b = rn(4096, 4096), rn(4096, 4096)
+    streams = [torch.cuda.Stream() for _ in range(5)]
+    out, err = [None] * 4, []
+    stop = threading.Event()
+
+    def chain(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(6):
+                    out[i] = ops.qr(mats[i])
+                streams[i].synchronize()
+        except BaseException as e:          # noqa: BLE001
+            err.append(e)
+
+    def load():
+        with torch.cuda.stream(streams[4]):
+            while not stop.is_set():
+                ops.mm(big_a, big_b)
+                streams[4].synchronize()
+    th = [threading.Thread(target=chain, args=(i,)) for i in range(4)]
+    tl = threading.Thread(target=load)
+    tl.start()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    stop.set()
+    tl.join()
+    assert not err, err
+    for i in range(4):
+        assert torch.equal(out[i][0], ref[i][0]) and torch.equal(out[i][1], ref[i][1]), i

@@ -156,7 +156,8 @@ int tn_panel_orth(const double* X, int64_t rs, int64_t cs, int64_t nrows, int b,
     if (method == 1) return tsqr_orthonormalize(ST, X, rs, cs, Y, yrs, ycs, nrows, b, ws, ws_bytes);
     int rc = cholqr_reset(ST, ws);
     if (rc) return rc;
-    if ((rc = cholqr_orthonormalize(ST, X, rs, cs, Y, yrs, ycs, nrows, b, ws, ws_bytes, 0x5DEECE66DULL))) return rc;
+    int fbase = 0;
+    if ((rc = cholqr_orthonormalize(ST, X, rs, cs, Y, yrs, ycs, nrows, b, ws, ws_bytes, 0x5DEECE66DULL, &fbase))) return rc;
     if (state9_host && dev_host) return cholqr_debug_state(ST, ws, state9_host, dev_host);
     return 0;
 }

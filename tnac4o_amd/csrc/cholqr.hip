@@ -67,6 +67,8 @@ struct CqState {
     int ndefer_total;     // statistics: deferred pivots, refills, Householder fallbacks of this panel
     int nrefill_total;
     int fallback;
+    int fcounter;         // arrivals at the in-kernel barriers of the single-launch form (monotone over the panels of a call)
+    int timeout;          // sticky: a barrier of the single-launch form gave up (outputs poisoned with NaN)
     double dev_hist[CQ_MAXPASS + 2];
 };
 constexpr int CQ_STATE_BYTES = 256;
@@ -109,8 +111,9 @@ __device__ __forceinline__ void cq_publish_wait() { __builtin_amdgcn_fence(__ATO
 __device__ __forceinline__ int cq_ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Partial Gram of the 256 x 32 LDS tile T (pitch CQ_P): wave w covers rows 64w .. 64w+63 on the matrix cores, the four
-// partials meet in LDS (T is overwritten: callers are done with it) and their sum goes to part[0 .. 767].
-__device__ __forceinline__ void cq_block_gram(double* __restrict__ T, double* __restrict__ part, int tid) {
+// partials meet in the LDS scratch S (4 x 768 doubles; callers that are done with the tile pass T itself) and their sum goes
+// to part[0 .. 767].
+__device__ __forceinline__ void cq_block_gram(const double* T, double* S, double* __restrict__ part, int tid) {
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     d4c g00 = d4c{0, 0, 0, 0}, g01 = g00, g11 = g00;
 #pragma unroll
@@ -122,7 +125,7 @@ __device__ __forceinline__ void cq_block_gram(double* __restrict__ T, double* __
         g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, g11, 0, 0, 0);
     }
     __syncthreads();                                     // every wave has read its rows of T
-    double* sp = T + wave * CQ_PART;
+    double* sp = S + wave * CQ_PART;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = lk + 4 * r;
@@ -131,7 +134,7 @@ __device__ __forceinline__ void cq_block_gram(double* __restrict__ T, double* __
         sp[512 + i * 16 + li] = g11[r];
     }
     __syncthreads();
-    for (int e = tid; e < CQ_PART; e += 256) cq_st(part + e, (T[e] + T[CQ_PART + e]) + (T[2 * CQ_PART + e] + T[3 * CQ_PART + e]));
+    for (int e = tid; e < CQ_PART; e += 256) cq_st(part + e, (S[e] + S[CQ_PART + e]) + (S[2 * CQ_PART + e] + S[3 * CQ_PART + e]));
 }
 
 // process-wide statistics (diagnostics): panels, passes applied, deferred pivots, refilled columns, Householder fallbacks
@@ -343,7 +346,7 @@ __device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, i
                     const int i = ti * 16 + lk + 4 * q, j = tj * 16 + li_;
                     const double t = (i <= j && j < b) ? -acc[ti][tj][q] : 0.0;
                     Um[i * P + j] = t;                     // T
-                    if (i < b && j < b) Tp[i * b + j] = t;
+                    if (Tp && i < b && j < b) Tp[i * b + j] = t;
                 }
     }
     __syncthreads();
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__
     int nr;
     cq_block_rows(nrows, nblk, blk, r0, nr);
     const int ex = cq_load_scaled_tile(X, rs, cs, r0, nr, b, T, red, tid);
-    cq_block_gram(T, part + (int64_t)blk * CQ_PART, tid);
+    cq_block_gram(T, T, part + (int64_t)blk * CQ_PART, tid);
     if (tid == 0) cq_sti(bexp + blk, ex);
     cq_publish_wait();
     __syncthreads();
@@ -574,13 +577,14 @@ __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__
 
 // X <- X R^-1 on the 256-row tile T (LDS), row tid; Rs (LDS, 16-byte aligned): R row-major (1024) + reciprocal diagonal (32).
 // Columns flagged in deadmask (exactly zero before this pass) are refilled with hash noise.
-__device__ __forceinline__ void cq_substitute(double* T, const double* Rs, int tid, unsigned deadmask, uint64_t seed, int64_t r0, int nr) {
+__device__ __forceinline__ void cq_substitute(double* T, const double* Rs, int tid, unsigned deadmask, uint64_t seed, int64_t r0, int nr,
+                                              double scl = 1.0) {
     {   // substitution on row tid (right-looking: after step j all later columns are independent updates).  The multipliers
         // of step j+1 are fetched from LDS (broadcast reads) while step j computes; the scheduling barriers keep the compiler
         // from hoisting all 250 reads to the top (512 VGPRs and spills otherwise).
         double x[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) x[j] = T[tid * CQ_P + j];
+        for (int j = 0; j < 32; ++j) x[j] = T[tid * CQ_P + j] * scl;
         double2 mc[16], mn[16];
         double dc = Rs[1024], dn = 0.0, sc = Rs[1], sn = 0.0;      // reciprocal diagonal, the odd first multiplier
 #pragma unroll
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
             Rs[e] = T[(e >> 5) * CQ_P + (e & 31)];
         }
     }
-    if (!fin) cq_block_gram(T, part + (int64_t)blk * CQ_PART, tid);      // (its first barrier follows its reads of T)
+    if (!fin) cq_block_gram(T, T, part + (int64_t)blk * CQ_PART, tid);      // (its first barrier follows its reads of T)
     CQ_CLK(3);
     cq_publish_wait();
     __syncthreads();
@@ -747,8 +751,9 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
 // ---- post-processing: the reflector panels from the orthonormal one ---------------------------------------------------
 // rows >= b:  Y <- Q1 Uinv,  W <- Q1 UT (= Y T^T),  Wq <- Q1 UTq (= Y T, optional);  rows < b come from the reconstruction.
 // One tile of <= 256 rows on the matrix cores (wave w owns rows 64w .. 64w+63); tile: LDS 256 x CQ_P, Ss: LDS 3 x 1024.
+// tile_ready: the orthonormal tile is in `tile` already (single-launch form), otherwise it is fetched from Y.
 __device__ __forceinline__ void cq_post_tile(int blk, int nblk, int64_t nrows, int b, double* Y, int64_t rs, int64_t cs, double* W, int64_t wrs,
-                                             int64_t wcs, double* Wq, const double* lu, double* tile, double* Ss, int tid) {
+                                             int64_t wcs, double* Wq, const double* lu, double* tile, double* Ss, int tid, bool tile_ready = false) {
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     int64_t r0;
     int nr;
@@ -763,22 +768,26 @@ __device__ __forceinline__ void cq_post_tile(int blk, int nblk, int64_t nrows, i
             sv[1][t] = lu[CQ_LU_UT + e];
             sv[2][t] = lu[CQ_LU_UTQ + e];
         }
+        if (!tile_ready) {
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int e = tid + 256 * u;
-            const int i = xrow ? e >> 5 : e & 255, j = xrow ? e & 31 : e >> 8;
-            xv[u] = (i < nr && j < b) ? Y[(r0 + i) * rs + j * cs] : 0.0;
+            for (int u = 0; u < 32; ++u) {
+                const int e = tid + 256 * u;
+                const int i = xrow ? e >> 5 : e & 255, j = xrow ? e & 31 : e >> 8;
+                xv[u] = (i < nr && j < b) ? Y[(r0 + i) * rs + j * cs] : 0.0;
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int e = tid + 256 * t;
             Ss[e] = sv[0][t]; Ss[1024 + e] = sv[1][t]; Ss[2048 + e] = sv[2][t];
         }
+        if (!tile_ready) {
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int e = tid + 256 * u;
-            const int i = xrow ? e >> 5 : e & 255, j = xrow ? e & 31 : e >> 8;
-            tile[i * CQ_P + j] = xv[u];
+            for (int u = 0; u < 32; ++u) {
+                const int e = tid + 256 * u;
+                const int i = xrow ? e >> 5 : e & 255, j = xrow ? e & 31 : e >> 8;
+                tile[i * CQ_P + j] = xv[u];
+            }
         }
     }
     __syncthreads();
@@ -874,12 +883,306 @@ __global__ __launch_bounds__(256) void cq_post_kernel(const double* X, int64_t x
     }
 }
 
+// ---- the whole panel step in ONE launch ------------------------------------------------------------------------------
+// For panels of up to CQ_FUSED_MAXBLK x 256 rows (what the truncating passes and the variational sweeps factor: ~80 % of the
+// panels of a sweep) the chain  gram -> pass ... pass -> post  runs inside one kernel: every workgroup keeps its 256-row tile in
+// LDS from the first load to the last store (the six-launch form reloads and stores it in every launch), the workgroups meet at
+// in-kernel barriers (a monotone arrival counter polled by one lane, MI355X guide "Guideline 16": partials written with
+// agent-scope stores, drained, one atomic add per workgroup, relaxed agent-scope poll, agent-scope loads of the partials),
+// and after each barrier EVERY workgroup reduces the published partial Gram matrices, takes the decision and factors G itself
+// -- the same arithmetic in the same order as cq_tail, hence the same bits in every workgroup and the same result as the
+// six-launch form -- so no second hand-off is needed to distribute R.  The Householder reconstruction is redundant in the same
+// way: workgroup 0 publishes the top 32 x 32 block of the panel next to its partial Gram matrix.
+// Co-residency: <= 16 workgroups per launch, a handful of chains per device, 256 CUs: every workgroup of a launch is dispatched
+// as soon as the kernels ahead of it (which never wait for anything) drain; spins are bounded (CQ_SPIN_LIMIT polls, seconds), a
+// launch that gives up poisons its output with NaN and raises the sticky stt->timeout, which later launches of the call honour.
+constexpr int CQ_FUSED_MAXBLK = 16;
+constexpr unsigned CQ_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ bool cq_grid_barrier(int* counter, int target, int* s_flag, int tid) {
+    cq_publish_wait();                                     // every wave: its agent-scope stores have completed
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(counter, 1);
+        int ok = 1;
+        unsigned spins = 0;
+        while (cq_ldi(counter) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > CQ_SPIN_LIMIT) { ok = 0; break; }
+        }
+        *s_flag = ok;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+// cq_tail for the single-launch form, run by EVERY workgroup on the same published partials: sum (block order, optional
+// per-block power-of-two weights), distance from the identity, decision, Cholesky with deferral.  The factor goes to Rf (LDS:
+// 32 x 32 row-major + the 32 reciprocals of its diagonal) instead of global memory.  s_out (LDS, 4 ints): [0] decision
+// (0 factor again, 1 converged, 2 out of passes), [1] final_next, [2] dead-column mask, [3] emax (pass 0).  Only `writer`
+// (workgroup 0) keeps the panel's state block and the statistics.  Ends with a barrier.
+__device__ __forceinline__ void cq_tail_fused(const double* part, const int* bexp, int nblk, int b, int pass, CqState* stt, bool writer, double* Gs,
+                                              double* Rf, int* s_out, int maxpass, int tid) {
+    const int lane = tid & 63;
+    int emax = 0;
+    if (bexp) {
+        int e = -100000;
+        for (int i = lane; i < nblk; i += 64) { const int x = cq_ldi(bexp + i); e = x > e ? x : e; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(e, o, 64); e = y > e ? y : e; }
+        emax = e;
+    }
+    {
+        double acc[3] = {0.0, 0.0, 0.0};
+        for (int blk0 = 0; blk0 < nblk; blk0 += 32) {
+            double v[3][32];
+            int ex[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int blk = blk0 + u;
+                const bool in = blk < nblk;
+                ex[u] = (bexp && in) ? cq_ldi(bexp + blk) : emax;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) v[q][u] = in ? cq_ld(part + (int64_t)blk * CQ_PART + tid + 256 * q) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const double w = bexp ? ldexp(1.0, 2 * (ex[u] - emax)) : 1.0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[q] = fma(w, v[q][u], acc[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = tid + 256 * q, i = (e >> 4) & 15, j = e & 15;
+            const int gi = (q == 2 ? 16 : 0) + i, gj = (q == 0 ? 0 : 16) + j;
+            Gs[gi * CQ_P + gj] = acc[q];
+            if (q == 1) Gs[gj * CQ_P + gi] = acc[q];
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int k = lane & 31;
+        double g[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const double x = Gs[i * CQ_P + k];
+            g[i] = (i < b && k < b) ? x : ((i == k) ? 1.0 : 0.0);
+        }
+        double dev = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const double x = fabs(g[i] - (i == k ? 1.0 : 0.0));
+            dev = (x == x) ? fmax(dev, x) : 1e300;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dev = fmax(dev, __shfl_xor(dev, o, 64));
+        int dec = 0;
+        if (pass > 0 && dev <= CQ_DONE) dec = 1;
+        else if (pass >= maxpass) dec = 2;
+        if (lane == 0) {
+            s_out[0] = dec;
+            s_out[3] = emax;
+            if (dec != 0) { s_out[1] = 0; s_out[2] = 0; }
+            if (writer) {
+                stt->dev_hist[pass <= CQ_MAXPASS ? pass : CQ_MAXPASS] = dev;
+                if (bexp) stt->emax = emax;
+                if (dec != 0) {
+                    stt->done = 1;
+                    stt->final_next = 0;
+                    stt->dead = 0u;
+                    if (dec == 2) stt->fallback = 1;
+                    cq_count(pass, stt->ndefer_total, stt->nrefill_total, dec == 2);
+                }
+            }
+        }
+        if (dec == 0) {
+            double gd = 0.0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) gd = (i == k) ? g[i] : gd;
+            const bool zero_k = !(gd > 1e-290) || !(gd < 1e300);
+            const unsigned deadmask = (unsigned)(__ballot(zero_k) & 0xffffffffull);
+            const double thr_k = zero_k ? 1e308 : CQ_THETA * gd;
+            unsigned badmask = 0u;
+            double dkk = 1.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const double d = cq_readlane(g[j], j), thr = cq_readlane(thr_k, j);
+                const bool ok = d > thr;
+                badmask |= ok ? 0u : (1u << j);
+                const double rinv = cq_rsqrt2(ok ? d : 1.0);
+                double r = (k >= j) ? g[j] * (ok ? rinv : 0.0) : 0.0;
+                r = (!ok && k == j) ? 1.0 : r;
+                if (j == k) dkk = r;
+                if (lane < 32) Rf[j * 32 + k] = r;
+                if (j < 31) {
+                    const double m1 = cq_readlane(r, j + 1);
+                    const int i0 = (j + 3) & ~1;
+                    double2 m[16];
+                    double m2 = 0.0;
+                    if (j + 2 < 32 && ((j + 2) & 1)) m2 = Rf[j * 32 + j + 2];
+#pragma unroll
+                    for (int i = i0; i < 32; i += 2) m[i >> 1] = *reinterpret_cast<const double2*>(&Rf[j * 32 + i]);
+                    cq_fnma(g[j + 1], m1, r);
+                    if (j + 2 < 32 && ((j + 2) & 1)) cq_fnma(g[j + 2], m2, r);
+#pragma unroll
+                    for (int i = i0; i < 32; i += 2) {
+                        cq_fnma(g[i], m[i >> 1].x, r);
+                        cq_fnma(g[i + 1], m[i >> 1].y, r);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32) Rf[1024 + k] = fast_rcp(dkk);
+            if (lane == 0) {
+                const int fin = (pass > 0 && dev <= CQ_LAST && badmask == 0u) ? 1 : 0;
+                s_out[1] = fin;
+                s_out[2] = (int)deadmask;
+                if (writer) {
+                    stt->final_next = fin;
+                    stt->dead = deadmask;
+                    stt->ndefer_total += __popc(badmask & ~deadmask);
+                    stt->nrefill_total += __popc(deadmask);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// part: 2 x nblk x CQ_PART (pass parity), topblk: 2 x 1024 (pass parity), lu_all: nblk x CQ_LU_DOUBLES (private to each workgroup)
+// or NULL (orthonormalisation only).  base: arrivals booked on stt->fcounter by the earlier launches of the call; every launch books
+// exactly (maxpass + 1) * nblk.
+__global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t xrs, int64_t xcs, double* Y, int64_t rs, int64_t cs, int64_t nrows,
+                                                       int b, int nblk, double* part, int* bexp, double* topblk, CqState* stt, int base,
+                                                       uint64_t seed, double* lu_all, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq,
+                                                       int maxpass) {
+    __shared__ double T[CQ_RB * CQ_P];
+    __shared__ __attribute__((aligned(16))) double GR[3 * 1024];      // Gram 32 x 33 | factor 1024 + 32; later the three S matrices of the post step
+    __shared__ __attribute__((aligned(16))) double scr[4 * 32 * 33 + 64];
+    __shared__ double red[4];
+    __shared__ int s_out[4];
+    __shared__ int s_flag;
+    double* Gs = GR;
+    double* Rf = GR + 32 * CQ_P;                            // 1056 doubles in: 16-byte aligned
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    const bool writer = (blk == 0);
+    int64_t r0;
+    int nr;
+    cq_block_rows(nrows, nblk, blk, r0, nr);
+    int nbar = 0;
+    bool alive = true;
+    if (tid == 0) s_flag = cq_ldi(&stt->timeout) ? 0 : 1;
+    __syncthreads();
+    alive = s_flag != 0;
+    __syncthreads();
+    if (alive) {
+        if (writer && tid == 0) { stt->done = 0; stt->pass = 0; stt->ndefer_total = 0; stt->nrefill_total = 0; stt->fallback = 0; }
+        const int ex = cq_load_scaled_tile(X, xrs, xcs, r0, nr, b, T, red, tid);
+        cq_block_gram(T, scr, part + (int64_t)blk * CQ_PART, tid);
+        if (tid == 0) cq_sti(bexp + blk, ex);
+        alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid);
+        int dec = 0, tlast = 0;
+        if (alive) {
+            cq_tail_fused(part, bexp, nblk, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid);
+            dec = s_out[0];
+            const int emax = s_out[3];
+            const double scl0 = (ex > -2000 && emax > -2000) ? ldexp(1.0, ex - emax) : 0.0;     // tile is 2^-ex X; the passes work on 2^-emax X
+            for (int t = 1; dec == 0; ++t) {
+                const int fin = s_out[1];
+                const unsigned deadmask = (unsigned)s_out[2];
+                __syncthreads();                             // s_out is rewritten by the next tail
+                cq_substitute(T, Rf, tid, deadmask, seed + 0x9E3779B97F4A7C15ULL * (uint64_t)t, r0, nr, t == 1 ? scl0 : 1.0);
+                __syncthreads();
+                double* pt = part + (int64_t)(t & 1) * nblk * CQ_PART;
+                if (!fin) cq_block_gram(T, scr, pt + (int64_t)blk * CQ_PART, tid);
+                if (writer && lu_all) {
+                    double* tb = topblk + (t & 1) * 1024;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; cq_st(tb + e, T[(e >> 5) * CQ_P + (e & 31)]); }
+                }
+                if (writer && tid == 0) stt->pass = t;
+                alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid);
+                if (!alive) break;
+                tlast = t;
+                if (fin) {
+                    dec = 1;
+                    if (writer && tid == 0) {
+                        stt->done = 1; stt->final_next = 0; stt->dead = 0u;
+                        cq_count(t, stt->ndefer_total, stt->nrefill_total, false);
+                    }
+                    break;
+                }
+                cq_tail_fused(pt, nullptr, nblk, b, t, stt, writer, Gs, Rf, s_out, maxpass, tid);
+                dec = s_out[0];
+            }
+        }
+        if (alive && dec == 1) {
+            if (lu_all == nullptr) {
+                cq_store_tile(T, Y, rs, cs, r0, nr, b, tid);
+            } else {
+                double* lu = lu_all + (int64_t)blk * CQ_LU_DOUBLES;
+                cq_lu(topblk + (tlast & 1) * 1024, true, b, lu, writer ? Tp : nullptr, scr, tid);
+                __syncthreads();                             // (waits for this workgroup's stores to lu as well)
+                cq_post_tile(blk, nblk, nrows, b, Y, rs, cs, W, wrs, wcs, Wq, lu, T, GR, tid, true);
+            }
+        } else if (alive && dec == 2 && writer) {
+            // out of passes (never seen on the contraction path): workgroup 0 redoes the panel with Householder reflections from
+            // the untouched input and post-processes every tile itself, exactly as cq_post_kernel does
+            const int emax = s_out[3];
+            __syncthreads();
+            cq_fallback_householder(X, xrs, xcs, Y, rs, cs, nrows, b, emax, scr, tid);
+            if (lu_all) {
+                double* lu = lu_all;
+                __threadfence();
+                __syncthreads();
+                for (int e = tid; e < 1024; e += 256) {
+                    const int i = e >> 5, j = e & 31;
+                    lu[CQ_LU_YTOP + e] = (i < b && j < b && i < nrows) ? cq_ld(Y + (int64_t)i * rs + j * cs) : 0.0;
+                }
+                __threadfence();
+                __syncthreads();
+                cq_lu(lu + CQ_LU_YTOP, true, b, lu, Tp, scr, tid);
+                __threadfence();
+                __syncthreads();
+                for (int t = 0; t < nblk; ++t) {
+                    cq_post_tile(t, nblk, nrows, b, Y, rs, cs, W, wrs, wcs, Wq, lu, T, GR, tid);
+                    __threadfence();
+                    __syncthreads();
+                }
+            }
+        }
+    }
+    if (!alive) {                                            // a barrier gave up (or an earlier launch of this call did): poison the output
+        if (tid == 0) cq_sti(&stt->timeout, 1);
+        const double bad = __longlong_as_double(0x7ff8000000000000LL);
+        for (int e = tid; e < nr * b; e += 256) {
+            const int i = e / b, j = e % b;
+            Y[(r0 + i) * rs + j * cs] = bad;
+            if (W) W[(r0 + i) * wrs + j * wcs] = bad;
+        }
+    }
+    // every launch books (maxpass + 1) * nblk arrivals, however many barriers it took
+    if (tid == 0 && nbar < maxpass + 1) atomicAdd(&stt->fcounter, maxpass + 1 - nbar);
+}
+
 // ---- host driver ---------------------------------------------------------------------------------------------------
+// layout: state | R (1024 + 32) | partial Gram matrices (x 2 for the single-launch form) | block exponents |
+//         reconstruction buffers (one per workgroup for the single-launch form) | top block of the panel (x 2)
+static inline bool cq_fused_fits(int64_t nblk) { return nblk <= CQ_FUSED_MAXBLK; }
 int64_t cholqr_ws_bytes(int64_t nrows, int b) {
     (void)b;
     const int64_t nblk = cdiv(nrows, CQ_RB);
-    return CQ_STATE_BYTES + align_up((1024 + 32) * 8, 256) + align_up(nblk * CQ_PART * 8, 256) + align_up(nblk * 4, 256) +
-           align_up((int64_t)CQ_LU_DOUBLES * 8, 256) + 256;
+    const int64_t nlu = cq_fused_fits(nblk) ? nblk : 1, npart = cq_fused_fits(nblk) ? 2 * nblk : nblk;
+    return CQ_STATE_BYTES + align_up((1024 + 32) * 8, 256) + align_up(npart * CQ_PART * 8, 256) + align_up(nblk * 4, 256) +
+           align_up(nlu * CQ_LU_DOUBLES * 8, 256) + align_up(2 * 1024 * 8, 256) + 256;
+}
+
+// TN_PANEL_FUSED=0 keeps the six-launch chain for every panel (A/B measurements, cross-checks); read per call: the tests switch it
+static bool cq_fused_enabled() {
+    const char* e = getenv("TN_PANEL_FUSED");
+    return !(e && e[0] == '0');
 }
 
 // The state block at the head of the workspace must be zero before the first panel of a call (the kernels leave it clean).
@@ -894,7 +1197,7 @@ int cholqr_reset(hipStream_t st, void* ws) {
 // wrs/wcs) and, when Wq != NULL, Wq = Y T (strides of Y), i.e. what lu_reconstruct_kernel + rows_times_small3 of qr.hip produce,
 // in the launch slots that would otherwise return at once.
 int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws,
-                 int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq) {
+                 int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq, int* fused_base) {
     TN_CHECK_ARG(b >= 1 && b <= 32, "panel width must be <= 32");
     TN_CHECK_ARG(nrows >= b, "panel must have at least b rows");
     TN_CHECK_ARG(ws_bytes >= cholqr_ws_bytes(nrows, b), "workspace too small");
@@ -904,11 +1207,25 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
     char* p = (char*)ws;
     CqState* stt = (CqState*)p; p += CQ_STATE_BYTES;
     double* Rg = (double*)p; p += align_up((1024 + 32) * 8, 256);
-    double* part = (double*)p; p += align_up((int64_t)nblk * CQ_PART * 8, 256);
+    const bool fits = cq_fused_fits(nblk);
+    double* part = (double*)p; p += align_up((int64_t)(fits ? 2 * nblk : nblk) * CQ_PART * 8, 256);
     int* bexp = (int*)p; p += align_up((int64_t)nblk * 4, 256);
-    double* lu = reconstruct ? (double*)p : nullptr;
+    double* lu = reconstruct ? (double*)p : nullptr; p += align_up((int64_t)(fits ? nblk : 1) * CQ_LU_DOUBLES * 8, 256);
+    double* topblk = (double*)p;
     // TN_PANEL_MAXPASS (1 .. CQ_MAXPASS): fewer substitution passes, to drive the Householder fallback in tests
     static const int maxpass = [] { const char* e = getenv("TN_PANEL_MAXPASS"); const int v = e ? atoi(e) : CQ_MAXPASS; return v >= 1 && v <= CQ_MAXPASS ? v : CQ_MAXPASS; }();
+    if (fits && fused_base && cq_fused_enabled()) {
+        // one launch for the whole chain.  Algorithmic bytes: the panel in, the reflectors (and W, Wq) out -- the tile never
+        // leaves LDS in between; flops: Gram + post at launch time, the passes are booked from the device counter (cq_stats[3])
+        prof_begin(st, PROF_TSQR);
+        hipLaunchKernelGGL(cq_fused_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, part, bexp, topblk, stt,
+                           *fused_base, seed, lu, Tp, W, wrs, wcs, Wq, maxpass);
+        TN_CHECK_LAUNCH("cq_fused_kernel");
+        *fused_base += (maxpass + 1) * nblk;
+        const double e = (double)nrows * b;
+        prof_end(st, PROF_TSQR, (2.0 + (reconstruct ? (Wq ? 6.0 : 4.0) : 0.0)) * e * b, (reconstruct ? (Wq ? 32.0 : 24.0) : 16.0) * e);
+        return 0;
+    }
     prof_begin(st, PROF_TSQR);
     hipLaunchKernelGGL(cq_gram_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, nrows, b, nblk, part, bexp, stt, Rg);
     TN_CHECK_LAUNCH("cq_gram_kernel");
@@ -928,8 +1245,8 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
 }
 
 int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows,
-                          int b, void* ws, int64_t ws_bytes, uint64_t seed) {
-    return cholqr_panel(st, X, irs, ics, Y, rs, cs, nrows, b, ws, ws_bytes, seed, 0, nullptr, nullptr, 0, 0, nullptr);
+                          int b, void* ws, int64_t ws_bytes, uint64_t seed, int* fused_base) {
+    return cholqr_panel(st, X, irs, ics, Y, rs, cs, nrows, b, ws, ws_bytes, seed, 0, nullptr, nullptr, 0, 0, nullptr, fused_base);
 }
 
 // diagnostics: state block of the last panel (synchronises the stream) and the process-wide counters

@@ -164,11 +164,12 @@ int tsqr_orthonormalize(hipStream_t st, const double* Xin, int64_t irs, int64_t 
 // ---- iterated Cholesky-QR panel orthonormalisation (cholqr.hip), the default panel step -------------------------------
 int64_t cholqr_ws_bytes(int64_t nrows, int b);
 int cholqr_reset(hipStream_t st, void* ws);          // zero the state block once per call, before the first panel
+// fused_base: host counter of the call (0 after cholqr_reset) for the single-launch form of small panels; NULL = six-launch chain
 int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows,
-                          int b, void* ws, int64_t ws_bytes, uint64_t seed);
+                          int b, void* ws, int64_t ws_bytes, uint64_t seed, int* fused_base);
 // the whole panel step: orthonormal basis, and with reconstruct != 0 the Householder reconstruction (Y, T, W = Y T^T, Wq = Y T)
 int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws,
-                 int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq);
+                 int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq, int* fused_base);
 int cholqr_debug_state(hipStream_t st, const void* ws, int* ints9, double* dev_hist);
 int cholqr_stats(unsigned long long* out8, int reset);
 

@@ -605,9 +605,9 @@ static bool panel_tsqr() {
     return e && e[0] == 't';
 }
 static int panel_orthonormalize(hipStream_t st, const double* Xin, int64_t irs, int64_t ics, double* X, int64_t rs, int64_t cs, int64_t nrows,
-                                int b, void* ws, int64_t ws_bytes, bool tsqr, uint64_t seed) {
+                                int b, void* ws, int64_t ws_bytes, bool tsqr, uint64_t seed, int* fused_base) {
     if (tsqr) return tsqr_orthonormalize(st, Xin, irs, ics, X, rs, cs, nrows, b, ws, ws_bytes);
-    return cholqr_orthonormalize(st, Xin, irs, ics, X, rs, cs, nrows, b, ws, ws_bytes, seed);
+    return cholqr_orthonormalize(st, Xin, irs, ics, X, rs, cs, nrows, b, ws, ws_bytes, seed, fused_base);
 }
 
 constexpr int QR_NBO_MAX = 256;       // widest outer block of the two-level factorisation
@@ -688,7 +688,7 @@ int64_t qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_layout(m, n, nb, n
 // truncating passes checks the trailing block after every second panel, which needs it up to date.
 static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k, Mat Ym, QrWs& w, int nbo, int64_t rs, int64_t cs,
                         int64_t yrs, int64_t ycs, int64_t wrs, int64_t wcs, double* Q, int64_t qrs, int64_t qcs, double* R, int64_t rrs,
-                        int64_t rcs, bool use_tsqr) {
+                        int64_t rcs, bool use_tsqr, int* fused_base) {
     const int nb = 32;
     int rc;
     const int nblk = (int)cdiv(k, nbo);
@@ -713,10 +713,10 @@ static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k,
             if (!use_tsqr) {
                 // orthonormalisation + Householder reconstruction + the tall products in one chain of launches (cholqr.hip)
                 if ((rc = cholqr_panel(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, (uint64_t)p + 1, 1, Tp, Wp.p, wrs, wcs,
-                                       nullptr)))
+                                       nullptr, fused_base)))
                     return rc;
             } else {
-            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1))) return rc;
+            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1, fused_base))) return rc;
             // Wq_top goes to a scratch corner of the (otherwise unused here) Wq buffer: only Y, T and W = Y T^T are needed
             TN_PROF_LAUNCH(st, PROF_LU, hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT,
                                w.UTq, Wp.p, wrs, wcs, w.Wq));
@@ -838,12 +838,13 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
     int rc;
     const bool use_tsqr = panel_tsqr();
     if (nb == 32 && !use_tsqr && (rc = cholqr_reset(st, w.tsqr_ws))) return rc;
+    int fbase = 0;                            // arrivals booked by the single-launch panel steps of this call (cholqr.hip)
     {   // two-level blocking for the plain factorisation of matrices with several outer blocks (TN_QR_NBO = 0 disables it)
         const char* e_nbo = getenv("TN_QR_NBO");                      // read per call: the tests switch it
         const int v_nbo = e_nbo ? atoi(e_nbo) : 256, nbo = (v_nbo == 128 || v_nbo == 256) ? v_nbo : 0;
         if (nbo > 0 && nb == 32 && !(rank_tol > 0.0 && keff_host != nullptr) && k >= 2 * nbo && m >= 4 * nbo) {
             if (keff_host) *keff_host = k;
-            return qr_two_level(st, Am, m, n, k, Ym, w, nbo, rs, cs, yrs, ycs, wrs, wcs, Q, qrs, qcs, R, rrs, rcs, use_tsqr);
+            return qr_two_level(st, Am, m, n, k, Ym, w, nbo, rs, cs, yrs, ycs, wrs, wcs, Q, qrs, qcs, R, rrs, rcs, use_tsqr, &fbase);
         }
     }
     thread_local LookaheadEvents ev;
@@ -921,10 +922,10 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
             double* Tpf = w.T + (int64_t)p * nb * nb;
             Mat Wqf = sub(Wqm, j0, j0), Wpf = mat((lookahead && (p & 1)) ? w.W2 : w.W, wrs, wcs);
             if ((rc = cholqr_panel(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, (uint64_t)p + 1, 1, Tpf, Wpf.p, wrs, wcs,
-                                   Wqf.p)))
+                                   Wqf.p, &fbase)))
                 return rc;
         } else if (nb == 32) {
-            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1))) return rc;
+            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1, &fbase))) return rc;
         } else {
             if ((rc = copy_mat(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b))) return rc;
             const int nchunk = gram_nchunk(mp);
