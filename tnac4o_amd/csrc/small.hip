@@ -583,13 +583,15 @@ __global__ __launch_bounds__(256) void eig_small2_kernel(const double* __restric
             }
             return false;
         };
-        auto publish = [&](int s, int a, int p, double c, double sn, bool rot) {      // wave 0, lane a < HP: parameters of step s
-            *reinterpret_cast<double2*>(&cs2[s & 1][2 * a]) = make_double2(c, sn);
+        // wave 0, lane a < HP: parameters of step s into buffer `pb` (the buffers alternate from step to step ACROSS sweeps: a sweep
+        // has an odd number of steps, so the parity of s itself would collide at the sweep boundary)
+        auto publish = [&](int pb, int s, int a, int p, double c, double sn, bool rot) {
+            *reinterpret_cast<double2*>(&cs2[pb][2 * a]) = make_double2(c, sn);
             int up = s + a; up -= (up >= M) ? M : 0;
             const bool flipped = (a > 0) && (up != p);
-            *reinterpret_cast<double2*>(&csj[s & 1][2 * a]) = make_double2(c, flipped ? -sn : sn);
+            *reinterpret_cast<double2*>(&csj[pb][2 * a]) = make_double2(c, flipped ? -sn : sn);
             const unsigned long long any = __ballot(rot);
-            if (a == 0) stepflag[s & 1] = (any != 0ull) ? 1 : 0;
+            if (a == 0) stepflag[pb] = (any != 0ull) ? 1 : 0;
         };
         const bool jwave = (tid >= 192);
         double jr[NB];
@@ -597,11 +599,11 @@ __global__ __launch_bounds__(256) void eig_small2_kernel(const double* __restric
         for (int k = 0; k < NB; ++k) jr[k] = (k == tid - 192) ? 1.0 : 0.0;
         constexpr int FU = (NB == 64) ? 7 : 1;
         static_assert(M % FU == 0, "group length must divide the sweep");
-        auto apply_j = [&](int t, auto uc) {
+        auto apply_j = [&](int pb, auto uc) {
             constexpr int u = decltype(uc)::value;
             double2 r[HP];
 #pragma unroll
-            for (int a = 0; a < HP; ++a) r[a] = *reinterpret_cast<const double2*>(&csj[t & 1][2 * a]);
+            for (int a = 0; a < HP; ++a) r[a] = *reinterpret_cast<const double2*>(&csj[pb][2 * a]);
             {
                 const double x = jr[u], y = jr[NB - 1];
                 jr[u] = r[0].x * x - r[0].y * y;
@@ -636,14 +638,15 @@ __global__ __launch_bounds__(256) void eig_small2_kernel(const double* __restric
                 rot = decide(G[p * P + p], G[q * P + q], G[p * P + q], c, sn);
                 if (rot) ++mine;
             }
-            if (tid < HP) publish(0, tid, p, c, sn, rot);
+            if (tid < HP) publish(0, 0, tid, p, c, sn, rot);
             else (void)__ballot(false);
         }
         __syncthreads();
+        int par = 0;                                       // parameter buffer of the step in progress
         // one step of the tournament: phase of step s (u = s mod FU compile-time for the register frame of J)
         auto step = [&](int s, auto uc) -> void {
             constexpr int u = decltype(uc)::value;
-            const int flag = stepflag[s & 1];               // uniform
+            const int flag = stepflag[par];                 // uniform
             const double* Gc = Gb[cur];
             double* Gn = Gb[cur ^ 1];
             if (tid < 64) {
@@ -662,8 +665,8 @@ __global__ __launch_bounds__(256) void eig_small2_kernel(const double* __restric
                         int pp, qp, pq, qq;
                         slot_pair(s, ap, pp, qp);           // pair holding p in step s
                         slot_pair(s, aq, pq, qq);           // pair holding q in step s
-                        const double2 rp = *reinterpret_cast<const double2*>(&cs2[s & 1][2 * ap]);
-                        const double2 rq = *reinterpret_cast<const double2*>(&cs2[s & 1][2 * aq]);
+                        const double2 rp = *reinterpret_cast<const double2*>(&cs2[par][2 * ap]);
+                        const double2 rq = *reinterpret_cast<const double2*>(&cs2[par][2 * aq]);
                         // block (ap, ap) -> g_pp;  block (aq, aq) -> g_qq;  block (ap, aq) -> g_pq
                         const double a00 = Gc[pp * P + pp], a01 = Gc[pp * P + qp], a10 = Gc[qp * P + pp], a11 = Gc[qp * P + qp];
                         const double b00 = Gc[pq * P + pq], b01 = Gc[pq * P + qq], b10 = Gc[qq * P + pq], b11 = Gc[qq * P + qq];
@@ -689,10 +692,10 @@ __global__ __launch_bounds__(256) void eig_small2_kernel(const double* __restric
                     rot = decide(gpp, gqq, gpq, c, sn);
                     if (rot) { if (s + 1 == M) ++mine_next; else ++mine; }
                 }
-                if (tid < HP) publish(s + 1, tid, p, c, sn, rot);      // (parity of s + 1; the step index itself is s1)
+                if (tid < HP) publish(par ^ 1, s1, tid, p, c, sn, rot);
                 else (void)__ballot(false);
             } else if (jwave) {
-                if (flag) apply_j(s, uc);
+                if (flag) apply_j(par, uc);
                 if constexpr (u == FU - 1) advance_frame();
             } else if (flag) {
                 // ---- waves 1 and 2: G[nxt] <- R^T G[cur] R, block (a, b) = rows of slot a x columns of slot b
@@ -701,14 +704,14 @@ __global__ __launch_bounds__(256) void eig_small2_kernel(const double* __restric
                 constexpr int TS = 128 / HP;
                 int pb, qb;
                 slot_pair(s, tb, pb, qb);
-                const double2 rb = *reinterpret_cast<const double2*>(&cs2[s & 1][2 * tb]);
+                const double2 rb = *reinterpret_cast<const double2*>(&cs2[par][2 * tb]);
                 double g00[UB], g01[UB], g10[UB], g11[UB];
                 int pa[UB], qa[UB];
                 double2 ra[UB];
 #pragma unroll
                 for (int k = 0; k < UB; ++k) {
                     slot_pair(s, t0 + TS * k, pa[k], qa[k]);
-                    ra[k] = *reinterpret_cast<const double2*>(&cs2[s & 1][2 * (t0 + TS * k)]);
+                    ra[k] = *reinterpret_cast<const double2*>(&cs2[par][2 * (t0 + TS * k)]);
                     g00[k] = Gc[pa[k] * P + pb]; g01[k] = Gc[pa[k] * P + qb];
                     g10[k] = Gc[qa[k] * P + pb]; g11[k] = Gc[qa[k] * P + qb];
                 }
@@ -723,6 +726,7 @@ __global__ __launch_bounds__(256) void eig_small2_kernel(const double* __restric
             }
             __syncthreads();
             cur ^= flag;
+            par ^= 1;
         };
         for (int sweep = 0; sweep < max_sweeps; ++sweep) {
             if (tid == 0) cnt = 0;

@@ -15,8 +15,8 @@ def case(n, rank, decay, seed):
     rn = lambda *s: torch.randn(*s, dtype=torch.float64, generator=g).cuda()
     U, _ = torch.linalg.qr(rn(n, n))
     V, _ = torch.linalg.qr(rn(n, n))
-    S = torch.logspace(0, -decay, n, dtype=torch.float64).cuda()
-    S[rank:] *= 1e-3
+    # numerically low rank, as on the contraction path: the spectrum reaches 10^-decay at index `rank` and keeps falling
+    S = torch.pow(10.0, -decay * torch.arange(n, dtype=torch.float64) / rank).clamp_min(1e-300).cuda()
     A = (U * S[None, :]) @ V.t()
     _, R = torch.linalg.qr(A)              # what the canonisation hands to truncateC: a triangular factor
     return R.contiguous(), S
@@ -38,11 +38,27 @@ def main():
         ms = 1e3 * (time.perf_counter() - t0) / reps
         ou = (U.t() @ U - torch.eye(keep, dtype=torch.float64, device='cuda')).abs().max().item()
         ov = (Vt @ Vt.t() - torch.eye(keep, dtype=torch.float64, device='cuda')).abs().max().item()
-        ref = torch.linalg.svdvals(R)[:keep]
+        ref = torch.as_tensor(__import__('numpy').linalg.svd(R.cpu().numpy(), compute_uv=False)[:keep]).cuda()
         ds = ((Sg - ref).abs().max() / ref[0]).item()
         rec = ((U * Sg[None, :]) @ Vt - R).norm().item() / R.norm().item()
         print('svd_trunc %4d x %4d  keep %3d  sweeps %2d  %.3f ms   |U^T U - 1| %.1e  |V V^T - 1| %.1e  dS/S0 %.1e  residual %.1e (discarded %.1e)'
               % (n, n, keep, info['sweeps'], ms, ou, ov, ds, rec, disc), flush=True)
+        if os.environ.get('TN_PROBE_FAMILIES'):
+            import ctypes as C
+            from tnac4o_amd._lib import lib
+            L = lib()
+            L.tn_profile_reset()
+            L.tn_profile_enable((1 << 15) - 1)
+            ops.svd_trunc(R, dmax, 1e-16)
+            torch.cuda.synchronize()
+            L.tn_profile_enable(0)
+            names = ['gemm128x128', 'gemm128x32', 'gemm32x128', 'gemm64x64', 'splitk_reduce', 'absorb', 'gram', 'eig_small', 'rows_small',
+                     'vecs_small', 'panel', 'lu', 'qr_aux', 'svd_aux', 'misc']
+            for f, nm in enumerate(names):
+                calls, msf, fl, by = C.c_uint64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+                L.tn_profile_get(f, C.byref(calls), C.byref(msf), C.byref(fl), C.byref(by))
+                if calls.value:
+                    print('      %-14s %6d launches  %8.3f ms  (%.1f us each)' % (nm, calls.value, msf.value, 1e3 * msf.value / calls.value), flush=True)
 
 
 if __name__ == '__main__':
