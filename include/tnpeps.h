@@ -243,6 +243,39 @@ void tn_profile_sample(unsigned every);
 int tn_profile_get(int family, uint64_t* calls_host, double* ms_host, double* flops_host, double* bytes_host);
 int tn_profile_get_phase(int phase, int family, uint64_t* calls_host, double* ms_host, double* flops_host, double* bytes_host);
 
+/* ---- the chain driver: MPS.apply_mpo (mps.py:353-359) + MPS.compress_mps (mps.py:175-200) of ONE boundary MPS in ONE call ------------
+ * What tnac4o.py:1688-1693 does per row (copy, apply_mpo, compress_mps) without a host interpreter between the ~600 kernel-launching
+ * steps: the same kernels on the same operands in the same order as the per-step entry points above (bit-identical results), walked in
+ * C++ on the caller's thread.  Every intermediate tensor lives in `arena` (DEVICE, 256-byte aligned, arena_bytes >=
+ * tn_compress_mps_arena_bytes(...)), managed by a host-side allocator inside the call; the library still allocates nothing on the device.
+ *   sites_host[n]   DEVICE pointer to MPS site n, (Dl, p, Dr) C-order, dims in site_dims_host[3n .. 3n+2]; read only
+ *   mpo_host[n]     DEVICE pointer to MPO site n (ba, po, bb, pi) C-order (dims in mpo_dims_host[4n ..]) or NULL = no absorption at
+ *                   that site; mpo_host itself may be NULL (compress only).  hconj as for tn_absorb
+ *   Dmax, tolS, tolV, max_sweeps, graduate   the arguments of compress_mps (graduate_truncation as 0/1)
+ *   flags           bit 0: weighted rank-revealing first pass (MPS.canonise_right_weighted), bit 1: its Gram recursion
+ *                   through the MPS (x) MPO structure, bit 2: lazy Schmidt values in a stage's last sweep
+ *   out             DEVICE, L slots of out_slot doubles: compressed site n (left-canonical, C-order) at out + n*out_slot, its dims in
+ *                   out_dims_host[3n ..]
+ *   overlap_host    <psi|phi> returned by compress_mps;  discarded_host[L+1]: MPS.discarded;  schmidt_host ((L+1) x schmidt_pitch) /
+ *                   schmidt_len_host[L+1]: MPS.S (-1: bond never measured)
+ *   nfs_dev         DEVICE table of nfs_cap pairs [nf, 1/nf]: the power-of-two factors taken out of the centre matrices (normC is
+ *                   their product), *nfs_count_host of them written
+ *   info_host[8]    {a-posteriori bound of the weighted pass, plain-pass fallbacks, weighted pass used, peak arena bytes, sum of the
+ *                   bond dimensions before / after the first canonisation pass, 0, 0}
+ * Synchronises `stream` wherever the algorithm needs a number on the host (kept ranks, convergence, overlaps).  On return the results
+ * have been copied out of the arena by `stream`; the arena may be reused by the next call on the same stream.
+ * Errors: -3 arena too small, -4 Jacobi sweeps did not converge even after QR preconditioning, -5 zero centre matrix. */
+int64_t tn_compress_mps_arena_bytes(int64_t L, const int64_t* site_dims_host, const int64_t* mpo_dims_host, int64_t Dmax);
+int tn_compress_mps(int64_t L, const double* const* sites_host, const int64_t* site_dims_host, const double* const* mpo_host,
+                    const int64_t* mpo_dims_host, int hconj, int64_t Dmax, double tolS, double tolV, int max_sweeps, int graduate, int flags,
+                    double* out, int64_t out_slot, int64_t* out_dims_host, double* overlap_host, double* discarded_host, double* schmidt_host,
+                    int64_t schmidt_pitch, int64_t* schmidt_len_host, double* nfs_dev, int64_t nfs_cap, int64_t* nfs_count_host, double* info_host,
+                    void* arena, int64_t arena_bytes, void* stream);
+/* The two small reductions of the weighted first pass whose order is part of the result (both drivers call these):
+ * perm_out (DEVICE int64[n]) = stable descending argsort of w (NaN first);  w_out[i] = a[i] * b[i] and sum_out[0] = their sum in a fixed order. */
+int tn_argsort_desc(const double* w, int64_t n, int64_t* perm_out, void* stream);
+int tn_weighted_sum(const double* a, const double* b, int64_t n, double* w_out, double* sum_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

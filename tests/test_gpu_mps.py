@@ -542,17 +542,17 @@ def test_weighted_first_pass_matches_plain_pass(L, chi):
     from tnac4o_amd import ops, mps
     kw = dict(graduate_truncation=True, Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
     bounds, bonds = [], []
-    orig = mps.MPS.canonise_right_weighted
+    orig = mps.MPS._compress_native
 
-    def spy(self):
-        full = sum(self.D)
-        ok = orig(self)
-        bounds.append((ok, self.reveal_error_bound))
-        bonds.append((full, sum(self.D)))
-        return ok
+    def spy(self, *a, **k):                 # (the production path: the C++ chain driver reports the pass's bound and bond sums)
+        out = orig(self, *a, **k)
+        if self.native_info['weighted_used']:
+            bounds.append((self.native_info['reveal_fallbacks'] == 0, self.native_info['reveal_error_bound']))
+            bonds.append((self.native_info['bonds_before'], self.native_info['bonds_after']))
+        return out
     res = []
     saved = ops.PASS1_WEIGHTED, os.environ.get('TN_QR_NBO')
-    mps.MPS.canonise_right_weighted = spy
+    mps.MPS._compress_native = spy
     try:
         # plain pass twice (two-level and single-level QR blocking: a pure rounding-level change), then the weighted pass
         for weighted, nbo in ((False, '256'), (False, '0'), (True, '256')):
@@ -569,7 +569,7 @@ def test_weighted_first_pass_matches_plain_pass(L, chi):
             os.environ.pop('TN_QR_NBO', None)
         else:
             os.environ['TN_QR_NBO'] = saved[1]
-        mps.MPS.canonise_right_weighted = orig
+        mps.MPS._compress_native = orig
     a, a2, b = res
     assert bounds and all(ok and 0.0 <= e <= 2.0 ** -57 for ok, e in bounds)
     print('bond sums before / after the weighted pass:', bonds)
@@ -583,3 +583,41 @@ def test_weighted_first_pass_matches_plain_pass(L, chi):
     for x, x2, y in zip(a.rhoT, a2.rhoT, b.rhoT):
         spread = 1.0 - fidelity(host_chain(x), host_chain(x2))
         assert 1.0 - fidelity(host_chain(x), host_chain(y)) < 1e-13 + 10.0 * max(spread, 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('L,chi,rot,bottom', [(128, 8, 3, False), (128, 32, 0, True), (512, 32, 1, False), (2048, 64, 0, False)])
+def test_native_chain_driver_bit_identical_to_python_driver(L, chi, rot, bottom):
+    """tn_compress_mps (apply_mpo + compress_mps of a row in ONE library call, walked in C++: csrc/chain.hip) against the Python
+    driver that issues the same steps one library call at a time (MPS._compress_python): a whole sweep -- absorption, the weighted
+    rank-revealing first pass with its host decisions, all truncating passes, the variational sweeps with lazy / batched Schmidt
+    values -- must come out bit-identical: site tensors, bond dimensions, overlaps, discarded weights, Schmidt values."""
+    from tnac4o_amd import ops
+    from tnac4o_amd.auxx import synthetic_chimera
+    kw = dict(graduate_truncation=True, Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
+    res = []
+    saved = ops.NATIVE_CHAIN
+    try:
+        for native in (False, True):
+            ops.NATIVE_CHAIN = native
+            s = gpu_solver(L=L, rot=rot) if L != 2048 else gpu_solver(L=L, J=synthetic_chimera(16, 16, 20260004))
+            (s._setup_rhoB if bottom else s._setup_rhoT)(**kw)
+            res.append(s)
+    finally:
+        ops.NATIVE_CHAIN = saved
+    a, b = res
+    ra, rb = (a.rhoB, b.rhoB) if bottom else (a.rhoT, b.rhoT)
+    assert [m.D for m in ra] == [m.D for m in rb]
+    if bottom:
+        assert a.rhoB_discarded == b.rhoB_discarded and a.rhoB_overlap == b.rhoB_overlap
+    else:
+        assert a.rhoT_discarded == b.rhoT_discarded and a.rhoT_overlap == b.rhoT_overlap
+    for x, y in zip(ra, rb):
+        assert all(torch.equal(p, q) for p, q in zip(x.A, y.A))
+        assert all(np.array_equal(p, q) for p, q in zip(x.S, y.S))
+        assert getattr(x, 'reveal_error_bound', None) == getattr(y, 'reveal_error_bound', None)
+    if L == 2048:
+        info = rb[8].native_info
+        assert info['weighted_used'] and info['reveal_fallbacks'] == 0 and info['arena_peak'] <= info['arena_bytes']
+        print('arena: peak %.2f GB of %.2f GB; bonds %d -> %d after the weighted pass' % (info['arena_peak'] / 1e9, info['arena_bytes'] / 1e9,
+                                                                                       info['bonds_before'], info['bonds_after']))

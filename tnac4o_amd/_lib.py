@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libtnpeps.so')
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['api.hip', 'gemm_f64.hip', 'small.hip', 'qr.hip', 'svd.hip', 'absorb.hip', 'misc.hip', 'beam.hip', 'prof.hip', 'tsqr.hip', 'cholqr.hip', 'peps.hip', 'env.hip', 'batch.hip', 'site.hip']
+SOURCES = ['api.hip', 'gemm_f64.hip', 'small.hip', 'qr.hip', 'svd.hip', 'absorb.hip', 'misc.hip', 'beam.hip', 'prof.hip', 'tsqr.hip', 'cholqr.hip', 'peps.hip', 'env.hip', 'batch.hip', 'site.hip', 'chain.hip']
 
 _i64, _f64, _int, _ptr = C.c_int64, C.c_double, C.c_int, C.c_void_p
 
@@ -63,6 +63,12 @@ SIGNATURES = {
     'tn_apply_truncation_ws_bytes': (_i64, [_i64] * 5),
     'tn_apply_truncation': (_int, [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr,
                             _i64, _ptr]),
+    'tn_compress_mps_arena_bytes': (_i64, [_i64, C.POINTER(_i64), C.POINTER(_i64), _i64]),
+    'tn_compress_mps': (_int, [_i64, C.POINTER(_ptr), C.POINTER(_i64), C.POINTER(_ptr), C.POINTER(_i64), _int, _i64, _f64, _f64, _int, _int, _int,
+                        _ptr, _i64, C.POINTER(_i64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), _i64, C.POINTER(_i64), _ptr, _i64,
+                        C.POINTER(_i64), C.POINTER(_f64), _ptr, _i64, _ptr]),
+    'tn_argsort_desc': (_int, [_ptr, _i64, _ptr, _ptr]),
+    'tn_weighted_sum': (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr]),
     'tn_profile_enable': (None, [C.c_uint]),
     'tn_profile_reset': (None, []),
     'tn_profile_sample': (None, [C.c_uint]),
@@ -109,9 +115,9 @@ def _stale(L):
 SHORT_CALLS = ('tn_gemm', 'tn_gemm_ws_bytes', 'tn_qr_ws_bytes', 'tn_svd_ws_bytes', 'tn_absorb', 'tn_nfactor', 'tn_scale_by',
                'tn_normalize_pow2', 'tn_scale_phys', 'tn_calc_pn', 'tn_nfactor_batched', 'tn_env_rr_batched', 'tn_env_rl_batched',
                'tn_balance', 'tn_svdvals_async', 'tn_rar', 'tn_rar_ws_bytes', 'tn_env_mix', 'tn_env_mix_ws_bytes',
-               'tn_apply_truncation', 'tn_apply_truncation_ws_bytes', 'tn_site_qr_ws_bytes', 'tn_gram_weights', 'tn_rows_norm2', 'tn_gather_scale_rows', 'tn_peps_factor', 'tn_mpo_from_factor', 'tn_last_error')
+               'tn_apply_truncation', 'tn_apply_truncation_ws_bytes', 'tn_site_qr_ws_bytes', 'tn_gram_weights', 'tn_argsort_desc', 'tn_weighted_sum', 'tn_rows_norm2', 'tn_gather_scale_rows', 'tn_peps_factor', 'tn_mpo_from_factor', 'tn_last_error')
 _lib = None
-ABI_VERSION = 4          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
+ABI_VERSION = 5          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
 
 
 def lib():

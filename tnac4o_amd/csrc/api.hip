@@ -71,7 +71,7 @@ using namespace tn;
 
 extern "C" {
 
-int tn_version(void) { return 4; }
+int tn_version(void) { return 5; }
 
 #ifndef TN_SRC_HASH
 #define TN_SRC_HASH "unknown"

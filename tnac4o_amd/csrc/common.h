@@ -30,7 +30,8 @@ inline int hip_fail(hipError_t e, const char* what) {
         if (e__ != hipSuccess) return tn::hip_fail(e__, what); \
     } while (0)
 
-// Thread-local page-locked host buffers for the small read-backs / uploads around host decisions (slot 0..3, grown on demand,
+// Thread-local page-locked host buffers for the small read-backs / uploads around host decisions (slot 0..7: 0-1 tn_qr, 2-3 the
+// Jacobi SVD, 4-6 the chain driver; grown on demand,
 // released when the thread exits).  A copy into pageable memory makes hipMemcpyAsync drain the stream on the host first and only
 // then enqueue the transfer (15-20 us of idle device per read-back, 15 k read-backs per sweep); with page-locked memory the
 // transfer is queued right behind the producing kernel.  Returns nullptr if the allocation fails (callers fall back to pageable).

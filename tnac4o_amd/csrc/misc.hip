@@ -10,8 +10,8 @@ struct PinnedSlot {
     ~PinnedSlot() { if (p) (void)hipHostFree(p); }
 };
 void* pinned_host(size_t bytes, int slot) {
-    thread_local PinnedSlot slots[4];
-    if (slot < 0 || slot > 3) return nullptr;
+    thread_local PinnedSlot slots[8];
+    if (slot < 0 || slot > 7) return nullptr;
     PinnedSlot& s = slots[slot];
     if (s.cap < bytes) {
         if (s.p) { (void)hipHostFree(s.p); s.p = nullptr; s.cap = 0; }

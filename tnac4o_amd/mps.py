@@ -6,6 +6,7 @@ reference (file:line cited per method) so the solver code reads the same; PyTorc
 Site tensors are contiguous float64 ``(Dl, p, Dr)`` CUDA tensors.  Host syncs happen only where the algorithm
 needs a number on the host: the kept rank in ``truncateC``, the Schmidt values in ``update_S`` and the overlap.
 """
+import math
 import os
 
 import numpy as np
@@ -166,6 +167,15 @@ def _previous_S(psi, pC, size):
     return old
 
 
+def _dist(a, b):
+    """||a - b||_2 summed in index order (the C++ chain driver adds in the same order)."""
+    acc = 0.0
+    for x, y in zip(a, b):
+        d = float(x) - float(y)
+        acc += d * d
+    return math.sqrt(acc)
+
+
 class _DeferredSchmidt:
     """The update_S calls of one variational sweep (mps.py:550-560), taken asynchronously and replayed in order at the end.
 
@@ -227,7 +237,7 @@ class _DeferredSchmidt:
                     S = ops.svdvals(Cm)          # not converged in the fused kernel: the full path (raises if that fails too)
                 else:
                     S = host[row, :k].copy()
-            dS = float(np.sqrt(np.sum((_previous_S(psi, pC, S.size) - S) ** 2)))
+            dS = _dist(_previous_S(psi, pC, S.size), S)
             psi.S[pC] = S
             if measure:
                 diff = max(diff, dS)
@@ -506,10 +516,18 @@ class MPS:
             self.reveal_error_bound = 0.0
             return True
         pack = torch.cat([gfac[m][:1] for m in range(1, L + 1)] + [G.reshape(1)] + [weights[n][1][:64] for n in used]).cpu().numpy()
-        logg = np.concatenate([[0.0], np.cumsum(np.log2(pack[:L]))])              # log2 of the scale removed up to bond n
-        log_psi = 0.5 * (logg[L] + np.log2(pack[L]))                               # log2 ||psi||
+        # (host arithmetic through libm's log2 / pow / sqrt in a fixed order: tn_compress_mps reproduces it bit for bit)
+        logg = [0.0]
+        for m in range(L):
+            logg.append(logg[-1] + math.log2(float(pack[m])))                      # log2 of the scale removed up to bond n
+        log_psi = 0.5 * (logg[L] + math.log2(float(pack[L])))                      # log2 ||psi||
         kparts = pack[L + 1:].reshape(len(used), 64)
-        bound = {n: float(sum(float(x) for x in kparts[i])) ** 0.25 for i, n in enumerate(used)}       # ||L'||_2 <= ||K||_F^(1/2)
+        bound = {}
+        for i, n in enumerate(used):                                               # ||L'||_2 <= ||K||_F^(1/2)
+            acc = 0.0
+            for x in kparts[i]:
+                acc += float(x)
+            bound[n] = math.pow(acc, 0.25)
         budget = 2.0 ** -57 / len(used)
         self.C = torch.ones((1, 1), dtype=torch.float64, device=dev)
         self.pC = L
@@ -523,15 +541,16 @@ class MPS:
             Dl, p, Dr = self.A[n].shape
             r = self.C.shape[1]
             A = ops.mm(self.A[n].view(Dl * p, Dr), self.C).view(Dl, p * r)          # M_n (attach_AC)
-            w = d2 * ops.rows_norm2(A)
-            host = torch.cat([w.sum().reshape(1)] + [f[:1] for f in pending]).cpu().numpy()       # the per-site read-back
-            lognf_done += float(np.sum(np.log2(host[1:])))
+            w, wsum = ops.weighted_sum(d2, ops.rows_norm2(A))
+            host = torch.cat([wsum] + [f[:1] for f in pending]).cpu().numpy()       # the per-site read-back
+            for x in host[1:]:
+                lognf_done += math.log2(float(x))
             pending = []
             logN = log_psi - lognf_done                                             # log2 of the state norm in this step's units
-            scale = 2.0 ** (0.5 * logg[n] - logN) * bound[n]                        # relative change of the state per unit ||E||_F
-            fro = float(np.sqrt(host[0]))
+            scale = math.pow(2.0, 0.5 * logg[n] - logN) * bound[n]                  # relative change of the state per unit ||E||_F
+            fro = math.sqrt(float(host[0]))
             rel_tol = min(2.0 ** -40, max(1e-30, budget / (scale * fro))) if fro > 0.0 else 0.0
-            perm = torch.argsort(w, descending=True)                                # 1024 keys: index plumbing
+            perm = ops.argsort_desc(w)                                              # 1024 keys: index plumbing
             B = ops.gather_scale_rows(A, perm, d2)
             info = {}
             Qt, Ctp, k, _ = ops.site_qr(1, B.view(Dl, p, r), None, rel_tol, normalise=False, info=info, frobenius_exit=True,
@@ -545,7 +564,7 @@ class MPS:
             self.C = Ct
             self.D[n], self.D[n + 1] = k, r
             self.pC = n
-            err += scale * float(np.sqrt(info['dropped2']))
+            err += scale * math.sqrt(info['dropped2'])
         self.R[-1] = None
         self.reveal_error_bound = float(err)
         if ops.PASS1_TRACE:
@@ -638,7 +657,7 @@ class MPS:
     def update_S(self):
         """Schmidt values of the centre matrix; returns ||S_old - S_new||_2 (mps.py:550-560)."""
         S = ops.svdvals(self.C)
-        dS = float(np.sqrt(np.sum((_previous_S(self, self.pC, S.size) - S) ** 2)))
+        dS = _dist(_previous_S(self, self.pC, S.size), S)
         self.S[self.pC] = S
         return dS
 
@@ -675,8 +694,60 @@ class MPS:
             sweeps += 1
         return overlap
 
+    def _compress_native(self, mpo, Hconj, Dmax, tolS, tolV, max_sweeps, graduate_truncation):
+        """apply_mpo (when mpo is given) + compress_mps through tn_compress_mps: the whole chain of this row in one library call,
+        walked in C++ without the interpreter (and without the GIL: with the 4 lattice rotations on 4 host threads the Python
+        between the ~600 steps of a row sets the pace).  Same kernels, same order: bit-identical to the Python driver."""
+        W = None
+        A = [a if a.is_contiguous() else a.contiguous() for a in self.A]
+        if mpo is not None:
+            W = [mpo.W[n] if mpo.support[n] else None for n in range(self.L)]
+        else:
+            # an absorption recorded by apply_mpo whose products are still the current sites: hand the factors over instead (the
+            # driver absorbs them again, 16 launches, and pushes the Gram recursion of the weighted pass through them exactly as the
+            # Python driver does)
+            fac = getattr(self, '_absorbed', None) or {}
+            if fac and all(f[3] == self.A[n].data_ptr() for n, f in fac.items()) and len({f[2] for f in fac.values()}) == 1:
+                A = [fac[n][0].contiguous() if n in fac else A[n] for n in range(self.L)]
+                W = [fac[n][1].contiguous() if n in fac else None for n in range(self.L)]
+                Hconj = next(iter(fac.values()))[2]
+        res = ops.compress_mps_native(A, W, Hconj, int(Dmax), tolS if tolS is not None else self.zero, tolV if tolV is not None else self.zero,
+                                      max_sweeps, graduate_truncation, weighted=ops.PASS1_WEIGHTED, structured=PASS1_STRUCTURED, lazy=LAZY_SCHMIDT)
+        self.A = res['A']
+        self.d = [int(a.shape[1]) for a in self.A]
+        self.D = [int(self.A[0].shape[0])] + [int(a.shape[2]) for a in self.A]
+        self.C = torch.ones((1, 1), dtype=torch.float64, device=self.A[0].device)
+        self.pC = self.L
+        self._nfs = list(self._nfs) + res['nfs']
+        self._absorbed = None
+        self.discarded = res['discarded']
+        self.reset_R()
+        self.R[-1] = res['overlap']
+        self.S = _SchmidtList(res['S'][n] if res['S'][n] is not None else self._one_S(self.D[n]) for n in range(self.L + 1))
+        if res['info']['weighted_used']:
+            self.reveal_error_bound = res['info']['reveal_error_bound']
+            if res['info']['reveal_fallbacks']:
+                self.reveal_fallbacks = getattr(self, 'reveal_fallbacks', 0) + res['info']['reveal_fallbacks']
+        self.native_info = res['info']
+        return res['overlap']
+
+    def apply_mpo_compress(self, M, Hconj=False, Dmax=np.inf, tolS=None, tolV=None, max_sweeps=4, graduate_truncation=True):
+        """apply_mpo(M, Hconj) followed by compress_mps(...) -- the row step of the sweeps (tnac4o.py:1689-1693) -- as ONE library
+        call when the native chain driver is enabled, the two separate steps otherwise.  Returns the overlap."""
+        if ops.NATIVE_CHAIN and ops.FUSED_SITE and np.isfinite(Dmax):
+            return self._compress_native(M, Hconj, Dmax, tolS, tolV, max_sweeps, graduate_truncation)
+        self.apply_mpo(M, Hconj=Hconj)
+        return self._compress_python(Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps, graduate_truncation=graduate_truncation)
+
     def compress_mps(self, Dmax=np.inf, tolS=None, tolV=None, max_sweeps=4, graduate_truncation=True, verbose=False):
-        """Truncate: SVD initialisation + variational sweeps (mps.py:175-200).  Returns the overlap <psi|phi>."""
+        """Truncate: SVD initialisation + variational sweeps (mps.py:175-200).  Returns the overlap <psi|phi>.  Runs in the C++ chain
+        driver (tn_compress_mps) unless TN_NATIVE_CHAIN=0 selects the Python driver below (same kernels, same order)."""
+        if ops.NATIVE_CHAIN and ops.FUSED_SITE and np.isfinite(Dmax) and tolS is not None:
+            return self._compress_native(None, False, Dmax, tolS, tolV, max_sweeps, graduate_truncation)
+        return self._compress_python(Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps, graduate_truncation=graduate_truncation)
+
+    def _compress_python(self, Dmax=np.inf, tolS=None, tolV=None, max_sweeps=4, graduate_truncation=True):
+        """compress_mps step by step from Python (the first-generation driver; kept as the cross-check of tn_compress_mps)."""
         if ops.PASS1_WEIGHTED and ops.FUSED_SITE and max(self.D) >= 2 * PASS1_MIN_BOND:
             keep = (list(self.A), list(self.D), list(self._nfs))
             if not self.canonise_right_weighted():                   # bound not met: the plain pass on the kept input

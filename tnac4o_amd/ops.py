@@ -449,6 +449,103 @@ def gather_scale_rows(A2d, perm, w2, inverse=False):
     return out
 
 
+def argsort_desc(w):
+    """Stable descending argsort of a contiguous device vector (tn_argsort_desc; NaN first, ties by increasing index)."""
+    assert w.is_contiguous() and w.dim() == 1
+    out = torch.empty(w.numel(), dtype=torch.int64, device=w.device)
+    check(lib().tn_argsort_desc(w.data_ptr(), w.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+def weighted_sum(a, b):
+    """(a * b, its sum as a 1-element device tensor) with a fixed summation order (tn_weighted_sum)."""
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    w = torch.empty_like(a)
+    s = torch.empty(1, dtype=torch.float64, device=a.device)
+    check(lib().tn_weighted_sum(a.data_ptr(), b.data_ptr(), a.numel(), w.data_ptr(), s.data_ptr(), _stream()))
+    return w, s
+
+
+NATIVE_CHAIN = os.environ.get('TN_NATIVE_CHAIN', '1') != '0'     # compress_mps (and the absorption in front of it) as one library call
+_arena = {}
+
+
+def chain_arena(nbytes):
+    """The arena of tn_compress_mps for the current (device, stream): one persistent torch byte buffer, grown on demand."""
+    dev = _raw_device() if _raw_device is not None else torch.cuda.current_device()
+    key = (dev, _stream_handle())
+    buf = _arena.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _arena.pop(key, None)
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device='cuda')
+        _arena[key] = buf
+    return buf
+
+
+def compress_mps_native(sites, mpo_sites, hconj, Dmax, tolS, tolV, max_sweeps, graduate, weighted=True, structured=True, lazy=True):
+    """apply_mpo + compress_mps of one boundary MPS in one library call (tn_compress_mps).  sites: list of contiguous (Dl, p, Dr)
+    device tensors; mpo_sites: list of contiguous (ba, po, bb, pi) tensors / None per site, or None.  Returns a dict with the
+    compressed sites `A`, `overlap`, `discarded`, `S` (list of numpy arrays / None per bond), `nfs` (device pairs), `info`."""
+    L = len(sites)
+    for t in sites:
+        _need_gpu(t)
+        assert t.is_contiguous() and t.dim() == 3
+    sd = (C.c_int64 * (3 * L))(*[int(x) for t in sites for x in t.shape])
+    sp = (C.c_void_p * L)(*[t.data_ptr() for t in sites])
+    have_mpo = mpo_sites is not None and any(w is not None for w in mpo_sites)
+    md = mp = None
+    p_out = [int(t.shape[1]) for t in sites]
+    if have_mpo:
+        dims, ptrs = [], []
+        for n, w in enumerate(mpo_sites):
+            if w is None:
+                dims += [0, 0, 0, 0]
+                ptrs.append(None)
+            else:
+                _need_gpu(w)
+                assert w.is_contiguous() and w.dim() == 4
+                dims += [int(x) for x in w.shape]
+                ptrs.append(w.data_ptr())
+                p_out[n] = int(w.shape[3] if hconj else w.shape[1])
+        md = (C.c_int64 * (4 * L))(*dims)
+        mp = (C.c_void_p * L)(*ptrs)
+    Lb = lib()
+    need = int(Lb.tn_compress_mps_arena_bytes(L, sd, md, int(Dmax)))
+    arena = chain_arena(need)
+    dev = sites[0].device
+    cap = int(Dmax)
+    slot = max(cap * p * cap for p in p_out)
+    out = torch.empty((L, slot), dtype=torch.float64, device=dev)
+    od = (C.c_int64 * (3 * L))()
+    overlap = C.c_double(0.0)
+    disc = (C.c_double * (L + 1))()
+    pitch = max(cap, 1)
+    sch = (C.c_double * ((L + 1) * pitch))()
+    slen = (C.c_int64 * (L + 1))()
+    nfs_cap = 64 * L + 64
+    nfs = torch.empty((nfs_cap, 2), dtype=torch.float64, device=dev)
+    ncount = C.c_int64(0)
+    info = (C.c_double * 8)()
+    flags = (1 if weighted else 0) | (2 if structured else 0) | (4 if lazy else 0)
+    ab = arena.data_ptr()
+    off = (-ab) % 256
+    check(Lb.tn_compress_mps(L, sp, sd, mp, md, 1 if hconj else 0, int(Dmax), float(tolS), float(tolV), int(max_sweeps), 1 if graduate else 0,
+                             flags, out.data_ptr(), slot, od, C.byref(overlap), disc, sch, pitch, slen, nfs.data_ptr(), nfs_cap, C.byref(ncount),
+                             info, C.c_void_p(ab + off), arena.numel() - off, _stream()))
+    A = []
+    for n in range(L):
+        a, b, c = int(od[3 * n]), int(od[3 * n + 1]), int(od[3 * n + 2])
+        A.append(out[n, :a * b * c].view(a, b, c))
+    S = []
+    for i in range(L + 1):
+        k = int(slen[i])
+        S.append(None if k < 0 else np.array(sch[i * pitch:i * pitch + k], dtype=np.float64))
+    return dict(A=A, overlap=float(overlap.value), discarded=[float(x) for x in disc], S=S, nfs=[nfs[i] for i in range(int(ncount.value))],
+                info=dict(reveal_error_bound=float(info[0]), reveal_fallbacks=int(info[1]), weighted_used=bool(info[2]), arena_peak=int(info[3]), bonds_before=int(info[4]), bonds_after=int(info[5]),
+                          arena_bytes=int(arena.numel())))
+
+
 def rar(RL, A, RR):
     """RL . A . RR -> (c, s, c2) (tn_rar; MPS._mps_RAR)."""
     a, s_, a2 = A.shape

@@ -15,6 +15,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+_CHAIN_STREAMS = {}
+
+
 def run_concurrent(fns):
     """Run independent chains concurrently on one GPU: each callable gets its own host thread and its own HIP stream
     (one stream per rotation so that the latency-bound chains interleave on the device).  Returns the
@@ -23,17 +26,24 @@ def run_concurrent(fns):
     n = len(fns)
     if n == 1:
         return [fns[0]()]
-    # Fresh Stream objects (the next n of torch's 32-stream pool) and fresh threads on every call -- on purpose: reused
-    # streams (or a persistent thread pool) fell into a 1.5x slower regime under bench.py (2.45-2.53 vs 1.60-1.70 s/sweep)
-    # whenever an event had been recorded on the legacy default stream; this form held 1.70 s/sweep over 11 calls.
-    streams = [torch.cuda.Stream() for _ in range(n)]
+    # The chains own their streams for the life of the process: arenas, workspaces and torch's cached blocks are keyed by stream,
+    # so fresh streams on every call (the round-2 form: the next n of torch's 32-stream pool) rebuilt all of that per call and,
+    # every 8th call, wrapped the pool onto streams whose cached blocks had meanwhile been given back -- the 1.45x step every 8
+    # steps of the round-2 driver run.  TN_FRESH_STREAMS=1 restores that form for A/B runs.
+    import os
     from . import ops
+    if os.environ.get('TN_FRESH_STREAMS', '0') == '1':
+        streams = [torch.cuda.Stream() for _ in range(n)]
+    else:
+        key = (torch.cuda.current_device(), n)
+        streams = _CHAIN_STREAMS.get(key)
+        if streams is None:
+            streams = _CHAIN_STREAMS[key] = [torch.cuda.Stream() for _ in range(n)]
     # side streams (deferred Schmidt-value checks; tn_qr's look-ahead when enabled), taken right after the chains' own streams
     # so that the pairing with hardware queues is the same on every call (torch hands out pool streams round-robin, pool
     # stream k sits on hardware queue k mod 4): chain i's side stream is rotated by TN_AUX_ROT so that it does not share a
     # queue with its own chain
     if ops.LOOKAHEAD or ops.SCHMIDT_SIDE:
-        import os
         rot = int(os.environ.get('TN_AUX_ROT', '2'))
         side = [torch.cuda.Stream() for _ in range(n)]
         for i in range(n):

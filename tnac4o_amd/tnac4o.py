@@ -390,9 +390,8 @@ class tnac4o:
         self.rhoT[Ny] = mps.MPS(d=1, L=self.Nx, Dmax=1, initial='X')
         for ny in range(Ny - 1, -1, -1):
             psi = self.rhoT[ny + 1].copy()
-            psi.apply_mpo(self._row_mpo(ny), Hconj=True)
-            self.rhoT_overlap[ny] = psi.compress_mps(Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps,
-                                                     graduate_truncation=graduate_truncation)
+            self.rhoT_overlap[ny] = psi.apply_mpo_compress(self._row_mpo(ny), Hconj=True, Dmax=Dmax, tolS=tolS, tolV=tolV,
+                                                           max_sweeps=max_sweeps, graduate_truncation=graduate_truncation)
             self.rhoT_discarded[ny] = max(psi.discarded)
             self.rhoT[ny] = psi
 
@@ -405,9 +404,8 @@ class tnac4o:
         self.rhoB[0] = mps.MPS(d=1, L=self.Nx, Dmax=1, initial='X')
         for ny in range(Ny):
             psi = self.rhoB[ny].copy()
-            psi.apply_mpo(self._row_mpo(ny), Hconj=False)
-            self.rhoB_overlap[ny + 1] = psi.compress_mps(Dmax=Dmax, tolS=tolS, tolV=tolV, max_sweeps=max_sweeps,
-                                                         graduate_truncation=graduate_truncation)
+            self.rhoB_overlap[ny + 1] = psi.apply_mpo_compress(self._row_mpo(ny), Hconj=False, Dmax=Dmax, tolS=tolS, tolV=tolV,
+                                                               max_sweeps=max_sweeps, graduate_truncation=graduate_truncation)
             self.rhoB_discarded[ny + 1] = max(psi.discarded)
             self.rhoB[ny + 1] = psi
 
