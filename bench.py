@@ -26,6 +26,8 @@ import statistics
 import sys
 import time
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # one hardware queue per chain (see tnac4o_amd/__init__.py); before torch touches HIP
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, 'tests')):
     if p not in sys.path:

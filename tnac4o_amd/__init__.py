@@ -7,6 +7,14 @@
 Re-exports mirror the reference's tnac4o/__init__.py:1-2.  All compute runs in libtnpeps.so (hand-written HIP for
 gfx950); importing works without a GPU, running anything does not.
 """
+import os as _os
+
+# One hardware queue per chain: the 4 lattice rotations of an instance run as 4 chains on 4 HIP streams of one GPU, and ROCm
+# multiplexes all streams of a process (the default stream included) onto GPU_MAX_HW_QUEUES hardware queues, 4 unless told
+# otherwise -- two chains on one queue serialise (4.5 s per 4-rotation sweep step instead of 2.9 s, parallel.run_concurrent).
+# The runtime reads the variable when it initialises, i.e. at the first HIP call of the process; a value set by the user wins.
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 from .auxx import load_Jij, round_Jij, minus_Jij, Jij_f2p, energy_Jij, energy_RMF  # noqa: F401
 from . import mps  # noqa: F401
 from .tnac4o import tnac4o, load  # noqa: F401

@@ -223,9 +223,12 @@ private:
     std::map<int64_t, int64_t> free_, used_;
 };
 
-struct Block {
+struct Block {                  // owner of one arena block (never copied: the destructor gives the block back)
     Arena* ar;
     char* p;
+    Block(Arena* a, char* q) : ar(a), p(q) {}
+    Block(const Block&) = delete;
+    Block& operator=(const Block&) = delete;
     ~Block() { if (ar && p) ar->release(p); }
 };
 using Ref = std::shared_ptr<Block>;
@@ -286,7 +289,7 @@ public:
     int new_block(int64_t doubles, Ref& ref, double*& p, const char* what) {
         char* q = ar.alloc(doubles * 8);
         if (!q) return out_of_memory(what, doubles * 8);
-        ref = std::make_shared<Block>(Block{&ar, q});
+        ref = std::make_shared<Block>(&ar, q);
         p = (double*)q;
         return 0;
     }
@@ -309,7 +312,7 @@ public:
             int64_t got = want;
             if (!q) { q = ar.alloc(bytes); got = bytes; }
             if (!q) return out_of_memory("scratch", bytes);
-            s.blk = std::make_shared<Block>(Block{&ar, q});
+            s.blk = std::make_shared<Block>(&ar, q);
             s.p = q;
             s.bytes = got;
         }

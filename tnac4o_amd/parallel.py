@@ -26,24 +26,23 @@ def run_concurrent(fns):
     n = len(fns)
     if n == 1:
         return [fns[0]()]
-    # The chains own their streams for the life of the process: arenas, workspaces and torch's cached blocks are keyed by stream,
-    # so fresh streams on every call (the round-2 form: the next n of torch's 32-stream pool) rebuilt all of that per call and,
-    # every 8th call, wrapped the pool onto streams whose cached blocks had meanwhile been given back -- the 1.45x step every 8
-    # steps of the round-2 driver run.  TN_FRESH_STREAMS=1 restores that form for A/B runs.
-    import os
+    # The chains own their streams for the life of the process (arenas, workspaces and torch's cached blocks are keyed by stream).
+    # What decides whether 4 chains interleave (2.9 s per step) or pairs of them serialise (4.5 s) is the HARDWARE QUEUE behind each
+    # stream: ROCm multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4), the legacy default stream
+    # included, so with 4 chains + the default stream two chains end up on one queue (measured: 4 queues 4.48 s, 2 queues 4.65 s,
+    # 8 or 16 queues 2.90 s per step; the round-2 form with fresh pool streams on every call happened to dodge the collision until
+    # the pool wrapped, every 8th call).  tnac4o_amd/__init__.py therefore asks for 8 queues before the runtime starts.
     from . import ops
-    if os.environ.get('TN_FRESH_STREAMS', '0') == '1':
-        streams = [torch.cuda.Stream() for _ in range(n)]
-    else:
-        key = (torch.cuda.current_device(), n)
-        streams = _CHAIN_STREAMS.get(key)
-        if streams is None:
-            streams = _CHAIN_STREAMS[key] = [torch.cuda.Stream() for _ in range(n)]
+    key = (torch.cuda.current_device(), n)
+    streams = _CHAIN_STREAMS.get(key)
+    if streams is None:
+        streams = _CHAIN_STREAMS[key] = [torch.cuda.Stream() for _ in range(n)]
     # side streams (deferred Schmidt-value checks; tn_qr's look-ahead when enabled), taken right after the chains' own streams
     # so that the pairing with hardware queues is the same on every call (torch hands out pool streams round-robin, pool
     # stream k sits on hardware queue k mod 4): chain i's side stream is rotated by TN_AUX_ROT so that it does not share a
     # queue with its own chain
     if ops.LOOKAHEAD or ops.SCHMIDT_SIDE:
+        import os
         rot = int(os.environ.get('TN_AUX_ROT', '2'))
         side = [torch.cuda.Stream() for _ in range(n)]
         for i in range(n):
