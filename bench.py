@@ -38,17 +38,17 @@ import torch         # noqa: E402
 
 FAMILIES = ['gemm_kernel<128,128>', 'gemm_kernel<128,32>', 'gemm_kernel<32,128>', 'gemm_kernel<64,64>',
             'splitk_reduce_kernel', 'absorb_kernel', 'gram_partial_kernel', 'eig_small_kernel',
-            'rows_times_small_kernel', 'small_t_times_vecs_kernel', 'panel step (cq_gram / cq_pass / cq_post)',
+            'rows_times_small_kernel', 'small_t_times_vecs_kernel', 'panel step (cq_fused / cq_gram / cq_pass / cq_post)',
             'lu_reconstruct_kernel', 'qr_aux (diag_qr, assemble_R, init_Q, norms, copies)',
             'svd_aux (norms, init, gather)', 'misc (nfactor, scaling, builders)']
 COUNTERS = {'qr_nominal': 15, 'svd_nominal': 16, 'svd_stream': 17, 'svdvals_nominal': 18}   # counter-only families
 PHASES = ['gemm_var (attach / projector / environment GEMMs, scaling)', 'absorb', 'qr', 'svd_trunc', 'svdvals', 'mpo_build']
 MFMA_FAM = {0, 1, 2, 3}
 SERIAL_FAM = {7: ('eig_small_kernel', 'Jacobi step (32 plane rotations of a 64 x 64 Gram matrix in LDS)', 126),
-              10: ('panel step (cq_gram / cq_pass / cq_post)',
-                   'launch of the panel chain (6 per panel: Gram + 32-step one-wave Cholesky, up to 4 substitution passes of which '
-                   'those after convergence return at once, reflector products); each is a chain of 3-6 dependent memory round trips '
-                   'plus the serial tail of its last workgroup', 1)}
+              10: ('panel step (cq_fused / cq_gram / cq_pass / cq_post)',
+                   'launch of the panel step (ONE per panel of up to 4096 rows: Gram, 32-step one-wave Cholesky, substitution passes, '
+                   'Householder reconstruction and reflector products behind in-kernel barriers; six per taller panel, of which the '
+                   'passes after convergence return at once); each is a chain of dependent memory round trips and one-wave factorisations', 1)}
 PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X fp64 matrix peak (vendor figure quoted in SURVEY.md §7; not in the microarch guide)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 WORKLOADS = {'chimera2048': ('Ising', 16, 20260004, 3.0), 'chimera512': ('Ising', 8, 20260003, 3.0),
@@ -112,7 +112,7 @@ def cpu_model():
 
 
 def load_pmc():
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', name)))
             d['file'] = 'profiles/' + name
@@ -233,18 +233,14 @@ def main():
     mask_all = (1 << len(FAMILIES)) - 1
     if owner and rank == 0 and not args.no_profile and args.warmup > 0:
         torch.cuda.synchronize()
-        pst = (C.c_uint64 * 8)()
-        lib.tn_panel_stats(pst, 1)
+        from tnac4o_amd import ops as _ops
+        _ops.panel_stats(reset=True)
         t0 = time.perf_counter()
         solver._setup_rhoT(**kw)
         torch.cuda.synchronize()
         single_ms = 1e3 * (time.perf_counter() - t0)
-        lib.tn_panel_stats(pst, 0)
-        panel_stats = {'panels': int(pst[0]), 'substitution_passes': int(pst[1]), 'deferred_pivots': int(pst[2]),
-                       'refilled_columns': int(pst[3]), 'householder_fallbacks': int(pst[4]),
-                       'panels_with_3_or_more_passes': int(pst[5]), 'panels_with_4_or_more_passes': int(pst[6]),
-                       'panels_with_5_passes': int(pst[7]),
-                       'what': 'iterated Cholesky-QR panel step (csrc/cholqr.hip) over the un-instrumented single-chain sweep'}
+        panel_stats = _ops.panel_stats()
+        panel_stats['what'] = 'iterated Cholesky-QR panel step (csrc/cholqr.hip) over the un-instrumented single-chain sweep'
         lib.tn_profile_reset()
         lib.tn_profile_enable(mask_all)
         torch.cuda.synchronize()
@@ -266,6 +262,8 @@ def main():
         lib.tn_profile_reset()
         lib.tn_profile_sample(max(1, args.sample))
         lib.tn_profile_enable(dom_mask)
+        from tnac4o_amd import ops as _ops
+        _ops.panel_stats(reset=True)            # the passes the panel chain really applies during the timed steps (device counters)
     step_ms = []
     barrier()
     t0 = time.perf_counter()
@@ -276,11 +274,12 @@ def main():
         step_ms.append(1e3 * (time.perf_counter() - ts))
     barrier()
     dt = time.perf_counter() - t0
-    prof = None
+    prof, timed_panel = None, None
     if not args.no_profile:
         prof = profile_totals(lib)
         lib.tn_profile_enable(0)
         lib.tn_profile_sample(1)
+        timed_panel = _ops.panel_stats()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=parallel._comm_device(None))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -336,8 +335,23 @@ def main():
                                   'bond_dims_mid_row': [int(d) for d in solver.rhoT[n // 2].D]})
         if prof is not None:
             dom = max(range(len(prof)), key=lambda i: prof[i]['ms'])
-            d = prof[dom]
+            d = dict(prof[dom])
             avg_ms = d['ms'] / max(1, d['calls'])
+            executed = None
+            if dom == 10 and timed_panel is not None:
+                # The launches book what is known when they are enqueued (Gram, reflector products, the single-launch form's
+                # panel in / reflectors out); the substitution passes are data dependent, so the work they REALLY did comes from the
+                # device counters: 3 b flops per panel element and pass; 16 bytes per element and pass for the six-launch chain
+                # (read + write of the panel), none for the single-launch form (the tile stays in LDS).  A launch that finds its
+                # panel converged books nothing.  Counters cover every launch of the timed steps, the events every n-th: scale.
+                frac_sampled = 1.0 / max(1, args.sample)
+                pe6, pe1 = timed_panel['pass_elements_six_launch_chain'], timed_panel['pass_elements_single_launch']
+                d['flops'] += 3.0 * 32 * (pe6 + pe1) * frac_sampled
+                d['bytes'] += 16.0 * pe6 * frac_sampled
+                executed = {'panels': timed_panel['panels'], 'single_launch_panels': timed_panel['single_launch_panels'],
+                            'substitution_passes_applied': timed_panel['substitution_passes'],
+                            'pass_elements_six_launch_chain': pe6, 'pass_elements_single_launch': pe1,
+                            'note': 'bytes / flops of the substitution passes are booked from these device counters (executed work), not per launch'}
             if dom in MFMA_FAM:
                 ach = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
                 roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -345,6 +359,8 @@ def main():
             else:
                 ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9 if d['ms'] > 0 else 0.0
                 roof = {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS}
+            if executed is not None:
+                roof['executed_work'] = executed
             roof.update({'traffic': None, 'kernel': d['kernel'], 'launches_timed': d['calls'],
                          'launch_sampling': 'every %d-th launch of this family bracketed by HIP events on its stream, inside '
                                             'the timed region' % max(1, args.sample),
@@ -360,6 +376,9 @@ def main():
             fam = (pmc or {}).get('families', {}).get(d['kernel']) if pmc else None
             if fam:
                 roof['traffic'] = fam['traffic_bytes_per_launch']
+                roof['traffic_shape'] = fam.get('probe_shape', 'tn_qr 16384 x 1024 (tools/pmc_probe.py): per-launch mean of the probe, NOT of '
+                                                'the workload mix -- compare it with algorithmic_bytes_per_launch_same_probe below, not with '
+                                                'algorithmic_bytes_per_launch above')
                 roof['traffic_detail'] = {
                     'unit': 'bytes per launch', 'source': '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
                     'FETCH_SIZE x2 per the gfx950 correction) on tools/pmc_probe.py: the same kernels at the bulk shapes of '
@@ -409,13 +428,36 @@ def main():
         dist.destroy_process_group()
 
 
+def physical_cores():
+    """Physical cores of the box (sockets x cores per socket from /proc/cpuinfo; logical count as a fallback)."""
+    try:
+        phys = {}
+        pid = cid = None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('physical id'):
+                    pid = line.split(':')[1].strip()
+                elif line.startswith('core id'):
+                    cid = line.split(':')[1].strip()
+                elif not line.strip():
+                    if pid is not None and cid is not None:
+                        phys[(pid, cid)] = 1
+                    pid = cid = None
+        if phys:
+            return len(phys)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(n, args, solver, kw, single_ms):
-    """CPU oracle ("port" of the reference algorithm, numpy/scipy on OpenBLAS) on a bounded bulk sample of the same sweep:
-    the middle row's absorbed boundary MPS, first canonisation pass (attach GEMM, QR with the reference's gauge, nfactor;
-    reference mps.py:220-236) over the right edge and `cpu_rows` bulk sites, i.e. the shapes that make up ~40 % of a sweep
-    ((p Dr) x Dl = 16384 x 1024).  The same steps are timed on the GPU; the full-sweep CPU figure is a linear
-    extrapolation by that ratio (a full CPU sweep at L=2048 chi=64 takes the better part of an hour).  One bulk QR is also
-    timed with a single BLAS thread."""
+    """CPU oracle ("port" of the reference algorithm, numpy/scipy on OpenBLAS) on a bounded bulk sample of the same sweep: the
+    middle row's absorbed boundary MPS, first canonisation pass of compress_mps (attach GEMM, QR with the reference's gauge,
+    nfactor; reference mps.py:187, 220-236) over the right edge and `cpu_rows` bulk sites -- QR shapes up to (p Dr) x Dl = 16384 x
+    1024, what the reference spends 87 % of a sweep on.  Timed with 1 BLAS thread, one per physical core and one per logical core;
+    `value` is the FASTEST of them (`cores` = its thread count).  The GPU runs the SAME steps of the SAME algorithm on the same
+    tensors (`gpu_same_sample_ms`), the two results are compared (Schmidt spectrum of the centre matrix they end with), and the
+    first pass the product really runs on that row (the weighted rank-revealing form, all 16 sites) is timed next to it."""
     from oracle import mps_ref as mr
     from tnac4o_amd import mps
     try:
@@ -429,49 +471,75 @@ def cpu_baseline(n, args, solver, kw, single_ms):
     nsites = min(n, (n - first_bulk) + args.cpu_rows)
     sites = list(range(n - 1, n - 1 - nsites, -1))
     host = {s: psi.A[s].cpu().numpy() for s in sites}
-    o = mr.RefMPS(d=[int(a.shape[1]) for a in psi.A], L=n, Dmax=1, canonise=None)
-    o.A = [host.get(s) for s in range(n)]
-    o.D = list(psi.D)
-    o.C, o.pC = np.ones((1, 1)), n
-    t0 = time.perf_counter()
-    for s in sites:
-        o.attach_AC()
-        o.orth_right(s)
-    cpu_ms = 1e3 * (time.perf_counter() - t0)
+
+    def cpu_run():
+        o = mr.RefMPS(d=[int(a.shape[1]) for a in psi.A], L=n, Dmax=1, canonise=None)
+        o.A = [host[s].copy() if s in host else None for s in range(n)]
+        o.D = list(psi.D)
+        o.C, o.pC = np.ones((1, 1)), n
+        t0 = time.perf_counter()
+        for s in sites:
+            o.attach_AC()
+            o.orth_right(s)
+        return 1e3 * (time.perf_counter() - t0), o
+    phys, logical = physical_cores(), os.cpu_count() or 1
+    counts = [1] if threadpoolctl is None else sorted({1, phys, logical})
+    timings, best, spent = {}, None, 0.0
+    for nt in counts:
+        if spent > 45e3:                             # keep the CPU leg bounded
+            break
+        if threadpoolctl is not None:
+            with threadpoolctl.threadpool_limits(limits=nt):
+                ms, o = cpu_run()
+        else:
+            ms, o = cpu_run()
+        timings[str(nt)] = ms
+        spent += ms
+        if best is None or ms < best[0]:
+            best = (ms, nt, o)
+    cpu_ms, threads, o = best
     shapes = ['%dx%d' % (o.A[s].shape[1] * o.A[s].shape[2], host[s].shape[0]) for s in sites]
+    # the same steps on the GPU (plain pass, the reference's algorithm), from the same tensors
+    g = psi.copy()
+    g._nfs = []                                      # (the factors of this sample only, like the oracle's normC)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    psi.C = torch.ones((1, 1), dtype=torch.float64, device='cuda')
-    psi.pC = n
+    g.C = torch.ones((1, 1), dtype=torch.float64, device='cuda')
+    g.pC = n
     for s in sites:
-        psi.attach_AC()
-        psi.orth_right(s)
+        g.attach_AC()
+        g.orth_right(s)
     torch.cuda.synchronize()
     gpu_ms = 1e3 * (time.perf_counter() - t0)
-    threads = os.cpu_count()
-    if threadpoolctl is not None:
-        threads = max([p['num_threads'] for p in threadpoolctl.threadpool_info()] or [threads])
-    one = None
-    sb = max(sites, key=lambda s: host[s].size)      # the largest site of the sample: its input matrix with one BLAS thread
-    M1 = np.ascontiguousarray(host[sb].reshape(host[sb].shape[0], -1).T)
-    if threadpoolctl is not None:
-        with threadpoolctl.threadpool_limits(limits=1):
-            t0 = time.perf_counter()
-            mr.qr_pos(M1)
-            one = 1e3 * (time.perf_counter() - t0)
+    # parity of the two legs: the spectrum of the centre matrix (times the accumulated power-of-two factors) they end with
+    Sc = np.linalg.svd(o.C, compute_uv=False) * o.normC
+    Sg = np.linalg.svd(g.C.cpu().numpy(), compute_uv=False) * g.normC
+    k = min(len(Sc), len(Sg))
+    dev = float(np.max(np.abs(Sc[:k] - Sg[:k])) / Sc[0])
+    assert dev < 1e-12, 'cpu_baseline: GPU and CPU oracle disagree on the sample (max |dS| / S0 = %.2e)' % dev
+    # what the product runs on that row: the weighted rank-revealing first pass over all sites
+    w = psi.copy()
+    w._absorbed = getattr(psi, '_absorbed', None)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    mr.qr_pos(M1)
-    allc = 1e3 * (time.perf_counter() - t0)
+    ok = w.canonise_right_weighted()
+    torch.cuda.synchronize()
+    prod_ms = 1e3 * (time.perf_counter() - t0)
     ratio = cpu_ms / gpu_ms if gpu_ms > 0 else None
     return {'value': cpu_ms, 'unit': 'ms for the sample', 'cores': int(threads), 'kind': 'port', 'cpu_model': cpu_model(),
-            'sample': 'row %d of %d (bulk), first canonisation pass of compress_mps over sites %d..%d (attach GEMM + QR + nfactor; '
-                      'QR shapes %s), oracle/ numpy+scipy with %d BLAS threads; the same steps on the GPU: %.1f ms'
-                      % (ny, n, sites[0], sites[-1], ', '.join(shapes), threads, gpu_ms),
+            'physical_cores': phys, 'logical_cores': logical, 'ms_by_blas_threads': timings,
+            'sample': 'row %d of %d (bulk), first canonisation pass of compress_mps (reference algorithm: attach GEMM + QR + nfactor) over '
+                      'sites %d..%d, QR shapes %s; oracle/ numpy+scipy, fastest of the BLAS thread counts tried (%d threads)'
+                      % (ny, n, sites[0], sites[-1], ', '.join(shapes), threads),
             'gpu_same_sample_ms': gpu_ms, 'speedup_on_sample': ratio,
+            'parity_on_sample_max_dS_over_S0': dev,
+            'gpu_product_first_pass_whole_row_ms': prod_ms, 'gpu_product_first_pass_accepted': bool(ok),
+            'gpu_product_first_pass_note': 'the weighted rank-revealing first pass the product runs instead of the plain one, over all %d '
+                                           'sites of the same row (Gram recursion + pivoted early-exit QR)' % n,
             'full_sweep_cpu_ms_linear_extrapolation': (ratio * single_ms) if (ratio and single_ms) else None,
-            'extrapolation': 'single-chain GPU sweep latency x (CPU / GPU time on the sample); the sample is QR-dominated like '
-                             'the sweep (QR = 65 % of a sweep\'s kernel time), so this is an order-of-magnitude figure',
-            'bulk_qr_%dx%d_ms' % M1.shape: {'one_thread': one, 'all_threads': allc}}
+            'extrapolation': 'order of magnitude only: single-chain GPU sweep latency x (CPU / GPU time on the sample, same algorithm on '
+                             'both sides); the reference spends 87 % of a chi=64 sweep in these QR calls (SURVEY.md 3.1), the GPU sweep '
+                             'runs a cheaper first pass'}
 
 
 if __name__ == '__main__':

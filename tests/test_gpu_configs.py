@@ -91,13 +91,16 @@ def g6_reference_spread(rot, chi):
     g = load('g6_pn.npz')
     tag = 'L128_r%d_chi%d' % (rot, chi)
     spread = {}
-    for probe in ('qr', 'svd'):
+    for probe in ('qr', 'svd', 'svdin'):
         orig_qr, orig_svd = mr.qr_pos, scipy.linalg.svd
         if probe == 'qr':
             rng = np.random.default_rng(0)
             mr.qr_pos = lambda T: orig_qr(T * (1 + 1e-16 * rng.standard_normal(T.shape)))
-        else:
+        elif probe == 'svd':
             scipy.linalg.svd = lambda a, *args, **kw: orig_svd(a, *args, **dict(kw, lapack_driver='gesvd'))
+        else:               # every centre matrix perturbed by 1e-16 relative before its SVD (what another backward-stable SVD amounts to)
+            rng2 = np.random.default_rng(1)
+            scipy.linalg.svd = lambda a, *args, **kw: orig_svd(a * (1 + 1e-16 * rng2.standard_normal(np.shape(a))), *args, **kw)
         try:
             o = _oracle(rot)
             tr = []
@@ -116,10 +119,10 @@ def g6_reference_spread(rot, chi):
 def test_g6_marginals_hip_vs_reference_golden(rot, chi):
     """End to end (GPU sweep + GPU beam) against the `newprob` tables captured from the reference at 9-10 site-steps, incl.
     the rot=3 run whose tables contain negative entries.  Tolerance per table: 1e-10 relative or, in
-    absolute terms on the normalised table, 100x the movement of the reference algorithm's own tables under eps-level
-    probes (g6_reference_spread) with a floor of 1e-12.  The beam kernels themselves agree with the oracle to 3e-13 on a
-    common boundary MPS (previous test): what is left here is the conditioning of the truncated sweep (measured on the
-    MI355X: worst table 2.3e-10 absolute at chi=32, where the probes move the reference by 8e-12)."""
+    absolute terms on the normalised table, 10x the movement of the reference algorithm's own tables under eps-level
+    probes (g6_reference_spread: QR inputs, SVD inputs, SVD driver) with a floor of 1e-12.  The beam kernels themselves agree with
+    the oracle to 3e-13 on a common boundary MPS (previous test): what is left here is the conditioning of the truncated sweep.
+    The measured margins (largest |difference| / allowance per table) are printed."""
     g = load('g6_pn.npz')
     tag = 'L128_r%d_chi%d' % (rot, chi)
     trace = []
@@ -127,12 +130,19 @@ def test_g6_marginals_hip_vs_reference_golden(rot, chi):
     s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi, trace=trace)
     assert [t[2].shape[0] for t in trace] == list(g[tag + '_nbranch'])
     spread = g6_reference_spread(rot, chi)
+    worst = 0.0
     for k in g[tag + '_steps']:
         st = int(g[tag + '_stride%d' % k][0])
-        atol = max(1e-12, 100.0 * spread[int(k)])
-        np.testing.assert_allclose(trace[k][2][::st], g[tag + '_P%d' % k], rtol=1e-10, atol=atol)
-        np.testing.assert_allclose(trace[k][3][::st], g[tag + '_min%d' % k], rtol=1e-2, atol=atol)
-    assert s.negative_probability == pytest.approx(g[tag + '_neg'][0], rel=1e-2, abs=1e-13)
+        atol = max(1e-12, 10.0 * spread[int(k)])
+        want = g[tag + '_P%d' % k]
+        margin = float((np.abs(trace[k][2][::st] - want) / (atol + 1e-10 * np.abs(want))).max())
+        worst = max(worst, margin)
+        print('G6 %s step %d: max |dP| %.2e, probe spread %.2e, allowance used %.2f' % (tag, k, float(np.abs(trace[k][2][::st] - want).max()),
+                                                                                     spread[int(k)], margin))
+        np.testing.assert_allclose(trace[k][2][::st], want, rtol=1e-10, atol=atol)
+        np.testing.assert_allclose(trace[k][3][::st], g[tag + '_min%d' % k], rtol=1e-6, atol=atol)
+    print('G6 %s: worst margin %.2f of the allowance' % (tag, worst))
+    assert s.negative_probability == pytest.approx(g[tag + '_neg'][0], rel=1e-6, abs=1e-13)
 
 
 # ------------------------------------------------------------------------------------------------ K7 vs G4

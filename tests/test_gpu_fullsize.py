@@ -120,3 +120,78 @@ def test_rmf_d8_chi128_config5_shapes():
     s.search_ground_state(M=256, relative_P_cutoff=1e-10, Dmax=16)
     allst = np.array(list(itertools.product(range(4), repeat=9)), dtype=np.int64)
     assert float(s.energy[0]) == pytest.approx(float(energy_RMF(Js, allst).min()), abs=1e-9)
+
+
+# --------------------------------------------------------------------------- the headline size against the oracle
+def _oracle_row(inp_sites, mpo_sites, chi, perturb=None):
+    """One row step of the reference algorithm on the CPU oracle: apply_mpo(Hconj=True) + compress_mps from the given input MPS / MPO
+    (host arrays).  perturb: relative size of a random perturbation of every QR input (the eps probe of the oracle's own conditioning)."""
+    from oracle import mps_ref as mr
+    o = mr.RefMPS(d=[a.shape[1] for a in inp_sites], L=len(inp_sites), Dmax=1, canonise=None)
+    o.A = [np.array(a) for a in inp_sites]
+    o.D = [inp_sites[0].shape[0]] + [a.shape[2] for a in inp_sites]
+    M = mr.RefMPO(len(inp_sites))
+    for n, W in enumerate(mpo_sites):
+        M.set_direct(np.array(W), n)
+    orig = mr.qr_pos
+    if perturb:
+        rng = np.random.default_rng(0)
+        mr.qr_pos = lambda T: orig(T * (1 + perturb * rng.standard_normal(T.shape)))
+    try:
+        o.apply_mpo(M, Hconj=True)
+        ov = o.compress_mps(Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20, graduate_truncation=True)
+    finally:
+        mr.qr_pos = orig
+    return o, ov
+
+
+def test_headline_rows_hip_vs_oracle():
+    """BASELINE's headline size against the CPU oracle (reference tnac4o.py:1674-1695 at L = 2048, chi = 64, seed 20260004): rows 14
+    (absorbed bond 256, the first truncating row) and 13 (absorbed bond 1024: the bulk shape, 16384 x 1024 QRs and 1024 x 1024
+    centre matrices) of the bench's sweep, HIP (the production path: tn_compress_mps with the weighted rank-revealing first pass,
+    early-exit QR, block-Jacobi SVD) against oracle/ restating the reference's pass structure with LAPACK, both from the SAME input
+    MPS and MPO.  Fidelity of the compressed states >= 1 - 1e-12, overlaps to 1e-12, discarded weights to 1e-6 relative -- or, should
+    a row exceed that, to 3x the oracle's own movement under a 1e-16 perturbation of its QR inputs (printed)."""
+    import time
+    import tnac4o_amd
+    from tnac4o_amd import mps
+    from tnac4o_amd.auxx import synthetic_chimera
+    from oracle import mps_ref as mr
+    try:
+        import threadpoolctl
+        limit = threadpoolctl.threadpool_limits(limits=16)
+    except ImportError:
+        limit = None
+    n, chi = 16, 64
+    s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=synthetic_chimera(n, n, 20260004), beta=3.0)
+    kw = dict(Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20, graduate_truncation=True)
+    psi = mps.MPS(d=1, L=n, Dmax=1, initial='X')
+    try:
+        for ny in (15, 14, 13):
+            mpo = s._row_mpo(ny)
+            out = psi.copy()
+            ov = out.apply_mpo_compress(mpo, Hconj=True, **kw)
+            if ny in (14, 13):
+                inp = [a.cpu().numpy() for a in psi.A]
+                Ws = [w.cpu().numpy() for w in mpo.W]
+                t0 = time.perf_counter()
+                o, ov_ref = _oracle_row(inp, Ws, chi)
+                t_cpu = time.perf_counter() - t0
+                got = mr.RefMPS(d=[a.shape[1] for a in out.A], L=n, Dmax=1, canonise=None)
+                got.A = [a.cpu().numpy() for a in out.A]
+                fid = abs(mr.mps_dot(got, o)) / np.sqrt(mr.mps_dot(got, got) * mr.mps_dot(o, o))
+                dg, dr = max(out.discarded), max(o.discarded)
+                rel = abs(dg - dr) / max(dr, 1e-300)
+                print('row %d: absorbed bonds up to %d, oracle %.1f s; 1 - fidelity %.2e, |d overlap| %.2e, discarded %.6e vs %.6e (rel %.2e), D %s vs %s'
+                      % (ny, max(a.shape[0] for a in inp) * 16, t_cpu, 1.0 - fid, abs(ov - ov_ref), dg, dr, rel, out.D, o.D))
+                assert 1.0 - fid < 1e-12
+                assert abs(ov - ov_ref) < 1e-12
+                if not (rel < 1e-6 or abs(dg - dr) < 1e-14):
+                    o2, _ = _oracle_row(inp, Ws, chi, perturb=1e-16)
+                    spread = abs(max(o2.discarded) - dr)
+                    print('row %d: oracle eps-probe moves its discarded weight by %.3e (rel %.2e)' % (ny, spread, spread / dr))
+                    assert abs(dg - dr) <= 3.0 * spread
+            psi = out
+    finally:
+        if limit is not None:
+            limit.restore_original_limits() if hasattr(limit, 'restore_original_limits') else limit.unregister()

@@ -576,13 +576,19 @@ def test_weighted_first_pass_matches_plain_pass(L, chi):
     if L == 2048:
         assert sum(got for _, got in bonds) < 0.75 * sum(full for full, _ in bonds)   # the pass really shrinks the bonds
     np.testing.assert_allclose(np.array(a.rhoT_overlap, dtype=float), np.array(b.rhoT_overlap, dtype=float), rtol=0, atol=1e-12)
-    # discarded weights: 1e-6 relative, or 10x what the plain pass itself moves under the rounding-level change of its QR blocking
+    # discarded weights: 1e-6 relative, or 3x what the plain pass itself moves under the rounding-level change of its QR blocking
     # (deep rows of a chi=64 sweep amplify rounding: single rows move by tens of per cent between the two plain runs)
     da, da2, db = (np.array(x.rhoT_discarded, dtype=float) for x in (a, a2, b))
-    assert np.all(np.abs(db - da) <= 1e-14 + 1e-6 * da + 10.0 * np.abs(da2 - da)), (da, da2, db)
+    allow = 1e-14 + 1e-6 * da + 3.0 * np.abs(da2 - da)
+    print('discarded weights, weighted vs plain: largest |difference| / allowance = %.3f' % float((np.abs(db - da) / allow).max()))
+    assert np.all(np.abs(db - da) <= allow), (da, da2, db)
+    worst = 0.0
     for x, x2, y in zip(a.rhoT, a2.rhoT, b.rhoT):
         spread = 1.0 - fidelity(host_chain(x), host_chain(x2))
-        assert 1.0 - fidelity(host_chain(x), host_chain(y)) < 1e-13 + 10.0 * max(spread, 0.0)
+        got = 1.0 - fidelity(host_chain(x), host_chain(y))
+        worst = max(worst, got / (1e-13 + 3.0 * max(spread, 0.0)))
+        assert got < 1e-13 + 3.0 * max(spread, 0.0)
+    print('fidelity, weighted vs plain: largest (1 - F) / allowance = %.3f' % worst)
 
 
 @pytest.mark.gpu

@@ -161,9 +161,9 @@ int tn_panel_orth(const double* X, int64_t rs, int64_t cs, int64_t nrows, int b,
     if (state9_host && dev_host) return cholqr_debug_state(ST, ws, state9_host, dev_host);
     return 0;
 }
-int tn_panel_stats(uint64_t* out8_host, int reset) {
-    TN_CHECK_ARG(out8_host, "null output");
-    return cholqr_stats((unsigned long long*)out8_host, reset);
+int tn_panel_stats(uint64_t* out16_host, int reset) {
+    TN_CHECK_ARG(out16_host, "null output");
+    return cholqr_stats((unsigned long long*)out16_host, reset);
 }
 
 int tn_svd_trunc(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol, double* U,

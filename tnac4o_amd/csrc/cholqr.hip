@@ -137,14 +137,23 @@ __device__ __forceinline__ void cq_block_gram(const double* T, double* S, double
     for (int e = tid; e < CQ_PART; e += 256) cq_st(part + e, (S[e] + S[CQ_PART + e]) + (S[2 * CQ_PART + e] + S[3 * CQ_PART + e]));
 }
 
-// process-wide statistics (diagnostics): panels, passes applied, deferred pivots, refilled columns, Householder fallbacks
-__device__ unsigned long long cq_stats[8];
-// one thread, once per panel: two packed 64-bit adds instead of up to seven (each costs the last workgroup ~0.5 us)
-//   [0] = panels + (passes << 32),  [1] = deferred + (>= 3 passes << 32) + (>= 4 passes << 48),  [2] = refilled + (fallbacks << 32) (rare)
-__device__ __forceinline__ void cq_count(int passes, int ndefer, int nrefill, bool fallback) {
-    atomicAdd(&cq_stats[0], 1ull + ((unsigned long long)passes << 32));
-    atomicAdd(&cq_stats[1], (unsigned long long)ndefer + ((unsigned long long)(passes >= 3 ? 1 : 0) << 32) + ((unsigned long long)(passes >= 4 ? 1 : 0) << 48));
-    if (nrefill > 0 || fallback) atomicAdd(&cq_stats[2], (unsigned long long)nrefill + ((unsigned long long)(fallback ? 1 : 0) << 32));
+// process-wide diagnostic counters (tn_panel_stats), one 64-bit word each -- no packed sub-fields that could carry into each other:
+//   [0] panels  [1] substitution passes applied  [2] deferred pivots  [3] refilled columns  [4] Householder fallbacks
+//   [5] panels with >= 3 passes  [6] panels with >= 4 passes  [7] panel elements x passes applied by the six-launch chain (each such
+//   pass reads and writes the panel: 16 bytes per element)  [8] the same for the single-launch form (the tile stays in LDS: flops only)
+//   [9] panels handled by the single-launch form
+__device__ unsigned long long cq_stats[16];
+// one thread, once per panel; the adds do not return a value, so the wave does not wait for them
+__device__ __forceinline__ void cq_count(int passes, int ndefer, int nrefill, bool fallback, long long elems, bool single_launch = false) {
+    atomicAdd(&cq_stats[0], 1ull);
+    atomicAdd(&cq_stats[1], (unsigned long long)passes);
+    atomicAdd(&cq_stats[single_launch ? 8 : 7], (unsigned long long)passes * (unsigned long long)elems);
+    if (single_launch) atomicAdd(&cq_stats[9], 1ull);
+    if (ndefer > 0) atomicAdd(&cq_stats[2], (unsigned long long)ndefer);
+    if (nrefill > 0) atomicAdd(&cq_stats[3], (unsigned long long)nrefill);
+    if (fallback) atomicAdd(&cq_stats[4], 1ull);
+    if (passes >= 3) atomicAdd(&cq_stats[5], 1ull);
+    if (passes >= 4) atomicAdd(&cq_stats[6], 1ull);
 }
 
 // 256-thread sum through LDS (two barriers); red: >= 4 doubles
@@ -375,7 +384,7 @@ __device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, i
 // Gs: LDS 32 x 33, Rs: LDS 32 x 32 (16-byte aligned).  pass = number of passes applied to the panel whose Gram matrix this is.  Returns 1 when the caller
 // decision (0: factor again, 1: converged, 2: out of passes; all threads get the same value).
 __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int nblk, int b, int pass, CqState* stt, double* Rg, double* Gs,
-                                       double* Rs, int maxpass, int tid) {
+                                       double* Rs, int maxpass, int tid, long long elems) {
     __shared__ int s_dec;
     const int lane = tid & 63;
     // exponents of pass 0: block weights 4^(e_blk - emax); every wave finds emax itself (no barrier)
@@ -447,7 +456,7 @@ __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int 
                 stt->final_next = 0;
                 stt->dead = 0u;
                 if (dec == 2) stt->fallback = 1;
-                cq_count(pass, stt->ndefer_total, stt->nrefill_total, dec == 2);
+                cq_count(pass, stt->ndefer_total, stt->nrefill_total, dec == 2, elems);
             }
         } else {
             // ---- Cholesky, right-looking.  Lane k holds column k of the trailing matrix; row j of R (lane k: R[j][k]) goes
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__
     __threadfence();
     if (tid == 0) { stt->counter = 0; stt->done = 0; stt->pass = 0; stt->ndefer_total = 0; stt->nrefill_total = 0; stt->fallback = 0; }
     __syncthreads();
-    cq_tail(part, bexp, nblk, b, 0, stt, Rg, Gs, Rs, CQ_MAXPASS, tid);
+    cq_tail(part, bexp, nblk, b, 0, stt, Rg, Gs, Rs, CQ_MAXPASS, tid, (long long)nrows * b);
 }
 
 // X <- X R^-1 on the 256-row tile T (LDS), row tid; Rs (LDS, 16-byte aligned): R row-major (1024) + reciprocal diagonal (32).
@@ -736,12 +745,12 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
     if (fin) {
         if (tid == 0) {
             stt->done = 1; stt->final_next = 0; stt->dead = 0u;
-            cq_count(launch_no, stt->ndefer_total, stt->nrefill_total, false);
+            cq_count(launch_no, stt->ndefer_total, stt->nrefill_total, false, (long long)nrows * b);
         }
         __syncthreads();
     } else {
         __syncthreads();
-        dec = cq_tail(part, nullptr, nblk, b, launch_no, stt, Rg, Gs, Rs + 1056, maxpass, tid);
+        dec = cq_tail(part, nullptr, nblk, b, launch_no, stt, Rg, Gs, Rs + 1056, maxpass, tid, (long long)nrows * b);
     }
     CQ_CLK(7);
     if (launch_no <= 2) CQ_CLK_DUMP(12 * (launch_no - 1));
@@ -922,7 +931,7 @@ __device__ __forceinline__ bool cq_grid_barrier(int* counter, int target, int* s
 // (0 factor again, 1 converged, 2 out of passes), [1] final_next, [2] dead-column mask, [3] emax (pass 0).  Only `writer`
 // (workgroup 0) keeps the panel's state block and the statistics.  Ends with a barrier.
 __device__ __forceinline__ void cq_tail_fused(const double* part, const int* bexp, int nblk, int b, int pass, CqState* stt, bool writer, double* Gs,
-                                              double* Rf, int* s_out, int maxpass, int tid) {
+                                              double* Rf, int* s_out, int maxpass, int tid, long long elems) {
     const int lane = tid & 63;
     int emax = 0;
     if (bexp) {
@@ -992,7 +1001,7 @@ __device__ __forceinline__ void cq_tail_fused(const double* part, const int* bex
                     stt->final_next = 0;
                     stt->dead = 0u;
                     if (dec == 2) stt->fallback = 1;
-                    cq_count(pass, stt->ndefer_total, stt->nrefill_total, dec == 2);
+                    cq_count(pass, stt->ndefer_total, stt->nrefill_total, dec == 2, elems, true);
                 }
             }
         }
@@ -1085,7 +1094,7 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
         alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid);
         int dec = 0, tlast = 0;
         if (alive) {
-            cq_tail_fused(part, bexp, nblk, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid);
+            cq_tail_fused(part, bexp, nblk, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b);
             dec = s_out[0];
             const int emax = s_out[3];
             const double scl0 = (ex > -2000 && emax > -2000) ? ldexp(1.0, ex - emax) : 0.0;     // tile is 2^-ex X; the passes work on 2^-emax X
@@ -1110,11 +1119,11 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
                     dec = 1;
                     if (writer && tid == 0) {
                         stt->done = 1; stt->final_next = 0; stt->dead = 0u;
-                        cq_count(t, stt->ndefer_total, stt->nrefill_total, false);
+                        cq_count(t, stt->ndefer_total, stt->nrefill_total, false, (long long)nrows * b, true);
                     }
                     break;
                 }
-                cq_tail_fused(pt, nullptr, nblk, b, t, stt, writer, Gs, Rf, s_out, maxpass, tid);
+                cq_tail_fused(pt, nullptr, nblk, b, t, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b);
                 dec = s_out[0];
             }
         }
@@ -1235,7 +1244,9 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
         hipLaunchKernelGGL(cq_pass_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, t == 1 ? 1 : 0, t, part, stt,
                            Rg, seed + 0x9E3779B97F4A7C15ULL * (uint64_t)t, lu, Tp, maxpass);
         TN_CHECK_LAUNCH("cq_pass_kernel");
-        prof_end(st, PROF_TSQR, 3.0 * nrows * b * b, 16.0 * nrows * b);
+        // (the passes that really run are booked from the device counter cq_stats[7] by the caller of tn_panel_stats:
+        //  3 n b^2 flops and 16 n b bytes per applied pass; a launch that finds the panel converged moves nothing)
+        prof_end(st, PROF_TSQR, 0.0, 0.0);
     }
     prof_begin(st, PROF_TSQR);
     hipLaunchKernelGGL(cq_post_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, stt, lu, Tp, W, wrs, wcs, Wq);
@@ -1260,20 +1271,13 @@ int cholqr_debug_state(hipStream_t st, const void* ws, int* ints9, double* dev_h
     for (int i = 0; i <= CQ_MAXPASS + 1; ++i) dev_hist[i] = h.dev_hist[i];
     return 0;
 }
-int cholqr_stats(unsigned long long* out8, int reset) {
-    unsigned long long raw[8];
-    hipError_t e = hipMemcpyFromSymbol(raw, HIP_SYMBOL(cq_stats), 8 * sizeof(unsigned long long));
+int cholqr_stats(unsigned long long* out16, int reset) {
+    unsigned long long raw[16];
+    hipError_t e = hipMemcpyFromSymbol(raw, HIP_SYMBOL(cq_stats), 16 * sizeof(unsigned long long));
     if (e != hipSuccess) return hip_fail(e, "read panel statistics");
-    out8[0] = raw[0] & 0xffffffffull;             // panels
-    out8[1] = raw[0] >> 32;                       // substitution passes
-    out8[2] = raw[1] & 0xffffffffull;             // deferred pivots
-    out8[3] = raw[2] & 0xffffffffull;             // refilled columns
-    out8[4] = raw[2] >> 32;                       // Householder fallbacks
-    out8[5] = (raw[1] >> 32) & 0xffffull;         // panels with >= 3 passes
-    out8[6] = raw[1] >> 48;                       // panels with >= 4 passes
-    out8[7] = 0;
+    for (int i = 0; i < 16; ++i) out16[i] = raw[i];
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if ((e = hipMemcpyToSymbol(HIP_SYMBOL(cq_stats), z, sizeof(z))) != hipSuccess) return hip_fail(e, "reset panel statistics");
     }
     return 0;

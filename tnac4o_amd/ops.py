@@ -239,13 +239,15 @@ def panel_orth(X, method=0, state=False, out=None):
     return Y
 
 
+PANEL_STAT_KEYS = ('panels', 'substitution_passes', 'deferred_pivots', 'refilled_columns', 'householder_fallbacks', 'panels_with_3_or_more_passes',
+                   'panels_with_4_or_more_passes', 'pass_elements_six_launch_chain', 'pass_elements_single_launch', 'single_launch_panels')
+
+
 def panel_stats(reset=False):
-    """Process-wide counters of the Cholesky-QR panel step since the last reset (tn_panel_stats): dict."""
-    st = (C.c_uint64 * 8)()
+    """Process-wide diagnostic counters of the Cholesky-QR panel step since the last reset (tn_panel_stats): dict."""
+    st = (C.c_uint64 * 16)()
     check(lib().tn_panel_stats(st, 1 if reset else 0))
-    keys = ('panels', 'substitution_passes', 'deferred_pivots', 'refilled_columns', 'householder_fallbacks', 'panels_with_3_or_more_passes',
-            'panels_with_4_or_more_passes')
-    return {k: int(st[i]) for i, k in enumerate(keys)}
+    return {k: int(st[i]) for i, k in enumerate(PANEL_STAT_KEYS)}
 
 
 def qr(T, overwrite=False, nb=None):

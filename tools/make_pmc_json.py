@@ -51,7 +51,7 @@ alg = 0.0
 for p in range(32):
     rows = 16384 - 32 * p
     alg += (8.0 + 2 * 16.0 + 24.0) * rows * 32
-fam['panel step (cq_gram / cq_pass / cq_post)'] = {'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
+fam['panel step (cq_fused / cq_gram / cq_pass / cq_post)'] = {'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
                                    'traffic_bytes_per_launch': (fb + wb) / n, 'algorithmic_bytes_per_launch': alg / n,
                                    'traffic_over_algorithmic': (fb + wb) / alg}
 for name, pat in (('eig_small_kernel', 'eig_small_kernel'), ('absorb_kernel', 'absorb_mfma_kernel')):
