@@ -819,14 +819,425 @@ __global__ __launch_bounds__(256) void eig_small2_kernel(const double* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------ eig_small, third form
+// The pipelined kernel above is bound by the instruction streams of its single waves (a wave issues one fp64 instruction per 4
+// cycles: 128 for the update of a quarter of G, 128 for J, ~70 dependent ones for the rotation parameters), not by its barrier.
+// Here the workgroup has 8 waves: wave 0 decides the next step's rotations, wave 3 turns its register rows of J, and FIVE waves
+// (1, 2, 4, 5, 6) update G over the 2 x 2 blocks of the upper triangle only (528 instead of 1024 for a 64 x 64 matrix), writing
+// every block and its mirror image, so that G stays exactly symmetric and a thread has two blocks per step instead of eight.
+template <int NB>
+__global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restrict__ part, int nchunk, int nvec, int mode,
+                                                         int max_sweeps, double dead_thresh,
+                                                         double* __restrict__ out, int* __restrict__ dead,
+                                                         int* __restrict__ nrot_out, double* __restrict__ maxoff_out,
+                                                         double relevant2) {
+    constexpr int P = NB + 1;
+    __shared__ double Gb[2][NB * P];
+    __shared__ double J[NB * P];
+    __shared__ double dsc[NB];
+    __shared__ int cnt, total;
+    __shared__ int stepflag[2];
+    __shared__ double red[512];
+    constexpr int NT_ = 512;
+    const int tid = threadIdx.x, grp = blockIdx.x;
+    const double* pg = part + (int64_t)grp * nchunk * nvec * nvec;
+    double* G = Gb[0];
+    {
+        constexpr int EPT = NB * NB / NT_;
+        double acc[EPT];
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) acc[t] = 0.0;
+        for (int c = 0; c < nchunk; c += 2) {
+            double v0[EPT], v1[EPT];
+            const bool two = (c + 1 < nchunk);
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) {
+                const int e = tid + NT_ * t, i = e / NB, j = e % NB;
+                const bool in = (i < nvec && j < nvec);
+                const int64_t o = (int64_t)c * nvec * nvec + i * nvec + j;
+                v0[t] = in ? pg[o] : 0.0;
+                v1[t] = (in && two) ? pg[o + (int64_t)nvec * nvec] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) acc[t] = (acc[t] + v0[t]) + v1[t];
+        }
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            const int e = tid + NT_ * t, i = e / NB, j = e % NB;
+            const bool in = (i < nvec && j < nvec);
+            G[i * P + j] = in ? acc[t] : (i == j ? 1.0 : 0.0);
+            J[i * P + j] = (i == j) ? 1.0 : 0.0;
+        }
+    }
+    if (tid == 0) total = 0;
+    __syncthreads();
+    if (mode != 2) {
+        if (tid < NB) {
+            const double gii = G[tid * P + tid];
+            const bool ok = (gii > dead_thresh) && (gii < 1.7e308);
+            dsc[tid] = ok ? sqrt(gii) : 1.0;
+            if (tid < nvec && dead) dead[grp * nvec + tid] = ok ? 0 : 1;
+            if (!ok) dsc[tid] = 0.0;
+        }
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += NT_) {
+            const int i = e / NB, j = e % NB;
+            const double di = dsc[i], dj = dsc[j];
+            double g;
+            if (di == 0.0 || dj == 0.0) g = (i == j) ? 1.0 : 0.0;
+            else g = (i == j) ? 1.0 : G[i * P + j] * fast_rcp(di * dj);
+            G[i * P + j] = g;
+        }
+        __syncthreads();
+    }
+    {
+        __shared__ double rdg[NB];
+        if (tid < NB) {
+            const double gii = fabs(G[tid * P + tid]);
+            rdg[tid] = (gii > relevant2 && tid < nvec) ? fast_rcp(gii) : 0.0;
+        }
+        __syncthreads();
+        double m = 0.0;
+#pragma unroll
+        for (int t = 0; t < NB * NB / NT_; ++t) {
+            const int e = tid + NT_ * t, i = e / NB, j = e % NB;
+            const double g = G[i * P + j];
+            const double r2 = (i < j) ? g * g * rdg[i] * rdg[j] : 0.0;
+            m = r2 > m ? r2 : m;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+            const double mm = fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
+            red[0] = sqrt(mm);
+            if (maxoff_out) maxoff_out[grp] = red[0];
+        }
+        __syncthreads();
+    }
+    const bool need = (mode != 1) && (nvec >= 2) && (red[0] > 8.881784197001252e-16);
+    int cur = 0;
+    if (need) {
+        constexpr int HP = NB / 2;
+        constexpr int M = NB - 1;                          // steps per sweep
+        constexpr int NBLK = HP * (HP + 1) / 2;            // 2 x 2 blocks (a <= b): G stays exactly symmetric, half the arithmetic
+        constexpr int GT = 320;                            // threads of the five updating waves (1, 2, 4, 5, 6)
+        constexpr int UB = (NBLK + GT - 1) / GT;           // blocks per updating thread
+        __shared__ unsigned char blk_a[NBLK], blk_b[NBLK];
+        for (int e = tid; e < NBLK; e += NT_) {            // block list: e -> (a, b), a <= b, row by row
+            int a = 0, rem = e;
+            while (rem >= HP - a) { rem -= HP - a; ++a; }
+            blk_a[e] = (unsigned char)a;
+            blk_b[e] = (unsigned char)(a + rem);
+        }
+        __shared__ __attribute__((aligned(16))) double cs2[2][HP * 2];
+        __shared__ __attribute__((aligned(16))) double csj[2][HP * 2];
+        const double tol = 8.881784197001252e-16;          // 2^-50
+        auto slot_pair = [](int s, int a, int& p, int& q) {
+            if (a == 0) { p = NB - 1; q = s; }
+            else { p = s + a; p -= (p >= M) ? M : 0; q = s - a; q += (q < 0) ? M : 0; }
+            if (p > q) { const int t = p; p = q; q = t; }
+        };
+        // slot of index i in step s, and whether i is the larger member of its pair
+        auto slot_of = [&](int s, int i, int& a, int& hi) {
+            if (i == NB - 1 || i == s) a = 0;
+            else { int d = i - s; d += (d < 0) ? M : 0; a = (d <= HP - 1) ? d : M - d; }
+            int p, q;
+            slot_pair(s, a, p, q);
+            hi = (i == q) ? 1 : 0;
+        };
+        // rotation of pair (p < q) from g_pp, g_qq, g_pq (the smaller-angle rotation, as in eig_small_kernel)
+        auto decide = [&](double gpp, double gqq, double gpq, double& c, double& sn) -> bool {
+            c = 1.0; sn = 0.0;
+            const double g2 = gpq * gpq;
+            if (g2 > tol * tol * fabs(gpp * gqq)) {
+                const double d = gqq - gpp;
+                const double rh = rsqrt2n(d * d + 4.0 * g2);
+                const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+                const double rcv = rsqrt2n(c2);
+                const double sabs = fabs(gpq) * rh * rcv;
+                if (sabs <= 1.0 && c2 <= 1.0000000000000002) {
+                    c = c2 * rcv;
+                    sn = ((d >= 0.0) == (gpq >= 0.0)) ? sabs : -sabs;
+                    return true;
+                }
+            }
+            return false;
+        };
+        // wave 0, lane a < HP: parameters of step s into buffer `pb` (the buffers alternate from step to step ACROSS sweeps: a sweep
+        // has an odd number of steps, so the parity of s itself would collide at the sweep boundary)
+        auto publish = [&](int pb, int s, int a, int p, double c, double sn, bool rot) {
+            *reinterpret_cast<double2*>(&cs2[pb][2 * a]) = make_double2(c, sn);
+            int up = s + a; up -= (up >= M) ? M : 0;
+            const bool flipped = (a > 0) && (up != p);
+            *reinterpret_cast<double2*>(&csj[pb][2 * a]) = make_double2(c, flipped ? -sn : sn);
+            const unsigned long long any = __ballot(rot);
+            if (a == 0) stepflag[pb] = (any != 0ull) ? 1 : 0;
+        };
+        const int wave_ = tid >> 6, lane_ = tid & 63;
+        const int wave_g = (wave_ == 1) ? 0 : (wave_ == 2) ? 1 : (wave_ == 4) ? 2 : (wave_ == 5) ? 3 : (wave_ == 6) ? 4 : -1;
+        const bool jwave = (wave_ == 3);
+        double jr[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) jr[k] = (k == tid - 192) ? 1.0 : 0.0;
+        constexpr int FU = (NB == 64) ? 7 : 1;
+        static_assert(M % FU == 0, "group length must divide the sweep");
+        auto apply_j = [&](int pb, auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int CH = (HP >= 16) ? 16 : HP;       // parameters fetched 16 pairs at a time (two waves per SIMD: 256 registers each)
+#pragma unroll
+            for (int a0 = 0; a0 < HP; a0 += CH) {
+                double2 r[CH];
+#pragma unroll
+                for (int a = 0; a < CH; ++a) r[a] = *reinterpret_cast<const double2*>(&csj[pb][2 * (a0 + a)]);
+#pragma unroll
+                for (int a = 0; a < CH; ++a) {
+                    const int aa = a0 + a;
+                    const int px = (aa == 0) ? u : (u + aa) % M, py = (aa == 0) ? NB - 1 : (u - aa + M) % M;
+                    const double x = jr[px], y = jr[py];
+                    jr[px] = r[a].x * x - r[a].y * y;
+                    jr[py] = r[a].y * x + r[a].x * y;
+                }
+            }
+        };
+        auto advance_frame = [&]() {
+            double tmp[FU];
+#pragma unroll
+            for (int f = 0; f < FU; ++f) tmp[f] = jr[f];
+#pragma unroll
+            for (int f = 0; f < NB - 1 - FU; ++f) jr[f] = jr[f + FU];
+#pragma unroll
+            for (int f = 0; f < FU; ++f) jr[NB - 1 - FU + f] = tmp[f];
+        };
+        int mine = 0;                                      // (wave 0) rotations decided for the sweep in progress
+        int mine_next = 0;                                 // ... for the next sweep (the look-ahead of a sweep's last step)
+        // parameters of step 0 straight from G
+        if (tid < 64) {
+            bool rot = false;
+            double c = 1.0, sn = 0.0;
+            int p = 0, q = 0;
+            if (tid < HP) {
+                slot_pair(0, tid, p, q);
+                rot = decide(G[p * P + p], G[q * P + q], G[p * P + q], c, sn);
+                if (rot) ++mine;
+            }
+            if (tid < HP) publish(0, 0, tid, p, c, sn, rot);
+            else (void)__ballot(false);
+        }
+        __syncthreads();
+        int par = 0;                                       // parameter buffer of the step in progress
+        // one step of the tournament: phase of step s (u = s mod FU compile-time for the register frame of J)
+        auto step = [&](int s, auto uc) -> void {
+            constexpr int u = decltype(uc)::value;
+            const int flag = stepflag[par];                 // uniform
+            const double* Gc = Gb[cur];
+            double* Gn = Gb[cur ^ 1];
+            if (tid < 64) {
+                // ---- wave 0: rotations of step s+1 from G[cur] and the rotations of step s
+                const int s1 = (s + 1 == M) ? 0 : s + 1;
+                bool rot = false;
+                double c = 1.0, sn = 0.0;
+                int p = 0, q = 0;
+                if (tid < HP) {
+                    slot_pair(s1, tid, p, q);
+                    double gpp, gqq, gpq;
+                    if (flag) {
+                        int ap, hp_, aq, hq_;
+                        slot_of(s, p, ap, hp_);
+                        slot_of(s, q, aq, hq_);
+                        int pp, qp, pq, qq;
+                        slot_pair(s, ap, pp, qp);           // pair holding p in step s
+                        slot_pair(s, aq, pq, qq);           // pair holding q in step s
+                        const double2 rp = *reinterpret_cast<const double2*>(&cs2[par][2 * ap]);
+                        const double2 rq = *reinterpret_cast<const double2*>(&cs2[par][2 * aq]);
+                        // block (ap, ap) -> g_pp;  block (aq, aq) -> g_qq;  block (ap, aq) -> g_pq
+                        const double a00 = Gc[pp * P + pp], a01 = Gc[pp * P + qp], a10 = Gc[qp * P + pp], a11 = Gc[qp * P + qp];
+                        const double b00 = Gc[pq * P + pq], b01 = Gc[pq * P + qq], b10 = Gc[qq * P + pq], b11 = Gc[qq * P + qq];
+                        const double x00 = Gc[pp * P + pq], x01 = Gc[pp * P + qq], x10 = Gc[qp * P + pq], x11 = Gc[qp * P + qq];
+                        {
+                            const double t0 = hp_ ? rot_q(rp.x, rp.y, a00, a10) : rot_p(rp.x, rp.y, a00, a10);
+                            const double t1 = hp_ ? rot_q(rp.x, rp.y, a01, a11) : rot_p(rp.x, rp.y, a01, a11);
+                            gpp = hp_ ? rot_q(rp.x, rp.y, t0, t1) : rot_p(rp.x, rp.y, t0, t1);
+                        }
+                        {
+                            const double t0 = hq_ ? rot_q(rq.x, rq.y, b00, b10) : rot_p(rq.x, rq.y, b00, b10);
+                            const double t1 = hq_ ? rot_q(rq.x, rq.y, b01, b11) : rot_p(rq.x, rq.y, b01, b11);
+                            gqq = hq_ ? rot_q(rq.x, rq.y, t0, t1) : rot_p(rq.x, rq.y, t0, t1);
+                        }
+                        if (ap <= aq) {     // block (ap, aq): rows of p's pair, columns of q's pair, output (hp_, hq_)
+                            const double t0 = hp_ ? rot_q(rp.x, rp.y, x00, x10) : rot_p(rp.x, rp.y, x00, x10);
+                            const double t1 = hp_ ? rot_q(rp.x, rp.y, x01, x11) : rot_p(rp.x, rp.y, x01, x11);
+                            gpq = hq_ ? rot_q(rq.x, rq.y, t0, t1) : rot_p(rq.x, rq.y, t0, t1);
+                        } else {            // the update computes block (aq, ap) and mirrors it: rows of q's pair, columns of p's pair
+                            // (its entries G[pq][pp], G[pq][qp], G[qq][pp], G[qq][qp] equal x00, x10, x01, x11: G is exactly symmetric)
+                            const double t0 = hq_ ? rot_q(rq.x, rq.y, x00, x01) : rot_p(rq.x, rq.y, x00, x01);
+                            const double t1 = hq_ ? rot_q(rq.x, rq.y, x10, x11) : rot_p(rq.x, rq.y, x10, x11);
+                            gpq = hp_ ? rot_q(rp.x, rp.y, t0, t1) : rot_p(rp.x, rp.y, t0, t1);
+                        }
+                    } else {
+                        gpp = Gc[p * P + p]; gqq = Gc[q * P + q]; gpq = Gc[p * P + q];
+                    }
+                    rot = decide(gpp, gqq, gpq, c, sn);
+                    if (rot) { if (s + 1 == M) ++mine_next; else ++mine; }
+                }
+                if (tid < HP) publish(par ^ 1, s1, tid, p, c, sn, rot);
+                else (void)__ballot(false);
+            } else if (jwave) {
+                if (flag) apply_j(par, uc);
+                if constexpr (u == FU - 1) advance_frame();
+            } else if (flag && wave_g >= 0) {
+                // ---- waves 1, 2, 4, 5, 6: G[nxt] <- R^T G[cur] R over the blocks (a <= b), each written to both triangles
+                int pa[UB], qa[UB], pb[UB], qb[UB];
+                double2 ra[UB], rb[UB];
+                double g00[UB], g01[UB], g10[UB], g11[UB];
+                bool on[UB];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    const int e = wave_g * 64 + lane_ + GT * k;
+                    on[k] = e < NBLK;
+                    const int a = on[k] ? blk_a[e] : 0, b = on[k] ? blk_b[e] : 0;
+                    slot_pair(s, a, pa[k], qa[k]);
+                    slot_pair(s, b, pb[k], qb[k]);
+                    ra[k] = *reinterpret_cast<const double2*>(&cs2[par][2 * a]);
+                    rb[k] = *reinterpret_cast<const double2*>(&cs2[par][2 * b]);
+                    g00[k] = Gc[pa[k] * P + pb[k]]; g01[k] = Gc[pa[k] * P + qb[k]];
+                    g10[k] = Gc[qa[k] * P + pb[k]]; g11[k] = Gc[qa[k] * P + qb[k]];
+                }
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    if (!on[k]) continue;
+                    const double t00 = rot_p(ra[k].x, ra[k].y, g00[k], g10[k]), t01 = rot_p(ra[k].x, ra[k].y, g01[k], g11[k]);
+                    const double t10 = rot_q(ra[k].x, ra[k].y, g00[k], g10[k]), t11 = rot_q(ra[k].x, ra[k].y, g01[k], g11[k]);
+                    const double o00 = rot_p(rb[k].x, rb[k].y, t00, t01), o01 = rot_q(rb[k].x, rb[k].y, t00, t01);
+                    const double o10 = rot_p(rb[k].x, rb[k].y, t10, t11), o11 = rot_q(rb[k].x, rb[k].y, t10, t11);
+                    if (pa[k] == pb[k]) {                  // diagonal block: (p, q) and (q, p) both take o01
+                        Gn[pa[k] * P + pa[k]] = o00; Gn[pa[k] * P + qa[k]] = o01;
+                        Gn[qa[k] * P + pa[k]] = o01; Gn[qa[k] * P + qa[k]] = o11;
+                    } else {
+                        Gn[pa[k] * P + pb[k]] = o00; Gn[pb[k] * P + pa[k]] = o00;
+                        Gn[pa[k] * P + qb[k]] = o01; Gn[qb[k] * P + pa[k]] = o01;
+                        Gn[qa[k] * P + pb[k]] = o10; Gn[pb[k] * P + qa[k]] = o10;
+                        Gn[qa[k] * P + qb[k]] = o11; Gn[qb[k] * P + qa[k]] = o11;
+                    }
+                }
+            }
+            __syncthreads();
+            cur ^= flag;
+            par ^= 1;
+        };
+        for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+            if (tid == 0) cnt = 0;
+            for (int s0 = 0; s0 < M; s0 += FU) {
+                if constexpr (FU == 7) {
+                    step(s0 + 0, std::integral_constant<int, 0>{});
+                    step(s0 + 1, std::integral_constant<int, 1>{});
+                    step(s0 + 2, std::integral_constant<int, 2>{});
+                    step(s0 + 3, std::integral_constant<int, 3>{});
+                    step(s0 + 4, std::integral_constant<int, 4>{});
+                    step(s0 + 5, std::integral_constant<int, 5>{});
+                    step(s0 + 6, std::integral_constant<int, 6>{});
+                } else {
+                    step(s0, std::integral_constant<int, 0>{});
+                }
+            }
+            if (mine) atomicAdd(&cnt, mine);
+            __syncthreads();
+            if (tid == 0) total += cnt;
+            const int done = (cnt == 0);
+            __syncthreads();
+            mine = mine_next;
+            mine_next = 0;
+            if (done) break;
+        }
+        if (jwave && tid - 192 < NB) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) J[(tid - 192) * P + k] = jr[k];
+        }
+        __syncthreads();
+    }
+    double* Gf = Gb[cur];                                  // the rotated Gram matrix
+    double* Gs = Gb[cur ^ 1];                              // scratch for the Newton-Schulz step
+    if (tid == 0 && nrot_out) nrot_out[grp] = total;
+    if (mode != 1 && total > 0) {
+        typedef double d4e __attribute__((ext_vector_type(4)));
+        constexpr int NT = NB / 16, TPW = NT * NT / 4;
+        const bool mm = tid < 256;                            // the two products run on waves 0-3
+        const int lane = tid & 63, wave = (tid >> 6) & 3, li = lane & 15, lk = lane >> 4;
+        const int ti = (NB == 64) ? wave : (wave >> 1), tj0 = (NB == 64) ? 0 : (wave & 1);
+        d4e acc[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = d4e{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {                   // S = J^T J
+            const int k = ks * 4 + lk;
+            const double fa = J[k * P + ti * 16 + li];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, J[k * P + (tj0 + t) * 16 + li], acc[t], 0, 0, 0);
+        }
+        if (mm) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Gs[(ti * 16 + lk + 4 * r) * P + (tj0 + t) * 16 + li] = acc[t][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = d4e{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {                   // N = J S
+            const int k = ks * 4 + lk;
+            const double fa = J[(ti * 16 + li) * P + k];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, Gs[k * P + (tj0 + t) * 16 + li], acc[t], 0, 0, 0);
+        }
+        double nv[TPW][4];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                nv[t][r] = 1.5 * J[(ti * 16 + lk + 4 * r) * P + (tj0 + t) * 16 + li] - 0.5 * acc[t][r];
+        __syncthreads();
+        if (mm) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) J[(ti * 16 + lk + 4 * r) * P + (tj0 + t) * 16 + li] = nv[t][r];
+        }
+        __syncthreads();
+    }
+    (void)Gf;
+    double* o = out + (int64_t)grp * nvec * nvec;
+    for (int e = tid; e < nvec * nvec; e += NT_) {
+        const int i = e / nvec, j = e % nvec;
+        double v = J[i * P + j];
+        if (mode != 2) {
+            const double di = dsc[i];
+            v = (di == 0.0) ? 0.0 : v / di;
+            if (dsc[j] == 0.0) v = 0.0;
+        }
+        o[e] = v;
+    }
+}
+
 int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngroups, int mode, int max_sweeps,
               double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2) {
     TN_CHECK_ARG(nvec >= 1 && nvec <= NBMAX, "nvec out of range");
     if (ngroups <= 0) return 0;
     prof_begin(st, PROF_EIG);
     // TN_EIG_PIPELINED=0 selects the first-generation kernel (two barriers per Jacobi step) for A/B measurements
-    static const bool pipelined = [] { const char* e = getenv("TN_EIG_PIPELINED"); return !(e && e[0] == '0'); }();
-    if (pipelined) {
+    static const int gen = [] { const char* e = getenv("TN_EIG_PIPELINED"); return e ? atoi(e) : 2; }();      // 0, 1 (256 threads), 2 (512 threads)
+    const bool pipelined = gen == 1;
+    if (gen >= 2) {
+        if (nvec <= 32)
+            hipLaunchKernelGGL((eig_small3_kernel<32>), dim3(ngroups), dim3(512), 0, st, part, nchunk, nvec, mode, max_sweeps,
+                               dead_thresh, out, dead, nrot, maxoff, relevant2);
+        else
+            hipLaunchKernelGGL((eig_small3_kernel<64>), dim3(ngroups), dim3(512), 0, st, part, nchunk, nvec, mode, max_sweeps,
+                               dead_thresh, out, dead, nrot, maxoff, relevant2);
+    } else if (pipelined) {
         if (nvec <= 32)
             hipLaunchKernelGGL((eig_small2_kernel<32>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,
                                dead_thresh, out, dead, nrot, maxoff, relevant2);
