@@ -830,7 +830,7 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
                                                          int max_sweeps, double dead_thresh,
                                                          double* __restrict__ out, int* __restrict__ dead,
                                                          int* __restrict__ nrot_out, double* __restrict__ maxoff_out,
-                                                         double relevant2) {
+                                                         double relevant2, int dbg) {
     constexpr int P = NB + 1;
     __shared__ double Gb[2][NB * P];
     __shared__ double J[NB * P];
@@ -1042,7 +1042,8 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
                 if (tid < HP) {
                     slot_pair(s1, tid, p, q);
                     double gpp, gqq, gpq;
-                    if (flag) {
+                    if (dbg & 4) { gpp = 1.0; gqq = 1.0; gpq = 0.0; }
+                    else if (flag) {
                         int ap, hp_, aq, hq_;
                         slot_of(s, p, ap, hp_);
                         slot_of(s, q, aq, hq_);
@@ -1079,14 +1080,15 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
                         gpp = Gc[p * P + p]; gqq = Gc[q * P + q]; gpq = Gc[p * P + q];
                     }
                     rot = decide(gpp, gqq, gpq, c, sn);
+                    if (dbg) rot = true;                   // diagnostics: keep every step "rotating"
                     if (rot) { if (s + 1 == M) ++mine_next; else ++mine; }
                 }
                 if (tid < HP) publish(par ^ 1, s1, tid, p, c, sn, rot);
                 else (void)__ballot(false);
             } else if (jwave) {
-                if (flag) apply_j(par, uc);
+                if (flag && !(dbg & 1)) apply_j(par, uc);
                 if constexpr (u == FU - 1) advance_frame();
-            } else if (flag && wave_g >= 0) {
+            } else if (flag && wave_g >= 0 && !(dbg & 2)) {
                 // ---- waves 1, 2, 4, 5, 6: G[nxt] <- R^T G[cur] R over the blocks (a <= b), each written to both triangles
                 int pa[UB], qa[UB], pb[UB], qb[UB];
                 double2 ra[UB], rb[UB];
@@ -1230,13 +1232,14 @@ int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngro
     // TN_EIG_PIPELINED=0 selects the first-generation kernel (two barriers per Jacobi step) for A/B measurements
     static const int gen = [] { const char* e = getenv("TN_EIG_PIPELINED"); return e ? atoi(e) : 2; }();      // 0, 1 (256 threads), 2 (512 threads)
     const bool pipelined = gen == 1;
+    static const int dbg = [] { const char* e = getenv("TN_EIG_DBG"); return e ? atoi(e) : 0; }();      // timing diagnostics of the third form
     if (gen >= 2) {
         if (nvec <= 32)
             hipLaunchKernelGGL((eig_small3_kernel<32>), dim3(ngroups), dim3(512), 0, st, part, nchunk, nvec, mode, max_sweeps,
-                               dead_thresh, out, dead, nrot, maxoff, relevant2);
+                               dead_thresh, out, dead, nrot, maxoff, relevant2, dbg);
         else
             hipLaunchKernelGGL((eig_small3_kernel<64>), dim3(ngroups), dim3(512), 0, st, part, nchunk, nvec, mode, max_sweeps,
-                               dead_thresh, out, dead, nrot, maxoff, relevant2);
+                               dead_thresh, out, dead, nrot, maxoff, relevant2, dbg);
     } else if (pipelined) {
         if (nvec <= 32)
             hipLaunchKernelGGL((eig_small2_kernel<32>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,
