@@ -146,11 +146,20 @@ int tn_mpo_from_factor(const double* F, const int32_t* dmap, const int32_t* rmap
  *   T1: (npref, p, Dr)  left environment times the top MPS site, one row block per distinct prefix
  *   RR: (nsuf, Dr, br)  right environments per distinct suffix
  *   F : (q, nl, nu)     non-zero factor of the PEPS tensor, T[s,l,d,r,u] = F[s,l,u] [d=dmap[s]] [r=rmap[s]]
- *   per branch kk: pref[kk], suf[kk], lidx[kk], uidx[kk] (int32).  Out: P (nb, q) normalised, minP (nb). */
+ *   per branch kk: pref[kk], suf[kk], lidx[kk], uidx[kk] (int32).  Out: P (nb, q) normalised, minP (nb).
+ *   parent_log2p (nb) / log2p_out (nb, q), both or neither: log2p_out[kk, s] = log2(P[kk, s]) + parent_log2p[kk], the expansion of
+ *   the branch log-probabilities of tnac4o.py:450-453 in the same launch. */
 int tn_calc_pn(const double* T1, const double* RR, const double* F, const int32_t* dmap, const int32_t* rmap,
                const int32_t* pref, const int32_t* suf, const int32_t* lidx, const int32_t* uidx, int64_t nb,
                int64_t q, int64_t nl, int64_t nu, int64_t p, int64_t Dr, int64_t br, double* P, double* minP,
-               void* stream);
+               const double* parent_log2p, double* log2p_out, void* stream);
+/* ---- a12: merge of the branches of a site-step with identical boundary indices (tnac4o.py:481-509).  The candidates arrive sorted by
+ * group, in candidate order inside a group: E, log2p, deg, pos (their position in the candidate list), group g = members starts[g] ..
+ * starts[g+1]-1 (ngroups + 1 offsets).  Per group: rep_pos_out = position of the FIRST member of minimal energy, deg_out = sum of the
+ * degeneracies of the members within min_dEng of that minimum, log2p_out = the representative's log2p when it is alone in that set,
+ * else the mean over the set added up in member order. */
+int tn_merge_groups(const double* E, const double* log2p, const int64_t* deg, const int64_t* pos, const int64_t* starts, int64_t ngroups,
+                    double min_dEng, int64_t* rep_pos_out, int64_t* deg_out, double* log2p_out, void* stream);
 /* ---- K9: per-item power-of-two normalisation of a batch of environments (tnac4o.py:533, 1781):
  * each of the `batch` contiguous blocks of `len` doubles is divided by its own nfactor. */
 int tn_nfactor_batched(double* x, int64_t batch, int64_t len, void* stream);

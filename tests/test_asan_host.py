@@ -57,8 +57,11 @@ expect_neg(L.tn_svdvals(P, 4, 1, 0, 4, host, None, None, P, 1 << 20, None), 'tn_
 expect_neg(L.tn_nfactor(P, 0, P, P, None), 'tn_nfactor empty')
 expect_neg(L.tn_nfactor(None, 4, P, P, None), 'tn_nfactor null')
 expect_neg(L.tn_normalize_pow2(P, 4, P, None, 8192, None), 'tn_normalize null')
-expect_neg(L.tn_calc_pn(P, P, P, P, P, P, P, P, P, 4, 0, 1, 1, 1, 1, 1, P, P, None), 'tn_calc_pn q')
-expect_neg(L.tn_calc_pn(P, P, P, P, P, P, P, P, P, 4, 256, 1, 1, 64, 512, 64, P, P, None), 'tn_calc_pn lds')
+expect_neg(L.tn_calc_pn(P, P, P, P, P, P, P, P, P, 4, 0, 1, 1, 1, 1, 1, P, P, None, None, None), 'tn_calc_pn q')
+expect_neg(L.tn_calc_pn(P, P, P, P, P, P, P, P, P, 4, 256, 1, 1, 64, 512, 64, P, P, None, None, None), 'tn_calc_pn lds')
+expect_neg(L.tn_calc_pn(P, P, P, P, P, P, P, P, P, 4, 16, 1, 1, 1, 1, 1, P, P, P, None, None), 'tn_calc_pn log2p pair')
+expect_neg(L.tn_merge_groups(P, P, P, P, P, -1, 0.0, P, P, P, None), 'tn_merge_groups ngroups')
+expect_neg(L.tn_compress_mps_arena_bytes(0, None, None, 8), 'tn_compress_mps_arena_bytes L')
 expect_neg(L.tn_env_rr_batched(P, P, P, P, P, 4, 512, 16, 64, 16, 16, 16, P, None), 'tn_env_rr acc')
 expect_neg(L.tn_env_rr_batched(P, P, P, P, P, -1, 4, 4, 4, 4, 4, 4, P, None), 'tn_env_rr nk')
 expect_neg(L.tn_env_rl_batched(None, P, P, 4, 4, 4, P, None), 'tn_env_rl null')

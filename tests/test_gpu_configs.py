@@ -277,3 +277,54 @@ def test_config5_rmf64_d8_chi128_fullsize():
     assert s.states.shape[1] == 64 * 64
     assert energy_RMF(J, s.states[:1])[0] == pytest.approx(s.energy[0], abs=1e-8)
     assert np.isfinite(s.probability[0]) and s.probability[0] < 0 and abs(s.negative_probability) < 1e-8
+
+
+# ------------------------------------------------------------------------------------------------ a12 on the device
+def _solve_with(mode, make, **kw):
+    saved = os.environ.get('TN_BEAM')
+    os.environ['TN_BEAM'] = mode
+    try:
+        s = make()
+        s.search_ground_state(**kw)
+        return s
+    finally:
+        if saved is None:
+            os.environ.pop('TN_BEAM', None)
+        else:
+            os.environ['TN_BEAM'] = saved
+
+
+@pytest.mark.parametrize('case', ['L128_1', 'L128_2_rot1', 'L128_3_chi32', 'L512', 'J124', 'rmf'])
+def test_beam_on_device_bit_identical_to_host_merge(case):
+    """a12 (reference tnac4o.py:437-537: cut-off, merge of equal boundary indices, top-M) resident on the GPU (tnac4o_amd/beam.py:
+    torch.unique on packed keys, tn_merge_groups, stable sorts) against the same canonical order evaluated with numpy on the host:
+    energies, degeneracies, log-probabilities, discarded / negative probabilities and the state table must agree bit for bit --
+    also on the degenerate J124 instance (degeneracy 1152, ties inside merge groups) and on the dense RMF path."""
+    import tnac4o_amd
+    import golden_inputs as gi
+    kw = dict(M=1024, relative_P_cutoff=1e-8, Dmax=8)
+    if case == 'L128_1':
+        make = lambda: gpu_solver()
+    elif case == 'L128_2_rot1':
+        make = lambda: gpu_solver(ins=2, rot=1)
+    elif case == 'L128_3_chi32':
+        make, kw = (lambda: gpu_solver(ins=3, rot=2)), dict(M=1024, relative_P_cutoff=1e-8, Dmax=32)
+    elif case == 'L512':
+        make, kw = (lambda: gpu_solver(L=512)), dict(M=1024, relative_P_cutoff=1e-8, Dmax=32)
+    elif case == 'J124':
+        def make():
+            s = tnac4o_amd.tnac4o(mode='Ising', Nx=8, Ny=8, Nc=8, J=gi.j124_J(1), beta=0.75)
+            s.precondition(mode='balancing')
+            return s
+        kw = dict(M=4096, relative_P_cutoff=1e-8, Dmax=8)
+    else:
+        from tnac4o_amd.auxx import synthetic_rmf
+        make = lambda: tnac4o_amd.tnac4o(mode='RMF', Nx=6, Ny=5, J=synthetic_rmf(6, 5, 4, 77), beta=1.0)
+        kw = dict(M=64, relative_P_cutoff=1e-8, Dmax=16)
+    a = _solve_with('device', make, **kw)
+    b = _solve_with('host', make, **kw)
+    assert np.array_equal(a.energy, b.energy) and np.array_equal(a.probability, b.probability)
+    assert int(a.degeneracy) == int(b.degeneracy) and np.array_equal(a.states, b.states) and a.states.dtype == b.states.dtype
+    assert a.discarded_probability == b.discarded_probability and a.negative_probability == b.negative_probability
+    if case == 'J124':
+        assert a.energy[0] == pytest.approx(-2309.0, abs=1e-9) and int(a.degeneracy) == 1152

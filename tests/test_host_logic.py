@@ -117,6 +117,23 @@ def test_fast_unique_and_merge_match_reference_semantics():
             else:
                 degn[k], probn[k] = deg[same][0], prob[same][0]
             lo += sz
+        a, b, c, _, _ = _merge_groups(i1, Eng, prob, deg, min_dEng, canonical=False)
+        assert np.array_equal(a, indn) and np.array_equal(b, degn) and np.array_equal(c, probn)
+        # the canonical order (tnac4o_amd/beam.py): members in candidate order, first minimal-energy member, mean in member order
+        order = i1.argsort(kind='stable')
+        lo = 0
+        for k, sz in enumerate(sizes):
+            ind = order[lo:lo + sz]
+            assert np.all(np.diff(ind) > 0)
+            Ek = Eng[ind]
+            imin = np.argmin(Ek)
+            indn[k] = ind[imin]
+            same = ind[(Ek - Ek[imin]) <= min_dEng]
+            acc = 0.0
+            for v in prob[same]:
+                acc += float(v)
+            degn[k], probn[k] = sum(deg[same]), (acc / len(same) if len(same) > 1 else prob[same][0])
+            lo += sz
         a, b, c, _, _ = _merge_groups(i1, Eng, prob, deg, min_dEng)
         assert np.array_equal(a, indn) and np.array_equal(b, degn) and np.array_equal(c, probn)
 

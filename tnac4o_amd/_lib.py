@@ -43,7 +43,8 @@ SIGNATURES = {
     'tn_scale_by': (_int, [_ptr, _i64, _ptr, _ptr]),
     'tn_normalize_pow2': (_int, [_ptr, _i64, _ptr, _ptr, _i64, _ptr]),
     'tn_scale_phys': (_int, [_ptr, _i64, _i64, _i64, _ptr, _int, _ptr]),
-    'tn_calc_pn': (_int, [_ptr] * 9 + [_i64] * 7 + [_ptr, _ptr, _ptr]),
+    'tn_calc_pn': (_int, [_ptr] * 9 + [_i64] * 7 + [_ptr, _ptr, _ptr, _ptr, _ptr]),
+    'tn_merge_groups': (_int, [_ptr] * 5 + [_i64, _f64, _ptr, _ptr, _ptr, _ptr]),
     'tn_nfactor_batched': (_int, [_ptr, _i64, _i64, _ptr]),
     'tn_env_rr_batched': (_int, [_ptr] * 5 + [_i64] * 7 + [_ptr, _ptr]),
     'tn_env_rl_batched': (_int, [_ptr] * 3 + [_i64] * 3 + [_ptr, _ptr]),
@@ -114,7 +115,7 @@ def _stale(L):
 # short, non-blocking entry points (see lib())
 SHORT_CALLS = ('tn_gemm', 'tn_gemm_ws_bytes', 'tn_qr_ws_bytes', 'tn_svd_ws_bytes', 'tn_absorb', 'tn_nfactor', 'tn_scale_by',
                'tn_normalize_pow2', 'tn_scale_phys', 'tn_calc_pn', 'tn_nfactor_batched', 'tn_env_rr_batched', 'tn_env_rl_batched',
-               'tn_balance', 'tn_svdvals_async', 'tn_rar', 'tn_rar_ws_bytes', 'tn_env_mix', 'tn_env_mix_ws_bytes',
+               'tn_balance', 'tn_merge_groups', 'tn_svdvals_async', 'tn_rar', 'tn_rar_ws_bytes', 'tn_env_mix', 'tn_env_mix_ws_bytes',
                'tn_apply_truncation', 'tn_apply_truncation_ws_bytes', 'tn_site_qr_ws_bytes', 'tn_gram_weights', 'tn_argsort_desc', 'tn_weighted_sum', 'tn_rows_norm2', 'tn_gather_scale_rows', 'tn_peps_factor', 'tn_mpo_from_factor', 'tn_last_error')
 _lib = None
 ABI_VERSION = 5          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()

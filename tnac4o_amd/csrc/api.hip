@@ -35,7 +35,9 @@ int normalize_pow2(hipStream_t, double*, int64_t, double*, void*, int64_t);
 int scale_phys(hipStream_t, double*, int64_t, int64_t, int64_t, const double*, int);
 int calc_pn(hipStream_t, const double*, const double*, const double*, const int32_t*, const int32_t*, const int32_t*,
             const int32_t*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, double*,
-            double*);
+            double*, const double*, double*);
+int merge_groups(hipStream_t, const double*, const double*, const int64_t*, const int64_t*, const int64_t*, int64_t, double, int64_t*, int64_t*,
+                 double*);
 int nfactor_batched(hipStream_t, double*, int64_t, int64_t);
 int peps_factor(hipStream_t, const double*, const double*, const double*, const double*, const double*, const double*, const double*,
                 const int32_t*, const int32_t*, int64_t, int64_t, int64_t, double*);
@@ -229,9 +231,16 @@ int tn_scale_phys(double* A, int64_t Dl, int64_t p, int64_t Dr, const double* di
 
 int tn_calc_pn(const double* T1, const double* RR, const double* F, const int32_t* dmap, const int32_t* rmap,
                const int32_t* pref, const int32_t* suf, const int32_t* lidx, const int32_t* uidx, int64_t nb, int64_t q,
-               int64_t nl, int64_t nu, int64_t p, int64_t Dr, int64_t br, double* P, double* minP, void* stream) {
+               int64_t nl, int64_t nu, int64_t p, int64_t Dr, int64_t br, double* P, double* minP, const double* parent_log2p,
+               double* log2p_out, void* stream) {
     TN_CHECK_ARG(T1 && RR && F && dmap && rmap && pref && suf && lidx && uidx && P && minP, "null operand");
-    return calc_pn(ST, T1, RR, F, dmap, rmap, pref, suf, lidx, uidx, nb, q, nl, nu, p, Dr, br, P, minP);
+    return calc_pn(ST, T1, RR, F, dmap, rmap, pref, suf, lidx, uidx, nb, q, nl, nu, p, Dr, br, P, minP, parent_log2p, log2p_out);
+}
+int tn_merge_groups(const double* E, const double* log2p, const int64_t* deg, const int64_t* pos, const int64_t* starts, int64_t ngroups,
+                    double min_dEng, int64_t* rep_pos_out, int64_t* deg_out, double* log2p_out, void* stream) {
+    TN_CHECK_ARG(ngroups >= 0, "negative group count");
+    TN_CHECK_ARG(ngroups == 0 || (E && log2p && deg && pos && starts && rep_pos_out && deg_out && log2p_out), "null operand");
+    return merge_groups(ST, E, log2p, deg, pos, starts, ngroups, min_dEng, rep_pos_out, deg_out, log2p_out);
 }
 int tn_peps_factor(const double* Es, const double* E1, const double* E4, const double* Xu, const double* Xl, const double* Xr,
                    const double* Xd, const int32_t* dmap, const int32_t* rmap, int64_t q, int64_t nl, int64_t nu, double* F,

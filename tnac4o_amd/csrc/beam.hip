@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void calc_pn_kernel(const double* __restrict__
                                                       const int32_t* __restrict__ rmap, const int32_t* __restrict__ pref,
                                                       const int32_t* __restrict__ suf, const int32_t* __restrict__ lidx,
                                                       const int32_t* __restrict__ uidx, int q, int nl, int nu, int p,
-                                                      int Dr, int br, double* __restrict__ P, double* __restrict__ minP) {
+                                                      int Dr, int br, double* __restrict__ P, double* __restrict__ minP,
+                                                      const double* __restrict__ parent_log2p, double* __restrict__ log2p_out) {
     extern __shared__ double lds[];
     double* sT1 = lds;                  // [p][Dr]
     double* sRR = sT1 + p * Dr;         // [Dr][br]
@@ -90,18 +91,25 @@ __global__ __launch_bounds__(256) void calc_pn_kernel(const double* __restrict__
         mPn = -1.0;
     }
     if (tid == 0) minP[kk] = mPn;
+    if (log2p_out) {                                   // tnac4o.py:450-453: log2 of the table plus the parent's log-probability
+        const double base = parent_log2p[kk];
+        double* lo = log2p_out + kk * q;
+        for (int s = tid; s < q; s += 256) lo[s] = log2(out[s]) + base;      // (out[s] was written by this very thread)
+    }
 }
 
 int calc_pn(hipStream_t st, const double* T1, const double* RR, const double* F, const int32_t* dmap, const int32_t* rmap,
             const int32_t* pref, const int32_t* suf, const int32_t* lidx, const int32_t* uidx, int64_t nb, int64_t q,
-            int64_t nl, int64_t nu, int64_t p, int64_t Dr, int64_t br, double* P, double* minP) {
+            int64_t nl, int64_t nu, int64_t p, int64_t Dr, int64_t br, double* P, double* minP, const double* parent_log2p,
+            double* log2p_out) {
     if (nb <= 0) return 0;
+    TN_CHECK_ARG((parent_log2p == nullptr) == (log2p_out == nullptr), "parent_log2p and log2p_out go together");
     TN_CHECK_ARG(q >= 1 && nl >= 1 && nu >= 1 && p >= 1 && Dr >= 1 && br >= 1, "non-positive dimension");
     const int64_t lds = (p * Dr + Dr * br + p * br + q) * 8;
     TN_CHECK_ARG(lds <= 150 * 1024, "site too large for calc_pn");
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)calc_pn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(calc_pn_kernel, dim3((unsigned)nb), dim3(256), (size_t)lds, st, T1, RR, F, dmap, rmap, pref, suf, lidx,
-                       uidx, (int)q, (int)nl, (int)nu, (int)p, (int)Dr, (int)br, P, minP));
+                       uidx, (int)q, (int)nl, (int)nu, (int)p, (int)Dr, (int)br, P, minP, parent_log2p, log2p_out));
     TN_CHECK_LAUNCH("calc_pn_kernel");
     return 0;
 }
@@ -130,6 +138,40 @@ int nfactor_batched(hipStream_t st, double* x, int64_t batch, int64_t len) {
     if (batch <= 0 || len <= 0) return 0;
     TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(nfactor_batched_kernel, dim3((unsigned)batch), dim3(256), 0, st, x, len));
     TN_CHECK_LAUNCH("nfactor_batched_kernel");
+    return 0;
+}
+
+// ---- merge of branches with identical boundary indices (tnac4o.py:481-509), one thread per group ------------------------------
+// The candidates of a site-step arrive sorted by group (stable, i.e. in candidate order inside a group): E, log2 p, degeneracy and
+// the candidate position of every member, group g = members starts[g] .. starts[g+1]-1.  Per group: the representative is the FIRST
+// member of minimal energy, the degeneracies of the members within min_dEng of that minimum are added up, and the group's log2 p is
+// the representative's when it is alone, else the mean over those members, summed in member order (a fixed order: the host path of
+// tnac4o.search_ground_state adds in the same order, so both give the same bits).
+__global__ __launch_bounds__(256) void merge_groups_kernel(const double* __restrict__ E, const double* __restrict__ lp, const int64_t* __restrict__ deg,
+                                                           const int64_t* __restrict__ pos, const int64_t* __restrict__ starts, int64_t ng, double min_dEng,
+                                                           int64_t* __restrict__ rep_pos, int64_t* __restrict__ degn, double* __restrict__ lpn) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ng) return;
+    const int64_t lo = starts[g], hi = starts[g + 1];
+    double emin = E[lo];
+    int64_t first = lo;
+    for (int64_t i = lo + 1; i < hi; ++i)
+        if (E[i] < emin) { emin = E[i]; first = i; }
+    int64_t cnt = 0, d = 0;
+    double acc = 0.0;
+    for (int64_t i = lo; i < hi; ++i)
+        if (E[i] - emin <= min_dEng) { ++cnt; d += deg[i]; acc += lp[i]; }
+    rep_pos[g] = pos[first];
+    degn[g] = d;
+    lpn[g] = (cnt > 1) ? acc / (double)cnt : lp[first];
+}
+
+int merge_groups(hipStream_t st, const double* E, const double* lp, const int64_t* deg, const int64_t* pos, const int64_t* starts, int64_t ng,
+                 double min_dEng, int64_t* rep_pos, int64_t* degn, double* lpn) {
+    if (ng <= 0) return 0;
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(merge_groups_kernel, dim3((unsigned)cdiv(ng, 256)), dim3(256), 0, st, E, lp, deg, pos, starts, ng, min_dEng,
+                       rep_pos, degn, lpn));
+    TN_CHECK_LAUNCH("merge_groups_kernel");
     return 0;
 }
 

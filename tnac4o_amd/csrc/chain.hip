@@ -927,7 +927,7 @@ extern "C" {
 // conservative size of the arena for tn_compress_mps: the absorbed sites, the pass-1 output and its copy, the largest site's scratch
 int64_t tn_compress_mps_arena_bytes(int64_t L, const int64_t* site_dims_host, const int64_t* mpo_dims_host, int64_t Dmax) {
     (void)Dmax;
-    if (L < 1 || !site_dims_host) return -1;
+    if (L < 1 || !site_dims_host) { set_error("tn_compress_mps_arena_bytes: bad arguments"); return -1; }
     int64_t total = 0, biggest = 0, bmax = 1;
     for (int64_t n = 0; n < L; ++n) {
         int64_t Dl = site_dims_host[3 * n], p = site_dims_host[3 * n + 1], Dr = site_dims_host[3 * n + 2];

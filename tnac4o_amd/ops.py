@@ -636,8 +636,9 @@ def nfactor_batched_(X):
     return X
 
 
-def calc_pn(T1, RR, F, dmap, rmap, pref, suf, lidx, uidx):
-    """Batched conditional probabilities (tn_calc_pn).  Returns (P (nb,q), minP (nb))."""
+def calc_pn(T1, RR, F, dmap, rmap, pref, suf, lidx, uidx, parent_log2p=None):
+    """Batched conditional probabilities (tn_calc_pn).  Returns (P (nb,q), minP (nb)); with parent_log2p (nb) also the expanded
+    log-probabilities log2(P) + parent_log2p[:, None] as third value."""
     nb = pref.numel()
     q, nl, nu = F.shape
     _, p, Dr = T1.shape
@@ -646,10 +647,31 @@ def calc_pn(T1, RR, F, dmap, rmap, pref, suf, lidx, uidx):
         assert t.is_contiguous() and t.is_cuda
     P = torch.empty((nb, q), dtype=torch.float64, device=T1.device)
     mP = torch.empty((nb,), dtype=torch.float64, device=T1.device)
+    LP = None
+    if parent_log2p is not None:
+        assert parent_log2p.is_contiguous() and parent_log2p.numel() == nb and parent_log2p.dtype == torch.float64
+        LP = torch.empty((nb, q), dtype=torch.float64, device=T1.device)
     check(lib().tn_calc_pn(T1.data_ptr(), RR.data_ptr(), F.data_ptr(), dmap.data_ptr(), rmap.data_ptr(), pref.data_ptr(),
                            suf.data_ptr(), lidx.data_ptr(), uidx.data_ptr(), nb, q, nl, nu, p, Dr, br, P.data_ptr(),
-                           mP.data_ptr(), _stream()))
+                           mP.data_ptr(), parent_log2p.data_ptr() if LP is not None else None, LP.data_ptr() if LP is not None else None,
+                           _stream()))
+    if LP is not None:
+        return P, mP, LP
     return P, mP
+
+
+def merge_groups(E, lp, deg, pos, starts, min_dEng):
+    """Per-group merge of a site-step's candidates (tn_merge_groups): members sorted by group, `starts` the ngroups + 1 offsets.
+    Returns (rep_pos, deg, log2p) per group, device tensors."""
+    ng = starts.numel() - 1
+    for t in (E, lp, deg, pos, starts):
+        assert t.is_contiguous() and t.is_cuda
+    rep = torch.empty(ng, dtype=torch.int64, device=E.device)
+    dn = torch.empty(ng, dtype=torch.int64, device=E.device)
+    ln = torch.empty(ng, dtype=torch.float64, device=E.device)
+    check(lib().tn_merge_groups(E.data_ptr(), lp.data_ptr(), deg.data_ptr(), pos.data_ptr(), starts.data_ptr(), ng, float(min_dEng),
+                                rep.data_ptr(), dn.data_ptr(), ln.data_ptr(), _stream()))
+    return rep, dn, ln
 
 
 def env_rr(A, RRprev, W, parent, uidx):

@@ -119,6 +119,43 @@ def gather_branch_tables(compute, nb, q, group):
     return np.ascontiguousarray(full[:, :q]), np.ascontiguousarray(full[:, q])
 
 
+def allreduce_minmax(mn, mx, group):
+    """Global minimum of `mn` and maximum of `mx` (1-element float64 device tensors) over the ranks of `group`: one all-reduce."""
+    dev = _comm_device(group)
+    t = torch.cat([-mn.reshape(1), mx.reshape(1)]).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    t = t.to(mn.device)
+    return (-t[0]).reshape(1), t[1].reshape(1)
+
+
+def allgather_candidates(idx, vals, rest_max, group):
+    """The pruned candidate exchange of a site-step: every rank contributes the candidates of ITS slice of the
+    branches that survive the relative cut-off -- global flat indices `idx` (int64, ascending) and their log2 p `vals` -- plus the
+    largest log2 p it cut (`rest_max`, 1 element).  Returns the concatenation in rank order (= ascending flat index, the canonical
+    candidate order of tnac4o_amd.beam) and the global largest cut value, identical on every rank.  Two small collectives: the
+    counts, then one padded (count + 1) x 16-byte payload per rank; nothing goes through host numpy on the nccl path."""
+    rank, world = _group_info(group)
+    dev = _comm_device(group)
+    home = idx.device
+    n = torch.tensor([idx.numel()], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    buf = torch.zeros((cap + 1, 2), dtype=torch.int64, device=dev)
+    buf[0, 0] = rest_max.reshape(1).view(torch.int64).to(dev)[0]
+    k = idx.numel()
+    if k:
+        buf[1:1 + k, 0] = idx.to(dev)
+        buf[1:1 + k, 1] = vals.contiguous().view(torch.int64).to(dev)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    all_idx = torch.cat([out[r][1:1 + counts[r], 0] for r in range(world)]).to(home)
+    all_vals = torch.cat([out[r][1:1 + counts[r], 1] for r in range(world)]).contiguous().view(torch.float64).to(home)
+    rm = torch.stack([out[r][0, 0] for r in range(world)]).view(torch.float64).max().reshape(1).to(home)
+    return all_idx, all_vals, rm
+
+
 def broadcast_site_tensors(rows, group, rehearse=False):
     """Broadcast a list (rows) of lists (sites) of float64 arrays from the first rank of `group` to the others.
 

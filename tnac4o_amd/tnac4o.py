@@ -14,6 +14,7 @@ never formed: T[s,l,d,r,u] = F[s,l,u] [d = dmap[s]] [r = rmap[s]].
 """
 import itertools
 import logging
+import os
 
 import numpy as np
 import torch
@@ -65,11 +66,13 @@ def _unique_rows(a):
     return a[first], inv
 
 
-def _merge_groups(inv, Eng, prob, deg, min_dEng):
+def _merge_groups(inv, Eng, prob, deg, min_dEng, canonical=True):
     """The merge of branches with identical boundary indices (tnac4o.py:481-509), vectorised: per group the
-    representative is the first minimal-energy member in the order `inv.argsort()` (the reference's order), the
-    degeneracy is summed over members within min_dEng of the minimum and their log-probabilities are averaged."""
-    order = inv.argsort()
+    representative is the first minimal-energy member, the degeneracy is summed over members within min_dEng of the minimum
+    and their log-probabilities are averaged.  canonical (default; see tnac4o_amd/beam.py): members in candidate order (stable
+    sort), the mean added up in member order -- what tn_merge_groups does on the device.  canonical=False: numpy's own order
+    (unstable argsort, np.mean), the order the reference happens to get."""
+    order = inv.argsort(kind='stable') if canonical else inv.argsort()
     ginv = inv[order]
     n_grp = int(ginv[-1]) + 1
     starts = np.flatnonzero(np.r_[True, ginv[1:] != ginv[:-1]])
@@ -88,7 +91,13 @@ def _merge_groups(inv, Eng, prob, deg, min_dEng):
         lo = starts[k]
         hi = starts[k + 1] if k + 1 < n_grp else E.size
         same = order[lo:hi][near[lo:hi]]
-        probn[k] = np.mean(prob[same])
+        if canonical:
+            acc = 0.0
+            for v in prob[same]:
+                acc += float(v)
+            probn[k] = acc / len(same)
+        else:
+            probn[k] = np.mean(prob[same])
     return indn, degn, probn, order, starts
 
 
@@ -626,6 +635,14 @@ class tnac4o:
             self._setup_rhoT(**kw_sweep)
         else:
             self._setup_rhoT_shared(beam_group, **kw_sweep)
+        # TN_BEAM: 'device' (default) = the beam step resident on the GPU (tnac4o_amd/beam.py); 'host' = the same canonical order
+        # with the bookkeeping in numpy (used whenever a droplet recorder or a trace wants the intermediate tables on the host);
+        # 'numpy' = the host path in numpy's own (unspecified) argpartition / argsort order, as the reference happens to run
+        beam_mode = os.environ.get('TN_BEAM', 'device')
+        if beam_mode == 'device' and recorder is None and trace is None:
+            from . import beam
+            return beam.search_device(self, M, relative_P_cutoff, min_dEng, beam_group=beam_group)
+        canonical = beam_mode != 'numpy'
         Nx, Ny = self.Nx, self.Ny
         vind = np.zeros((1, Nx + 1), dtype=self.indtype)
         states = np.zeros((1, Nx * Ny), dtype=self.indtype)
@@ -652,26 +669,42 @@ class tnac4o:
                 _, suf = _unique_rows(np.vstack([skeys, vind[:, nx + 2:]]))
                 suf = suf[len(skeys):]
                 def pn_slice(lo, hi):                                        # K8 on the branches lo..hi-1
-                    return ops.calc_pn(T1, RR, F, dmap, rmap, _dev_i32(pref[lo:hi]), _dev_i32(suf[lo:hi]),
-                                       _dev_i32(vind[lo:hi, nx]), _dev_i32(vind[lo:hi, nx + 1]))
-                newprob, mP = parallel.gather_branch_tables(pn_slice, nb, q, beam_group)
+                    if not canonical:
+                        return ops.calc_pn(T1, RR, F, dmap, rmap, _dev_i32(pref[lo:hi]), _dev_i32(suf[lo:hi]),
+                                           _dev_i32(vind[lo:hi, nx]), _dev_i32(vind[lo:hi, nx + 1]))
+                    # canonical order: the expanded log-probabilities come from the same launch (the device's log2, so that
+                    # this path and tnac4o_amd.beam see the same bits); they ride behind the table
+                    P, mP_, LP = ops.calc_pn(T1, RR, F, dmap, rmap, _dev_i32(pref[lo:hi]), _dev_i32(suf[lo:hi]), _dev_i32(vind[lo:hi, nx]),
+                                             _dev_i32(vind[lo:hi, nx + 1]), parent_log2p=_dev_f64(prob[lo:hi]))
+                    return torch.cat([P, LP], dim=1), mP_
+                newprob, mP = parallel.gather_branch_tables(pn_slice, nb, q if not canonical else 2 * q, beam_group)
                 minprob = float(mP.min())
+                if canonical:
+                    newprob, logp = np.ascontiguousarray(newprob[:, :q]), np.ascontiguousarray(newprob[:, q:])
                 if trace is not None:
                     trace.append((ny, nx, newprob.copy(), mP.copy(), vind.copy()))
 
-                with np.errstate(divide='ignore'):
-                    newprob = np.log2(newprob)
-                newprob += prob[:, None]
-                prob = newprob.reshape(nb * q)
+                if canonical:
+                    prob = logp.reshape(nb * q)
+                else:
+                    with np.errstate(divide='ignore'):
+                        newprob = np.log2(newprob)
+                    newprob += prob[:, None]
+                    prob = newprob.reshape(nb * q)
 
                 order = np.arange(prob.size)
                 if relative_P_cutoff > 0:                                    # tnac4o.py:458-465
                     cutoff = np.max(prob) + np.log2(relative_P_cutoff)
                     keep = max(int((prob > cutoff).sum()), 1)
                     if keep < prob.size:
-                        order = prob.argpartition(-keep - 1)
-                        pd_max = max(pd_max, prob[order[-keep - 1]])
-                        order = order[-keep:]
+                        if canonical:                                        # ascending flat index; the largest value cut
+                            kept = prob > cutoff
+                            order = np.flatnonzero(kept)
+                            pd_max = max(pd_max, float(np.max(prob[~kept])))
+                        else:
+                            order = prob.argpartition(-keep - 1)
+                            pd_max = max(pd_max, prob[order[-keep - 1]])
+                            order = order[-keep:]
                         prob = prob[order]
 
                 inds, indc = order // q, np.mod(order, q)                    # tnac4o.py:469-478
@@ -685,12 +718,17 @@ class tnac4o:
                 Eng += self._update_Eng(states, ny, nx)
 
                 vindn, inv = _unique_rows(vind)                              # merge equal boundaries (:481-515)
-                indn, degn, probn, gorder, gstarts = _merge_groups(inv, Eng, prob, deg, min_dEng)
+                indn, degn, probn, gorder, gstarts = _merge_groups(inv, Eng, prob, deg, min_dEng, canonical=canonical)
                 sel = None
                 if probn.size > M:                                           # keep the M most probable (:518-526)
-                    sel = probn.argpartition(-M - 1)
-                    pd_max = max(pd_max, probn[sel[-M - 1]])
-                    sel = sel[-M:]
+                    if canonical:                                            # ties to the smaller group index; survivors in group order
+                        srt = np.argsort(-probn, kind='stable')
+                        pd_max = max(pd_max, probn[srt[M]])
+                        sel = np.sort(srt[:M])
+                    else:
+                        sel = probn.argpartition(-M - 1)
+                        pd_max = max(pd_max, probn[sel[-M - 1]])
+                        sel = sel[-M:]
                 if recorder is not None:                                     # droplets of the merged-away branches
                     recorder.merge_step(ny * Nx + nx, inds, gorder, gstarts, Eng, prob, states, indn, probn,
                                         np.arange(probn.size) if sel is None else sel)
