@@ -40,6 +40,24 @@ def _oracle(rot):
     return o
 
 
+class _beam_order:
+    """TN_BEAM for the duration of a block: 'numpy' = host path in numpy's argpartition / argsort order (what the reference and the
+    oracle run), 'host' = canonical order on the host, 'device' = canonical order resident on the GPU (tnac4o_amd/beam.py)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.saved = os.environ.get('TN_BEAM')
+        os.environ['TN_BEAM'] = self.mode
+
+    def __exit__(self, *exc):
+        if self.saved is None:
+            os.environ.pop('TN_BEAM', None)
+        else:
+            os.environ['TN_BEAM'] = self.saved
+
+
 def _as_ref_chain(m):
     from oracle import mps_ref as mr
     r = mr.RefMPS(d=[int(a.shape[1]) for a in m.A], L=len(m.A), Dmax=1, canonise=None)
@@ -57,7 +75,8 @@ def test_g6_beam_kernels_vs_oracle_on_same_boundary(rot, chi):
     Measured on the MI355X: <= 3e-13 relative."""
     s = gpu_solver(rot=rot)
     tr = []
-    s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi, trace=tr)
+    with _beam_order('numpy'):              # row-for-row comparison with the oracle needs the reference's own (numpy) branch order
+        s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi, trace=tr)
     o = _oracle(rot)
 
     def hook(solver, run):
@@ -127,7 +146,8 @@ def test_g6_marginals_hip_vs_reference_golden(rot, chi):
     tag = 'L128_r%d_chi%d' % (rot, chi)
     trace = []
     s = gpu_solver(rot=rot)
-    s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi, trace=trace)
+    with _beam_order('numpy'):              # the golden tables are in the reference's branch order
+        s.search_ground_state(M=1024, relative_P_cutoff=1e-8, Dmax=chi, trace=trace)
     assert [t[2].shape[0] for t in trace] == list(g[tag + '_nbranch'])
     spread = g6_reference_spread(rot, chi)
     worst = 0.0
