@@ -518,8 +518,7 @@ def cpu_baseline(n, args, solver, kw, single_ms):
     dev = float(np.max(np.abs(Sc[:k] - Sg[:k])) / Sc[0])
     assert dev < 1e-12, 'cpu_baseline: GPU and CPU oracle disagree on the sample (max |dS| / S0 = %.2e)' % dev
     # what the product runs on that row: the weighted rank-revealing first pass over all sites
-    w = psi.copy()
-    w._absorbed = getattr(psi, '_absorbed', None)
+    w = psi                                          # (last use of psi: the pass works on the absorbed MPS itself, factors attached)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ok = w.canonise_right_weighted()

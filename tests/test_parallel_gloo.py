@@ -104,10 +104,11 @@ def run_beam_world(nproc, rots, shards, inst, port):
     return outs
 
 
-@pytest.mark.parametrize('nproc,rots,inst', [(2, (0,), 1), (4, (0, 3), 2)])
+@pytest.mark.parametrize('nproc,rots,inst', [(2, (0,), 1), (4, (0, 3), 2), (8, (0, 1, 2, 3), 1)])
 def test_beam_sharded_inside_a_rotation(nproc, rots, inst):
     """teams of 2 ranks per rotation; the team's first rank sweeps and broadcasts rhoT, every site-step's
-    branches are split between the two, one all-gather per step; every rank must end with the serial result."""
+    branches are split between the two, one all-gather per step; every rank must end with the serial result.  The world-8 case is
+    the exact layout `bench.py --gpus 8` runs on a node: 4 rotation teams x 2 beam partners, all 4 rotations of one instance."""
     outs = run_beam_world(nproc, rots, 2, inst, 29560 + nproc)
     for o in outs[1:]:
         for k in ('energy', 'degeneracy', 'rotation', 'probability', 'state', 'records'):
@@ -124,6 +125,62 @@ def test_beam_sharded_inside_a_rotation(nproc, rots, inst):
     assert ser['probability'] == a['probability']               # same arithmetic on the same tables: bit-identical
     for r1, r2 in zip(ser['records'], a['records']):
         assert r1 == r2
+
+
+EXCHANGE_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from tnac4o_amd import parallel
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+grp = dist.new_group(list(range(world)))       # (the helpers take an explicit group: None means 'no sharding')
+ok = True
+for trial, (nb, q) in enumerate([(37, 16), (5, 8), (1, 4), (64, 256), (2, 3)]):
+    rng = np.random.default_rng(100 + trial)                      # the same table on every rank
+    tab = rng.standard_normal((nb, q)) * 8.0
+    tab[rng.random((nb, q)) < 0.1] = -np.inf                      # zero-probability entries
+    lo, hi = parallel.shard_range(nb, rank, world)
+    flat = torch.as_tensor(tab[lo:hi].reshape(-1).copy())
+    mn = flat.min().reshape(1) if flat.numel() else torch.full((1,), float('inf'), dtype=torch.float64)
+    mx = flat.max().reshape(1) if flat.numel() else torch.full((1,), float('-inf'), dtype=torch.float64)
+    gmn, gmx = parallel.allreduce_minmax(mn, mx, grp)
+    ok &= float(gmn) == tab.min() and float(gmx) == tab.max()
+    cutoff = gmx + float(np.log2(1e-3))
+    mask = flat > cutoff
+    idx = mask.nonzero().squeeze(1) + lo * q
+    vals = flat[mask]
+    rest = torch.where(mask, torch.full_like(flat, float('-inf')), flat)
+    rest_max = rest.max().reshape(1) if flat.numel() else torch.full((1,), float('-inf'), dtype=torch.float64)
+    gi_, gv, grm = parallel.allgather_candidates(idx, vals, rest_max, grp)
+    full = tab.reshape(-1)
+    want = np.flatnonzero(full > float(cutoff))
+    ok &= np.array_equal(gi_.numpy(), want) and np.array_equal(gv.numpy(), full[want])
+    cut = full[full <= float(cutoff)]
+    ok &= float(grm) == (cut.max() if cut.size else -np.inf)
+print('RESULT ' + json.dumps({'rank': rank, 'ok': bool(ok)}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('nproc', [2, 3])
+def test_pruned_candidate_exchange(nproc):
+    """The pruned exchange of a site-step (tnac4o_amd.parallel.allreduce_minmax / allgather_candidates, SURVEY.md 8e-ii): every rank
+    cuts the log-probabilities of ITS slice of the branches against the global maximum and only the survivors travel; the
+    concatenation in rank order must be exactly the candidates a single process keeps, in ascending flat index (the canonical order
+    of tnac4o_amd/beam.py), with the same largest cut value -- including empty slices and -inf entries."""
+    code = EXCHANGE_WORKER % dict(root=ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29590 + nproc), OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1')
+    procs = []
+    for r in range(nproc):
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, '-c', code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-2000:]
+        line = [l for l in out.splitlines() if l.startswith('RESULT ')][-1]
+        assert json.loads(line[7:])['ok']
 
 
 def test_shard_range_partitions():

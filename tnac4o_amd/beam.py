@@ -59,10 +59,10 @@ def unique_rows(keys):
     if W == 0 or n == 0:
         return (1 if n else 0), torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(min(n, 1), dtype=torch.int64, device=dev)
     if W == 1:
-        _, inv = torch.unique(keys[:, 0], sorted=True, return_inverse=True)
+        u, inv = torch.unique(keys[:, 0], sorted=True, return_inverse=True)
     else:
-        _, inv = torch.unique(keys, dim=0, sorted=True, return_inverse=True)
-    ng = int(inv.max().item()) + 1
+        u, inv = torch.unique(keys, dim=0, sorted=True, return_inverse=True)
+    ng = int(u.shape[0])
     first = torch.full((ng,), n, dtype=torch.int64, device=dev)
     first.scatter_reduce_(0, inv, torch.arange(n, dtype=torch.int64, device=dev), reduce='amin', include_self=True)
     return ng, inv, first

@@ -616,6 +616,7 @@ struct QrWs {
     double *G, *Tblk, *Zo, *Zo2, *tmpT;
     double *T, *X, *X2, *part, *Js, *Uinv, *Z, *Tri, *gemm_ws, *cn;
     int* dead;
+    int* pairs;          // swap list of the pivoted panel step (2 nb ints)
     int64_t gemm_ws_bytes;
     void* tsqr_ws;
     int64_t tsqr_bytes;
@@ -641,6 +642,7 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     double* Tri = (double*)take(P * nb * nb * 8);
     int* dead = (int*)take(nb * 4);
     double* cn = (double*)take(2 * n * 8);            // column norms^2: [input | current trailing block]
+    int* pairs = (int*)take((int64_t)2 * nb * 4);
     // split-K scratch for the tall TN products (b x n, K = m)
     int64_t gw = (int64_t)64 * nb * (n > k ? n : k) * 8;      // upper bound of pick_splitk's partial buffers
     {   // ... and of the outer-block products (NBO x n', K = m) of the two-level path: pick_splitk asks for about 512 tiles of
@@ -665,7 +667,7 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     if (w) { w->tsqr_ws = tsw; w->tsqr_bytes = tsb; }
     if (w) { w->Wq = Wq; w->W = Wp; w->W2 = Wp2; w->UT = UT; w->UTq = UTq; w->gemm_ws2 = gws2; }
     if (w) { w->Y = Y; w->T = T; w->X = X; w->X2 = X2; w->part = part; w->Js = Js; w->Uinv = Uinv; w->Z = Z; w->Tri = Tri;
-             w->dead = dead; w->gemm_ws = gws; w->gemm_ws_bytes = gw; w->cn = cn; }
+             w->dead = dead; w->gemm_ws = gws; w->gemm_ws_bytes = gw; w->cn = cn; w->pairs = pairs; }
     return off;
 }
 
@@ -911,7 +913,7 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
                     update(t);
                 }
             }
-            int* dpairs = (int*)(w.cn + 2 * n) - 2 * nb;                 // the tail of the norms buffer (2n doubles) is free here
+            int* dpairs = w.pairs;
             if ((he = hipMemcpyAsync(dpairs, pairs, (size_t)2 * b * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(he, "memcpy pairs");
             TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(swap_columns_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, A, rs, cs, m, dpairs, b));
             TN_CHECK_LAUNCH("swap_columns_kernel");

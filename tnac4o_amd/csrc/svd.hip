@@ -233,6 +233,21 @@ __global__ __launch_bounds__(256) void svd_vals_small_batched_kernel(const int64
     svd_vals_small_body(reinterpret_cast<const double*>(d[0]), d[1], d[2], (int)d[3], (int)d[4], out + 66 * (int64_t)blockIdx.x, X, nrm, flags);
 }
 
+// Page-locked slot 3 stages the asynchronous uploads of this file (tournament schedule, kept values / order).  An upload is only
+// guaranteed to have been consumed once ITS stream has passed a synchronisation; a thread that moves on to another stream must not
+// overwrite the slot while the previous stream may still be waiting to read it.
+static int upload_slot_guard(hipStream_t st) {
+    thread_local hipStream_t last = nullptr;
+    thread_local bool pending = false;
+    if (pending && last != st) {
+        const hipError_t e = hipStreamSynchronize(last);
+        if (e != hipSuccess) return hip_fail(e, "sync previous upload stream");
+    }
+    last = st;
+    pending = true;
+    return 0;
+}
+
 static void round_robin(int nblk, std::vector<int>& pairs) {     // (nblk-1) rounds x (nblk/2) pairs x 2
     std::vector<int> idx(nblk);
     for (int i = 0; i < nblk; ++i) idx[i] = i;
@@ -332,6 +347,7 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     std::copy(live.begin(), live.end(), hinit.begin());
     std::copy(pairs.begin(), pairs.end(), hinit.begin() + gap);
     {
+        if ((rc = upload_slot_guard(st))) return rc;
         int* stage = (int*)pinned_host(hinit.size() * 4, 3);
         if (stage) std::memcpy(stage, hinit.data(), hinit.size() * 4);
         if ((e = hipMemcpyAsync(w.live, stage ? stage : hinit.data(), hinit.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy init");
@@ -440,6 +456,7 @@ int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t
     std::memcpy(hpack.data() + (size_t)keep * 8, hO.data(), (size_t)keep * 4);
     double* dS = w.norms;
     const int* dO = (const int*)((const char*)w.norms + (size_t)keep * 8);
+    if ((rc = upload_slot_guard(st))) return rc;
     char* stage = (char*)pinned_host(hpack.size(), 3);         // (the schedule uploaded from this slot completed several synchronisations ago)
     if (stage) std::memcpy(stage, hpack.data(), hpack.size());
     if ((e = hipMemcpyAsync(w.norms, stage ? stage : hpack.data(), hpack.size(), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy S/order");

@@ -8,6 +8,7 @@ needs a number on the host: the kept rank in ``truncateC``, the Schmidt values i
 """
 import math
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -121,6 +122,19 @@ class MPO:
         """mps.py:859-865."""
         self.W[n] = _t(W).contiguous()
         self.support[n] = 1
+
+
+class _Ident:
+    """Identity of a tensor as recorded at some point: the object itself (weakly) and torch's in-place version counter.  matches(t) is
+    true only for that very tensor, unmodified by any torch in-place operation since (kernels of libtnpeps that write a site in place
+    go through MPS methods that drop the record)."""
+
+    def __init__(self, t):
+        self.ref = weakref.ref(t)
+        self.version = t._version
+
+    def matches(self, t):
+        return self.ref() is t and t._version == self.version
 
 
 class _LazyS:
@@ -337,12 +351,17 @@ class MPS:
                 old = self.A[n]
                 self.A[n] = ops.absorb(old, M.W[n], Hconj)
                 self.D[n], self.d[n], self.D[n + 1] = self.A[n].shape
-                self._absorbed[n] = (old, M.W[n], bool(Hconj), self.A[n].data_ptr())      # (no reference to the product itself)
+                # (a weak reference and the version counter of the product: identity, not an address that could be reused)
+                self._absorbed[n] = (old, M.W[n], bool(Hconj), _Ident(self.A[n]))
 
     def apply_diagonalO(self, diagO, n):
         """mps.py:361-366."""
-        self._absorbed = None                              # the site changes in place: any recorded factorisation is stale
-        ops.scale_phys_(self.A[n], _t(diagO).contiguous())
+        self.scale_site_(n, _t(diagO).contiguous())
+
+    def scale_site_(self, n, diag, inv=False):
+        """A[n] scaled (or divided) along its physical leg IN PLACE by a device vector; any recorded absorption is stale afterwards."""
+        self._absorbed = None
+        ops.scale_phys_(self.A[n], diag, inv=inv)
 
     # -- gauge moves --------------------------------------------------------------------------------------
     def attach_AC(self):
@@ -502,7 +521,7 @@ class MPS:
         for n in range(L):
             Dl, p, Dr = T[n].shape
             fac = absorbed.get(n)
-            if PASS1_STRUCTURED and fac is not None and fac[3] == T[n].data_ptr() and Dl >= PASS1_MIN_BOND and G.shape[0] == Dl:
+            if PASS1_STRUCTURED and fac is not None and fac[3].matches(T[n]) and Dl >= PASS1_MIN_BOND and G.shape[0] == Dl:
                 G = _gram_step_structured(G, fac[0], fac[1], fac[2])
             else:
                 X = ops.mm(G, T[n].view(Dl, p * Dr))
@@ -707,7 +726,7 @@ class MPS:
             # driver absorbs them again, 16 launches, and pushes the Gram recursion of the weighted pass through them exactly as the
             # Python driver does)
             fac = getattr(self, '_absorbed', None) or {}
-            if fac and all(f[3] == self.A[n].data_ptr() for n, f in fac.items()) and len({f[2] for f in fac.values()}) == 1:
+            if fac and all(f[3].matches(self.A[n]) for n, f in fac.items()) and len({f[2] for f in fac.values()}) == 1:
                 A = [fac[n][0].contiguous() if n in fac else A[n] for n in range(self.L)]
                 W = [fac[n][1].contiguous() if n in fac else None for n in range(self.L)]
                 Hconj = next(iter(fac.values()))[2]

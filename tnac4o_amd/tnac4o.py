@@ -442,8 +442,8 @@ class tnac4o:
         sc = ops.balance(B.bond_env_mix(T, nx), max_scale)
         nrm = torch.linalg.vector_norm
         o1 = B.expectation_mix_dev(T, nx) * torch.reciprocal(nrm(B.A[nx]) * nrm(T.A[nx]))
-        ops.scale_phys_(B.A[nx], sc)
-        ops.scale_phys_(T.A[nx], sc, inv=True)              # powers of two: dividing is exactly multiplying by 1/sc
+        B.scale_site_(nx, sc)
+        T.scale_site_(nx, sc, inv=True)                     # powers of two: dividing is exactly multiplying by 1/sc
         o2 = B.expectation_mix_dev(T, nx) * torch.reciprocal(nrm(B.A[nx]) * nrm(T.A[nx]))
         pending.append((ny, nx, sc, o1.reshape(1), o2.reshape(1)))
 
