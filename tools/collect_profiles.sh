@@ -1,16 +1,17 @@
 #!/bin/bash
-# Round-2 profile collection on the GPU box (run through gpurun): rocprofv3 kernel statistics of the bench command and
+# Profile collection (ROUND=r03 by default) on the GPU box (run through gpurun): rocprofv3 kernel statistics of the bench command and
 # PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA counters: separate runs, counters never combined with tracing domains) over
-# tools/pmc_probe.py.  Summaries land in gpurun_out/prof_r02/ and are copied into profiles/ by hand.
+# tools/pmc_probe.py.  Summaries land in gpurun_out/prof_$ROUND/ and are copied into profiles/ by hand.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof_r02
+ROUND=${ROUND:-r03}
+OUT=$ROOT/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "== counters" > $OUT/log.txt
 rocprofv3 -L 2>/dev/null | grep -i -E "mfma|FETCH_SIZE|WRITE_SIZE|SQ_BUSY_CYCLES|GRBM_GUI_ACTIVE" | head -60 > $OUT/counters_available.txt
 if [ -z "$PMC_ONLY" ]; then
 echo "== kernel trace of the bench command (4 interleaved chains)" >> $OUT/log.txt
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-search --cpu-rows 0 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-search --cpu-rows 0 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 echo "rc=$?" >> $OUT/log.txt
 if ! ls $OUT/kt/*/*kernel_stats.csv $OUT/kt/*kernel_stats.csv > /dev/null 2>&1; then
   echo "== fallback: kernel trace of the single-chain form" >> $OUT/log.txt

@@ -9,7 +9,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BASE = os.path.join(ROOT, 'gpurun_out', 'prof_r02')
+ROUND = os.environ.get('ROUND', 'r03')
+BASE = os.path.join(ROOT, 'gpurun_out', 'prof_' + ROUND)
 
 
 def load(tag):
@@ -41,17 +42,21 @@ for k in F:
                'traffic_bytes_per_launch': (fb + wb) / n}
 
 fam = {}
-ts = [k for k in kern if 'cq_gram_kernel' in k or 'cq_pass_kernel' in k or 'cq_post_kernel' in k]
+ts = [k for k in kern if 'cq_gram_kernel' in k or 'cq_pass_kernel' in k or 'cq_post_kernel' in k or 'cq_fused_kernel' in k]
 n = sum(kern[k]['dispatches'] for k in ts)
 fb = sum(kern[k]['fetch_bytes_per_launch'] * kern[k]['dispatches'] for k in ts)
 wb = sum(kern[k]['write_bytes_per_launch'] * kern[k]['dispatches'] for k in ts)
 # algorithmic bytes of the panel chain over one 16384 x 1024 QR: per panel the Gram launch reads the panel (8 B per element), a
 # substitution pass reads and writes it (16 B), the post launch reads it and writes Y and W (24 B); two passes per panel assumed
+# (the six-launch chain of the 16384 x 1024 QR); the single-launch form of the 4096 x 512 QR moves the panel in and Y, W out (24 B)
 alg = 0.0
 for p in range(32):
     rows = 16384 - 32 * p
     alg += (8.0 + 2 * 16.0 + 24.0) * rows * 32
-fam['panel step (cq_fused / cq_gram / cq_pass / cq_post)'] = {'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
+for p in range(16):
+    rows = 4096 - 32 * p
+    alg += 24.0 * rows * 32
+fam['panel step (cq_fused / cq_gram / cq_pass / cq_post)'] = {'probe_shape': 'tn_qr 16384 x 1024 (32 panels, six-launch chain) + tn_qr 4096 x 512 (16 panels, single-launch form)', 'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
                                    'traffic_bytes_per_launch': (fb + wb) / n, 'algorithmic_bytes_per_launch': alg / n,
                                    'traffic_over_algorithmic': (fb + wb) / alg}
 for name, pat in (('eig_small_kernel', 'eig_small_kernel'), ('absorb_kernel', 'absorb_mfma_kernel')):
@@ -62,7 +67,7 @@ for name, pat in (('eig_small_kernel', 'eig_small_kernel'), ('absorb_kernel', 'a
 
 # whole-call traffic: tn_qr 16384 x 1024 = every kernel of the QR (the probe runs exactly one such QR under the counters;
 # gemm<128,128,true,false> also contains the 3 plain 16384x1024x1024 products of the probe, which are subtracted)
-qr_names = ['cq_gram_kernel', 'cq_pass_kernel', 'cq_post_kernel', 'diag_qr_kernel',
+qr_names = ['cq_gram_kernel', 'cq_pass_kernel', 'cq_post_kernel', 'cq_fused_kernel', 'diag_qr_kernel',
             'assemble_R_kernel', 'init_Q_kernel', 'splitk_reduce_kernel', 'gemm_kernel<32, 128, false, false, false>',
             'gemm_kernel<128, 32, true, false, false>']
 qr_bytes = 0.0
@@ -101,12 +106,12 @@ for k in kern:
                    'SQ_WAIT_INST_LDS_per_launch': b.get('SQ_WAIT_INST_LDS', (0, 0, 0))[2],
                    'mfma_busy_over_wave_cycles': a['SQ_VALU_MFMA_BUSY_CYCLES'][2] / max(1.0, b.get('SQ_WAVE_CYCLES', (0, 0, 1))[2])}
 out = {'source': 'rocprofv3 --pmc (separate passes: FETCH_SIZE; WRITE_SIZE; SQ MFMA counters) over tools/pmc_probe.py on MI355X, '
-                 'round 2; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md); KB -> bytes',
-       'shapes': 'tn_qr 16384 x 1024 (nb=32, 32 panels x 6 launches of the Cholesky-QR panel chain), tn_svd_trunc 320 x 1024 (leading rows of the triangular factor of a graded rank-300 matrix), tn_absorb bulk '
+                 '%s; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md); KB -> bytes' % ROUND,
+       'shapes': 'tn_qr 16384 x 1024 (nb=32, 32 panels x 6 launches of the Cholesky-QR panel chain), tn_qr 4096 x 512 (16 panels in the single-launch form), tn_svd_trunc 320 x 1024 (leading rows of the triangular factor of a graded rank-300 matrix), tn_absorb bulk '
                  'site, tn_gemm 16384 x 1024 x 1024',
        'families': fam, 'kernels': kern, 'whole_call': whole, 'svd_step': svd,
-       'mfma_counters': {'file': 'profiles/r02_pmc_traffic.json (mfma_counters.kernels)', 'kernels': mfma,
+       'mfma_counters': {'file': 'profiles/%s_pmc_traffic.json (mfma_counters.kernels)' % ROUND, 'kernels': mfma,
                          'note': 'raw SQ counters per launch; the derived MfmaUtil of rocprofv3 falls back to gfx94x formulas on '
                                  'gfx950, so only ratios of raw counters are quoted'}}
-json.dump(out, open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(ROOT, 'profiles', '%s_pmc_traffic.json' % ROUND), 'w'), indent=1)
 print(json.dumps({'families': fam, 'whole_call': whole}, indent=1))

@@ -23,6 +23,10 @@ t0 = time.perf_counter()
 ops.qr_into(Xq, Q, Rr, overwrite=True)
 torch.cuda.synchronize()
 t_qr = time.perf_counter() - t0
+# one QR whose panels take the single-launch form (<= 4096 rows)
+X2 = torch.randn(4096, 512, dtype=torch.float64, device='cuda')
+Q2 = torch.empty((4096, 512), dtype=torch.float64, device='cuda'); R2 = torch.empty((512, 512), dtype=torch.float64, device='cuda')
+ops.qr_into(X2, Q2, R2, overwrite=True)
 G0 = torch.randn(4096, 300, dtype=torch.float64, device='cuda') * (10.0 ** (-torch.arange(300, dtype=torch.float64, device='cuda') / 20.0))
 _, Rfull = torch.linalg.qr(G0 @ torch.randn(300, 1024, dtype=torch.float64, device='cuda'))
 C = Rfull[:320].contiguous()
