@@ -110,33 +110,31 @@ int weighted_sum(hipStream_t st, const double* a, const double* b, int64_t n, do
 
 // perm[rank(i)] = i with rank(i) = #{ j : w[j] before w[i] } in the strict total order "larger value first, NaN before everything,
 // equal values by increasing index" -- a stable descending argsort by counting (n is a bond dimension: <= a few thousand)
+// (one workgroup per element: its 256 threads share the comparisons, so a 1024-key sort is one wave of short workgroups)
 __global__ __launch_bounds__(256) void argsort_desc_kernel(const double* __restrict__ w, int64_t n, int64_t* __restrict__ perm) {
-    __shared__ double tile[256];
+    __shared__ int red[4];
     const int tid = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
-    const double mine = i < n ? w[i] : 0.0;
+    const int64_t i = blockIdx.x;
+    const double mine = w[i];
     const bool mine_nan = !(mine == mine);
-    int64_t rank = 0;
-    for (int64_t j0 = 0; j0 < n; j0 += 256) {
-        tile[tid] = (j0 + tid < n) ? w[j0 + tid] : 0.0;
-        __syncthreads();
-        const int cnt = (int)((n - j0 < 256) ? n - j0 : 256);
-        for (int t = 0; t < cnt; ++t) {
-            const double x = tile[t];
-            const bool x_nan = !(x == x);
-            const int64_t j = j0 + t;
-            bool before;
-            if (x_nan || mine_nan) before = x_nan && (!mine_nan || j < i);
-            else before = (x > mine) || (x == mine && j < i);
-            rank += before ? 1 : 0;
-        }
-        __syncthreads();
+    int cnt = 0;
+    for (int64_t j = tid; j < n; j += 256) {
+        const double x = w[j];
+        const bool x_nan = !(x == x);
+        bool before;
+        if (x_nan || mine_nan) before = x_nan && (!mine_nan || j < i);
+        else before = (x > mine) || (x == mine && j < i);
+        cnt += before ? 1 : 0;
     }
-    if (i < n) perm[rank] = i;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) perm[(red[0] + red[1]) + (red[2] + red[3])] = i;
 }
 int argsort_desc(hipStream_t st, const double* w, int64_t n, int64_t* perm) {
     TN_CHECK_ARG(n >= 1 && n <= (1 << 20), "length out of range");
-    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(argsort_desc_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w, n, perm));
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(argsort_desc_kernel, dim3((unsigned)n), dim3(256), 0, st, w, n, perm));
     TN_CHECK_LAUNCH("argsort_desc_kernel");
     return 0;
 }
