@@ -641,7 +641,7 @@ def test_panel_single_launch_bit_identical_to_chain(ops):
     bit for bit, the same pass / deferral / refill record."""
     n = 0
     for name, X in _panel_cases():
-        if X.shape[0] > 4096:
+        if X.shape[0] > 8192:
             continue
         Y1, st1, dev1 = _with_env('TN_PANEL_FUSED', '1', lambda: ops.panel_orth(X, 0, state=True))
         Y0, st0, dev0 = _with_env('TN_PANEL_FUSED', '0', lambda: ops.panel_orth(X, 0, state=True))
@@ -661,7 +661,7 @@ def test_qr_single_launch_panels_bit_identical_to_chain(ops):
     rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g).cuda()
     A = (rn(4096, 256) * torch.logspace(0, -20, 256, dtype=torch.float64).cuda()[None, :]) @ torch.linalg.qr(rn(256, 256))[0]
     mats = [rn(4096, 256), rn(300, 1000).t(), rn(300, 1000), rn(50, 7), rn(4096, 64) @ rn(64, 512), A, rn(2048, 1024), rn(33, 33),
-            rn(1500, 700), torch.zeros(512, 64, dtype=torch.float64).cuda()]
+            rn(1500, 700), torch.zeros(512, 64, dtype=torch.float64).cuda(), rn(8192, 160), rn(8000, 96) @ rn(96, 300)]
     for T in mats:
         for tol in (0.0, 2.0 ** -56):
             def run():
@@ -686,7 +686,7 @@ def test_qr_single_launch_panels_under_uneven_load(ops):
     import threading
     g = torch.Generator(device='cpu').manual_seed(29)
     rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g).cuda()
-    mats = [rn(4096, 384), rn(3000, 256), rn(2048, 512), rn(1024, 1024)]
+    mats = [rn(8192, 256), rn(3000, 256), rn(6000, 384), rn(1024, 1024)]          # (8192 rows: 32 workgroups per panel launch)
     ref = [ops.qr(T) for T in mats]
     torch.cuda.synchronize()
     big_a, big_b = rn(4096, 4096), rn(4096, 4096)

@@ -893,8 +893,7 @@ __global__ __launch_bounds__(256) void cq_post_kernel(const double* X, int64_t x
 }
 
 // ---- the whole panel step in ONE launch ------------------------------------------------------------------------------
-// For panels of up to CQ_FUSED_MAXBLK x 256 rows (what the truncating passes and the variational sweeps factor: ~80 % of the
-// panels of a sweep) the chain  gram -> pass ... pass -> post  runs inside one kernel: every workgroup keeps its 256-row tile in
+// For panels of up to CQ_FUSED_MAXBLK x 256 = 8192 rows (everything but the 16384-row panels of the first edge sites) the chain  gram -> pass ... pass -> post  runs inside one kernel: every workgroup keeps its 256-row tile in
 // LDS from the first load to the last store (the six-launch form reloads and stores it in every launch), the workgroups meet at
 // in-kernel barriers (a monotone arrival counter polled by one lane, MI355X guide "Guideline 16": partials written with
 // agent-scope stores, drained, one atomic add per workgroup, relaxed agent-scope poll, agent-scope loads of the partials),
@@ -902,10 +901,13 @@ __global__ __launch_bounds__(256) void cq_post_kernel(const double* X, int64_t x
 // -- the same arithmetic in the same order as cq_tail, hence the same bits in every workgroup and the same result as the
 // six-launch form -- so no second hand-off is needed to distribute R.  The Householder reconstruction is redundant in the same
 // way: workgroup 0 publishes the top 32 x 32 block of the panel next to its partial Gram matrix.
-// Co-residency: <= 16 workgroups per launch, a handful of chains per device, 256 CUs: every workgroup of a launch is dispatched
-// as soon as the kernels ahead of it (which never wait for anything) drain; spins are bounded (CQ_SPIN_LIMIT polls, seconds), a
-// launch that gives up poisons its output with NaN and raises the sticky stt->timeout, which later launches of the call honour.
-constexpr int CQ_FUSED_MAXBLK = 16;
+// Co-residency: a workgroup needs a whole CU (127 KB of LDS) and only ever waits for workgroups of its OWN launch, so the launches in
+// flight can deadlock only if together they ask for more CUs than the chip has.  At most CQ_FUSED_MAXBLK = 32 workgroups per launch and
+// at most 8 launches in flight (the 8 hardware queues the package asks for, one chain per queue) make 256 = the CUs of an MI355X; every
+// other kernel on the device finishes without waiting for anyone.  Should a process be configured with more queues than that, the
+// spins are bounded (CQ_SPIN_LIMIT polls, seconds): a launch that gives up poisons its output with NaN and raises the sticky
+// stt->timeout, which later launches of the call honour.
+constexpr int CQ_FUSED_MAXBLK = 32;
 constexpr unsigned CQ_SPIN_LIMIT = 1u << 22;
 
 __device__ __forceinline__ bool cq_grid_barrier(int* counter, int target, int* s_flag, int tid) {

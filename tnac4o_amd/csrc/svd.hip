@@ -363,7 +363,10 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     // a single block pair is diagonalised completely inside eig_small (one round + one verification round);
     // with several pairs two inner sweeps per visit give the fewest total Jacobi steps
     static const int inner_env = [] { const char* e = getenv("TN_SVD_INNER"); return e ? atoi(e) : 2; }();
-    const int inner_sweeps = (ng == 1) ? 12 : inner_env;
+    // ... in the FIRST outer sweep, where the rotations are large; from the second outer sweep on the off-diagonals a visit meets are
+    // small (quadratic convergence), a second inner sweep finds next to nothing and the next outer sweep has to look at the pair again
+    // anyway (TN_SVD_INNER_LATER, default 1)
+    static const int inner_later = [] { const char* e = getenv("TN_SVD_INNER_LATER"); return e ? atoi(e) : 1; }();
     static const bool restrict_conv = [] { const char* e = getenv("TN_SVD_RELEVANT"); return !(e && e[0] == '0'); }();
     const double rel4 = 0.25 * rel_tol;
     const double relevant2 = restrict_conv ? nmax * rel4 * rel4 : 0.0;
@@ -381,7 +384,8 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
             if ((rc = gemm_ex(st, nvec, nvec, L, 1.0, w.X, pitch, 1, w.X, 1, pitch, 0.0, nullptr, 0, 0, ng, 0, 0, 0, w.part,
                               (int64_t)ng * nchunk * nvec * nvec * 8, &xg)))
                 return rc;
-            if ((rc = eig_small(st, w.part, used, nvec, ng, 2, inner_sweeps, 0.0, w.Js, nullptr, w.nrot, w.maxoff + (int64_t)r * ng, relevant2)))
+            if ((rc = eig_small(st, w.part, used, nvec, ng, 2, (ng == 1) ? 12 : (outer == 0 ? inner_env : inner_later), 0.0, w.Js, nullptr, w.nrot,
+                                w.maxoff + (int64_t)r * ng, relevant2)))
                 return rc;
             GemmExtra xa;
             xa.pairs = pr; xa.pw = SVD_W; xa.mapB = 1; xa.mapC = 1; xa.skip = w.nrot;
