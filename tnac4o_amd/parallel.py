@@ -53,8 +53,12 @@ def run_concurrent(fns):
     # it: 1.51 -> 1.62 s/sweep with fresh streams, 1.64 -> 2.36 with reused ones (tools/stream_regime_experiment.py).
     torch.cuda.current_stream().synchronize()
 
+    stagger = float(__import__('os').environ.get('TN_STAGGER_MS', '0')) * 1e-3
+
     def work(i):
         try:
+            if stagger > 0.0 and i:
+                __import__('time').sleep(i * stagger)      # (experiment: de-phase the chains' device-filling passes)
             with torch.cuda.stream(streams[i]):
                 out[i] = fns[i]()
                 streams[i].synchronize()
