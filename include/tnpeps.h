@@ -27,6 +27,9 @@ extern "C" {
 int tn_version(void);
 /* copies the hash of the sources the library was built from (set by the build recipe) into buf; returns its length */
 int tn_build_id(char* buf, int n);
+/* A stream confined to the compute units set in mask_host (nwords x 32 bits); see tnac4o_amd/parallel.py (TN_CU_MASK). */
+int tn_stream_create_masked(const uint32_t* mask_host, int nwords, void** stream_out);
+int tn_stream_destroy(void* stream);
 /* copies the calling thread's last error text into buf (NUL-terminated); returns its length */
 int tn_last_error(char* buf, int n);
 

@@ -16,6 +16,8 @@ SIGNATURES = {
     'tn_version': (_int, []),
     'tn_last_error': (_int, [C.c_char_p, _int]),
     'tn_build_id': (_int, [C.c_char_p, _int]),
+    'tn_stream_create_masked': (_int, [C.POINTER(C.c_uint32), _int, C.POINTER(_ptr)]),
+    'tn_stream_destroy': (_int, [_ptr]),
     'tn_gemm': (_int, [_i64, _i64, _i64, _f64, _ptr, _i64, _i64, _ptr, _i64, _i64, _f64, _ptr, _i64, _i64,
                        _i64, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     'tn_gemm_ws_bytes': (_i64, [_i64, _i64, _i64, _i64]),

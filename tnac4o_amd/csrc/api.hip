@@ -106,6 +106,22 @@ int tn_profile_get_phase(int phase, int family, uint64_t* calls_host, double* ms
     return 0;
 }
 
+// A HIP stream restricted to the compute units whose bits are set in `mask` (nwords x 32 bits; hipExtStreamCreateWithCUMask).  Used by
+// parallel.run_concurrent (TN_CU_MASK=1) to keep a share of the CUs out of every chain's reach, so that a device-filling GEMM of one
+// chain cannot occupy every CU the latency-bound kernels of the other chains could use.  The caller destroys it with tn_stream_destroy.
+int tn_stream_create_masked(const uint32_t* mask_host, int nwords, void** stream_out) {
+    TN_CHECK_ARG(mask_host && nwords >= 1 && stream_out, "bad arguments");
+    hipStream_t st = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask_host);
+    if (e != hipSuccess) return hip_fail(e, "hipExtStreamCreateWithCUMask");
+    *stream_out = (void*)st;
+    return 0;
+}
+int tn_stream_destroy(void* stream) {
+    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "hipStreamDestroy");
+}
+
 int tn_last_error(char* buf, int n) {
     const char* e = get_error();
     int len = (int)strlen(e);

@@ -860,8 +860,25 @@ public:
                 CH(add(true));
                 CH(update_RL(phi, n));
             }
-            // finish(): all small centre matrices in one launch, one read-back, then the bookkeeping of update_S in the reference's order
+            // finish(): all small centre matrices in one launch, one read-back, then the bookkeeping of update_S in the reference's order.
+            // Centre matrices recorded lazily by an earlier stage that the bookkeeping below is going to ask for (first use of the bond
+            // in this sweep, same length) ride along in the same launch instead of one synchronous decomposition each (same kernel
+            // body, same values).
             std::vector<double> table;
+            std::vector<int> lazy_row((size_t)L + 1, -1);
+            {
+                std::vector<char> seen((size_t)L + 1, 0);
+                for (const Pending& it : items) {
+                    if (seen[it.bond]) continue;
+                    seen[it.bond] = 1;
+                    const SState& ss = Sst[it.bond];
+                    const int64_t size = it.row >= 0 ? std::min(it.Cm.r, it.Cm.c) : (int64_t)it.S.size();
+                    if (ss.is_lazy && std::min(ss.lazy.r, ss.lazy.c) == size && std::max(ss.lazy.r, ss.lazy.c) <= 64) {
+                        lazy_row[it.bond] = (int)small.size();
+                        small.push_back(ss.lazy);
+                    }
+                }
+            }
             if (!small.empty()) {
                 const size_t ns = small.size();
                 std::vector<int64_t> desc(5 * ns);
@@ -887,6 +904,15 @@ public:
                 CH(d2h(stage ? stage : table.data(), out66, 66 * ns * 8));
                 CH(sync("Schmidt values"));
                 if (stage) std::copy(stage, stage + 66 * ns, table.begin());
+            }
+            for (int64_t bnd = 0; bnd <= L; ++bnd) {
+                if (lazy_row[bnd] < 0) continue;
+                SState& ss = Sst[bnd];
+                const int64_t k = std::min(ss.lazy.r, ss.lazy.c);
+                const double* row = &table[66 * (size_t)lazy_row[bnd]];
+                bool good = row[65] != 0.0;
+                for (int64_t i = 0; i < k && good; ++i) good = std::isfinite(row[i]);
+                if (good) { ss.val.assign(row, row + k); ss.has = true; ss.is_lazy = false; ss.lazy = M2(); }      // else: previous_S decomposes it
             }
             diff = 0.0;
             for (Pending& it : items) {

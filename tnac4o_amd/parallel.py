@@ -18,6 +18,44 @@ import torch.distributed as dist
 _CHAIN_STREAMS = {}
 
 
+def _make_chain_streams(n):
+    """The chains' streams.  TN_CU_MASK=<k> (experiment): chain i gets a stream whose CU mask leaves out the i-th of n groups of k
+    consecutive... see DESIGN.md 4.4; default: plain torch streams."""
+    import ctypes as C
+    import os
+    spec = os.environ.get('TN_CU_MASK', '')
+    if not spec:
+        return [torch.cuda.Stream() for _ in range(n)]
+    from ._lib import lib, check
+    ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    nwords = (ncu + 31) // 32
+    out = []
+    mode, _, arg = spec.partition(':')
+    for i in range(n):
+        bits = [1] * ncu
+        if mode == 'block':                  # leave out a contiguous block of ncu / n CUs
+            w = ncu // n
+            for c in range(i * w, (i + 1) * w):
+                bits[c] = 0
+        elif mode == 'stride':               # leave out every n-th CU, offset i
+            for c in range(i, ncu, n):
+                bits[c] = 0
+        elif mode == 'keep':                 # chain i keeps only `arg` per cent of the CUs, spread evenly, offset i
+            frac = float(arg or 75) / 100.0
+            bits = [0] * ncu
+            for c in range(ncu):
+                if ((c + i * 7) % 100) < frac * 100:
+                    bits[c] = 1
+        words = (C.c_uint32 * nwords)()
+        for c, b in enumerate(bits):
+            if b:
+                words[c // 32] |= (1 << (c % 32))
+        h = C.c_void_p()
+        check(lib().tn_stream_create_masked(words, nwords, C.byref(h)))
+        out.append(torch.cuda.ExternalStream(h.value))
+    return out
+
+
 def run_concurrent(fns):
     """Run independent chains concurrently on one GPU: each callable gets its own host thread and its own HIP stream
     (one stream per rotation so that the latency-bound chains interleave on the device).  Returns the
@@ -36,7 +74,7 @@ def run_concurrent(fns):
     key = (torch.cuda.current_device(), n)
     streams = _CHAIN_STREAMS.get(key)
     if streams is None:
-        streams = _CHAIN_STREAMS[key] = [torch.cuda.Stream() for _ in range(n)]
+        streams = _CHAIN_STREAMS[key] = _make_chain_streams(n)
     # side streams (deferred Schmidt-value checks; tn_qr's look-ahead when enabled), taken right after the chains' own streams
     # so that the pairing with hardware queues is the same on every call (torch hands out pool streams round-robin, pool
     # stream k sits on hardware queue k mod 4): chain i's side stream is rotated by TN_AUX_ROT so that it does not share a
