@@ -924,13 +924,6 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
         constexpr int NBLK = HP * (HP + 1) / 2;            // 2 x 2 blocks (a <= b): G stays exactly symmetric, half the arithmetic
         constexpr int GT = 320;                            // threads of the five updating waves (1, 2, 4, 5, 6)
         constexpr int UB = (NBLK + GT - 1) / GT;           // blocks per updating thread
-        __shared__ unsigned char blk_a[NBLK], blk_b[NBLK];
-        for (int e = tid; e < NBLK; e += NT_) {            // block list: e -> (a, b), a <= b, row by row
-            int a = 0, rem = e;
-            while (rem >= HP - a) { rem -= HP - a; ++a; }
-            blk_a[e] = (unsigned char)a;
-            blk_b[e] = (unsigned char)(a + rem);
-        }
         __shared__ __attribute__((aligned(16))) double cs2[2][HP * 2];
         __shared__ __attribute__((aligned(16))) double csj[2][HP * 2];
         const double tol = 8.881784197001252e-16;          // 2^-50
@@ -965,6 +958,30 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
             }
             return false;
         };
+        __shared__ unsigned char blk_a[NBLK], blk_b[NBLK];
+        // index tables (the modular arithmetic of the tournament once per launch instead of in every thread in every step; the kernel is
+        // bound by instruction issue): pq_tab[s][a] = the pair of slot a in step s (p < q, packed p | q << 8); so_tab[s][i] = slot of
+        // index i in step s, bit 7 set when i is the larger member of its pair.  (Fetching them one step ahead as well was tried: the
+        // extra reads cost more than the shorter dependency chain gains.)
+        __shared__ unsigned short pq_tab[M * HP];
+        __shared__ unsigned char so_tab[M * NB];
+        for (int e = tid; e < M * HP; e += NT_) {
+            int p, q;
+            slot_pair(e / HP, e % HP, p, q);
+            pq_tab[e] = (unsigned short)(p | (q << 8));
+        }
+        for (int e = tid; e < M * NB; e += NT_) {
+            int a, hi;
+            slot_of(e / NB, e % NB, a, hi);
+            so_tab[e] = (unsigned char)(a | (hi << 7));
+        }
+        for (int e = tid; e < NBLK; e += NT_) {            // block list: e -> (a, b), a <= b, row by row
+            int a = 0, rem = e;
+            while (rem >= HP - a) { rem -= HP - a; ++a; }
+            blk_a[e] = (unsigned char)a;
+            blk_b[e] = (unsigned char)(a + rem);
+        }
+        auto pair_of = [&](int s, int a, int& p, int& q) { const unsigned v = pq_tab[s * HP + a]; p = (int)(v & 255u); q = (int)(v >> 8); };
         // wave 0, lane a < HP: parameters of step s into buffer `pb` (the buffers alternate from step to step ACROSS sweeps: a sweep
         // has an odd number of steps, so the parity of s itself would collide at the sweep boundary)
         auto publish = [&](int pb, int s, int a, int p, double c, double sn, bool rot) {
@@ -1040,16 +1057,15 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
                 double c = 1.0, sn = 0.0;
                 int p = 0, q = 0;
                 if (tid < HP) {
-                    slot_pair(s1, tid, p, q);
+                    pair_of(s1, tid, p, q);
                     double gpp, gqq, gpq;
                     if (dbg & 4) { gpp = 1.0; gqq = 1.0; gpq = 0.0; }
                     else if (flag) {
-                        int ap, hp_, aq, hq_;
-                        slot_of(s, p, ap, hp_);
-                        slot_of(s, q, aq, hq_);
+                        const unsigned sp = so_tab[s * NB + p], sq = so_tab[s * NB + q];
+                        const int ap = (int)(sp & 127u), hp_ = (int)(sp >> 7), aq = (int)(sq & 127u), hq_ = (int)(sq >> 7);
                         int pp, qp, pq, qq;
-                        slot_pair(s, ap, pp, qp);           // pair holding p in step s
-                        slot_pair(s, aq, pq, qq);           // pair holding q in step s
+                        pair_of(s, ap, pp, qp);             // pair holding p in step s
+                        pair_of(s, aq, pq, qq);             // pair holding q in step s
                         const double2 rp = *reinterpret_cast<const double2*>(&cs2[par][2 * ap]);
                         const double2 rq = *reinterpret_cast<const double2*>(&cs2[par][2 * aq]);
                         // block (ap, ap) -> g_pp;  block (aq, aq) -> g_qq;  block (ap, aq) -> g_pq
@@ -1099,8 +1115,8 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
                     const int e = wave_g * 64 + lane_ + GT * k;
                     on[k] = e < NBLK;
                     const int a = on[k] ? blk_a[e] : 0, b = on[k] ? blk_b[e] : 0;
-                    slot_pair(s, a, pa[k], qa[k]);
-                    slot_pair(s, b, pb[k], qb[k]);
+                    pair_of(s, a, pa[k], qa[k]);
+                    pair_of(s, b, pb[k], qb[k]);
                     ra[k] = *reinterpret_cast<const double2*>(&cs2[par][2 * a]);
                     rb[k] = *reinterpret_cast<const double2*>(&cs2[par][2 * b]);
                     g00[k] = Gc[pa[k] * P + pb[k]]; g01[k] = Gc[pa[k] * P + qb[k]];
