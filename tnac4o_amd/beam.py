@@ -15,7 +15,7 @@ group or probabilities tie exactly at a cut); both the device path below and the
 it, and agree bit for bit (tests/test_gpu_configs.py).
 
 Device path: conditional tables, their log2 + parent log-probability (tn_calc_pn), maximum, cut-off and compaction (torch), gathers of
-the branch records, energies (table look-ups), packed-key unique of the boundary rows (torch.unique), the per-group merge
+the branch records, energies (table look-ups), unique of the boundary rows through one int64 rank key (torch.unique), the per-group merge
 (tn_merge_groups: fixed summation order), top-M (stable sort) and the environment bookkeeping all stay on the GPU; the host learns two
 integers per site-step (kept candidates, groups).  With a beam group (several ranks on one rotation) every rank evaluates the tables
 of its slice of the branches, prunes them against the global maximum and only the surviving (index, log2 p) pairs travel.
@@ -24,48 +24,6 @@ import numpy as np
 import torch
 
 from . import ops
-
-
-def _bits_needed(maxval):
-    return max(1, int(maxval).bit_length())
-
-
-class KeyPacker:
-    """Rows of small non-negative integers -> rows of int64 words, order preserving (lexicographic on the columns)."""
-
-    def __init__(self, maxval):
-        self.bits = _bits_needed(maxval)
-        self.per_word = max(1, 62 // self.bits)
-
-    def pack(self, rows):
-        """rows: (n, w) int64 device tensor -> (n, W) int64 (W = 0 for w = 0)."""
-        n, w = rows.shape
-        if w == 0:
-            return rows.new_zeros((n, 0))
-        words = []
-        for c0 in range(0, w, self.per_word):
-            blk = rows[:, c0:c0 + self.per_word]
-            k = blk.shape[1]
-            sh = torch.arange(k - 1, -1, -1, device=rows.device, dtype=torch.int64) * self.bits
-            words.append((blk << sh[None, :]).sum(dim=1))
-        return torch.stack(words, dim=1)
-
-
-def unique_rows(keys):
-    """Sorted unique rows of an (n, W) int64 tensor: (number of groups, inverse (n,), first member of every group (ng,)).
-    Lexicographic order over the words = lexicographic order of the original index rows (np.unique(axis=0) order)."""
-    n, W = keys.shape
-    dev = keys.device
-    if W == 0 or n == 0:
-        return (1 if n else 0), torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(min(n, 1), dtype=torch.int64, device=dev)
-    if W == 1:
-        u, inv = torch.unique(keys[:, 0], sorted=True, return_inverse=True)
-    else:
-        u, inv = torch.unique(keys, dim=0, sorted=True, return_inverse=True)
-    ng = int(u.shape[0])
-    first = torch.full((ng,), n, dtype=torch.int64, device=dev)
-    first.scatter_reduce_(0, inv, torch.arange(n, dtype=torch.int64, device=dev), reduce='amin', include_self=True)
-    return ng, inv, first
 
 
 class SiteTables:
@@ -96,7 +54,6 @@ def search_device(solver, M, relative_P_cutoff, min_dEng, beam_group=None):
     dev = solver.rhoT[0].A[0].device
     i64, f64 = torch.int64, torch.float64
     maxidx = int(max(np.max(solver.ld), np.max(solver.lr), 2)) - 1
-    packer = KeyPacker(maxidx)
     ninf = float('-inf')
     rank, world = parallel._group_info(beam_group)
 
@@ -115,19 +72,43 @@ def search_device(solver, M, relative_P_cutoff, min_dEng, beam_group=None):
             tables[(ny, nx)] = SiteTables(solver, ny, nx, dev)
         return tables[(ny, nx)]
 
+    B = maxidx + 1                                                      # radix of a boundary index
+
+    def unique_keys(key):
+        """Sorted unique values of an int64 key vector: (number of groups, inverse, first member of every group)."""
+        u, inv = torch.unique(key, sorted=True, return_inverse=True)
+        ng = int(u.shape[0])
+        first = torch.full((ng,), key.numel(), dtype=i64, device=dev)
+        first.scatter_reduce_(0, inv, torch.arange(key.numel(), dtype=i64, device=dev), reduce='amin', include_self=True)
+        return ng, inv, first
+
     for ny in range(Ny):
         solver.logger.info('Row %d / %d', ny + 1, Ny)
         top = solver.rhoT[ny + 1]
-        # ---- right environments of every distinct suffix (tnac4o._setup_RR, tnac4o.py:1768-1784); sufidx[:, j] = index of the branch's
+        # Every index row the search has to compare -- suffixes for the right environments, prefixes for the left ones, whole rows for
+        # the merge -- is compared through ONE int64 key built from order-preserving ranks: a suffix vind[:, c:] is (vind[:, c], rank of
+        # vind[:, c+1:]), a prefix vind[:, :c+1] is (rank of vind[:, :c], vind[:, c]), a whole row is (prefix rank, down index, right index,
+        # suffix rank).  Sorting the keys sorts the rows lexicographically (what np.unique(axis=0) does on the host path), without packing
+        # or multi-word sorts.
+        # ---- right environments of every distinct suffix (tnac4o._setup_RR, tnac4o.py:1768-1784); sufidx[j] = rank of the branch's
         # suffix vind[:, Nx-j+1:] among the keys of level j (level j serves site nx = Nx-1-j)
         nb = prob.numel()
+        site = {}
+
+        def cell(nx):                                                   # F, dmap, rmap and the MPO site of a cell, built once per row
+            if nx not in site:
+                F, dm, rm, pd, br = solver._peps_factor_dev(ny, nx)
+                site[nx] = (F, dm, rm, pd, br)
+            return site[nx]
         RRs = [torch.ones((1, 1, 1), dtype=f64, device=dev)]
         sufidx = [torch.zeros(nb, dtype=i64, device=dev)]
+        nkeys_prev = 1
         for nx in range(Nx - 1, 0, -1):
-            _, inv, first = unique_rows(packer.pack(vind[:, nx + 1:]))
+            nk, inv, first = unique_keys(vind[:, nx + 1] * nkeys_prev + sufidx[-1])
             parent = sufidx[-1][first]                                  # the key's own suffix [1:] in the previous level
             uidx = vind[first, nx + 1]
-            W = solver._mpo_site_dev(ny, nx)
+            F, dm, rm, pd, br_ = cell(nx)
+            W = ops.mpo_from_factor(F, dm, rm, pd, br_)
             bl, p, br, pu = W.shape
             A = top.A[nx]
             Dl, _, Dr = A.shape
@@ -141,6 +122,8 @@ def search_device(solver, M, relative_P_cutoff, min_dEng, beam_group=None):
                 ops.nfactor_batched_(RR)
             RRs.append(RR)
             sufidx.append(inv)
+            nkeys_prev = nk
+        nsuf = [int(r.shape[0]) for r in RRs]
         sufmat = torch.stack(sufidx, dim=1)                             # (nb, Nx)
         pref = torch.zeros(nb, dtype=i64, device=dev)
         RL = torch.ones((1, 1), dtype=f64, device=dev)
@@ -148,12 +131,13 @@ def search_device(solver, M, relative_P_cutoff, min_dEng, beam_group=None):
             tb = tab(ny, nx)
             q, nb = tb.q, prob.numel()
             pos = ny * Nx + nx
-            F, dmap, rmap, _, _ = solver._peps_factor_dev(ny, nx)
+            F, dmap, rmap, _, _ = cell(nx)
             AT = top.A[nx]
             Dl, p, Dr = AT.shape
             T1 = ops.mm(RL, AT.view(Dl, p * Dr)).view(-1, p, Dr)
-            RR = RRs[Nx - nx - 1]
-            suf = sufmat[:, Nx - nx - 1]
+            lvl = Nx - nx - 1
+            RR = RRs[lvl]
+            suf = sufmat[:, lvl]
             lo, hi = parallel.shard_range(nb, rank, world)
             if hi > lo:
                 _, mP, LP = ops.calc_pn(T1, RR, F, dmap, rmap, _i32(pref[lo:hi]), _i32(suf[lo:hi]), _i32(vind[lo:hi, nx]),
@@ -190,9 +174,7 @@ def search_device(solver, M, relative_P_cutoff, min_dEng, beam_group=None):
             child = idx - parent * q
             st_c = states[parent]
             st_c[:, pos] = child.to(torch.int16)
-            vi_c = vind[parent]
-            vi_c[:, nx] = tb.down[child]
-            vi_c[:, nx + 1] = tb.right[child]
+            down_c, right_c = tb.down[child], tb.right[child]
             dE = 1.0 * tb.Es[child]
             if nx > 0:
                 left = st_c[:, pos - 1].to(i64)
@@ -201,8 +183,11 @@ def search_device(solver, M, relative_P_cutoff, min_dEng, beam_group=None):
                 up = st_c[:, pos - Nx].to(i64)
                 dE = dE + tb.E4[child, tab(ny - 1, nx).down[up] if solver.mode == 'Ising' else up]
             E_c = Eng[parent] + dE
-            # ---- merge of equal boundary rows (tnac4o.py:481-515)
-            ng, inv, _ = unique_rows(packer.pack(vi_c))
+            # ---- merge of equal boundary rows (tnac4o.py:481-515): row = (prefix, down, right, suffix)
+            pref_c = pref[parent]
+            pkey = pref_c * B + down_c                                   # the new prefix vind[:, :nx+1] (ranks of the old one x radix)
+            key = (pkey * B + right_c) * nsuf[lvl] + suf[parent]
+            ng, inv, _ = unique_keys(key)
             sinv, perm = torch.sort(inv, stable=True)
             counts = torch.bincount(inv, minlength=ng)
             starts = torch.cat([torch.zeros(1, dtype=i64, device=dev), torch.cumsum(counts, 0)])
@@ -213,11 +198,15 @@ def search_device(solver, M, relative_P_cutoff, min_dEng, beam_group=None):
                 pd_max = torch.maximum(pd_max, sv[M].reshape(1))
                 sel = torch.sort(six[:M]).values
                 rep, degn, lpn = rep[sel], degn[sel], lpn[sel]
-            vind, states, Eng, prob, deg = vi_c[rep], st_c[rep], E_c[rep], lpn, degn
-            sufmat = sufmat[parent[rep]]
+            prep = parent[rep]
+            vind = vind[prep]
+            vind[:, nx] = down_c[rep]
+            vind[:, nx + 1] = right_c[rep]
+            states, Eng, prob, deg = st_c[rep], E_c[rep], lpn, degn
+            sufmat = sufmat[prep]
             # ---- left environments of the new distinct prefixes: rows of T1 (tnac4o.py:528-535)
-            _, ninv, nfirst = unique_rows(packer.pack(vind[:, :nx + 1]))
-            par = pref[parent[rep]][nfirst]
+            _, ninv, nfirst = unique_keys(pkey[rep])
+            par = pref_c[rep][nfirst]
             didx = vind[nfirst, nx]
             RL = ops.env_rl(T1, _i32(par), _i32(didx))
             pref = ninv
