@@ -4,11 +4,14 @@
 // :655-663, _mps_RAR :748-751, projector application :579-580) is a strided view of this kernel, so no
 // transposed copies are ever materialised.
 //
-// Tile: BM x BN per 256-thread workgroup (4 waves as 2 x 2), BK = 16.  Operands are staged through LDS
-// k-major (As[k][m], Bs[k][n]) with pitch = B? + 16 doubles and an XOR swizzle of the low 4 column bits by
-// k, which makes both the fragment reads (ds_read_b64, 16 consecutive doubles per k) and the transposed
-// stores of k-contiguous operands bank-conflict free.  The next K-tile is prefetched into registers while
-// the current one is multiplied.  MFMA f64 lane maps (cdna_hip_programming.md §3): A[l&15][l>>4],
+// Tile: BM x BN per 256-thread workgroup (4 waves as 2 x 2), K step BKT = 16 or 32.  Operands are staged through
+// two LDS stages, k-major (As[k][m], Bs[k][n]) with pitch = B? + 16 doubles and an XOR swizzle of the low column
+// bits by k, which makes both the fragment reads (ds_read_b64, 16 consecutive doubles per k) and the transposed
+// stores of k-contiguous operands bank-conflict free.  The next K-tile is prefetched into registers while the
+// current one is multiplied and lands in the other stage: one barrier per K step.  BKT = 32 serves the launches
+// that do not fill the chip (the chain's small products): there a K step costs one global-memory round trip
+// whatever its depth, so half as many steps is close to half the time; launches with many workgroups per CU keep
+// BKT = 16 (less LDS, more workgroups in flight).  MFMA f64 lane maps (cdna_hip_programming.md §3): A[l&15][l>>4],
 // B[l>>4][l&15], D reg r -> row (l>>4)+4r, col l&15.
 #include <stdlib.h>
 
@@ -44,15 +47,16 @@ struct GemmP {
     int pw, mapA, mapB, mapC;
 };
 
-constexpr int BK = 16;
+constexpr int BK = 16;          // granularity of the split-K chunks (multiples of 32 for the BKT = 32 kernels)
 
-template <int BM, int BN, bool AKFAST, bool BKFAST, bool MAPPED>
-__global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 1) void gemm_kernel(GemmP g) {
+template <int BM, int BN, int BKT, bool AKFAST, bool BKFAST, bool MAPPED>
+__global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 16) ? 2 : 1) void gemm_kernel(GemmP g) {
+    constexpr int BK = BKT;
     constexpr int PA = BM + 16, PB = BN + 16;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     constexpr int EA = BM * BK / 256, EB = BN * BK / 256;     // elements per thread per tile
-    __shared__ double As[BK * PA];
-    __shared__ double Bs[BK * PB];
+    __shared__ double As[2][BK * PA];
+    __shared__ double Bs[2][BK * PB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -109,16 +113,16 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 1) void gemm_ke
             }
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int stage) {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
             const int m = m0 + e * DM, k = kA0 + e * DKA;
-            As[k * PA + (m ^ k)] = ra[e];
+            As[stage][k * PA + (m ^ k)] = ra[e];
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
             const int n = n0 + e * DN, k = kB0 + e * DKB;
-            Bs[k * PB + (n ^ k)] = rb[e];
+            Bs[stage][k * PB + (n ^ k)] = rb[e];
         }
     };
 
@@ -129,26 +133,34 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 1) void gemm_ke
         for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
     const int lr = lane & 15, lk = lane >> 4;
-    if (k_lo < k_hi) load_tiles(k_lo);
+    int cur = 0;
+    if (k_lo < k_hi) {
+        load_tiles(k_lo);
+        store_tiles(0);
+    }
+    __syncthreads();
     for (int64_t k0 = k_lo; k0 < k_hi; k0 += BK) {
-        store_tiles();
-        __syncthreads();
-        if (k0 + BK < k_hi) load_tiles(k0 + BK);
+        const bool more = k0 + BK < k_hi;
+        if (more) load_tiles(k0 + BK);                    // in flight while this stage is multiplied
+        const double* Ac = As[cur];
+        const double* Bc = Bs[cur];
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             const int k = kk * 4 + lk;
             double a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[k * PA + ((wm * WM + i * 16 + lr) ^ k)];
+            for (int i = 0; i < TM; ++i) a[i] = Ac[k * PA + ((wm * WM + i * 16 + lr) ^ k)];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[k * PB + ((wn * WN + j * 16 + lr) ^ k)];
+            for (int j = 0; j < TN; ++j) b[j] = Bc[k * PB + ((wn * WN + j * 16 + lr) ^ k)];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) store_tiles(cur ^ 1);                    // the other stage: nobody reads it before the barrier
         __syncthreads();
+        cur ^= 1;
     }
 
     if (g.splitk > 1 || g.splitk < 0) {
@@ -204,45 +216,76 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP g) {
     *c = v;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BKT>
 static void launch_tile(hipStream_t st, const GemmP& g, dim3 grid, bool ak, bool bk) {
     if constexpr (BM == 64 && BN == 64) {          // the block-pair indirection of the Jacobi SVD only ever uses this tile
         if (g.pairs) {
-            if (ak && bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, true>), grid, dim3(256), 0, st, g);
-            else if (ak) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, true>), grid, dim3(256), 0, st, g);
-            else if (bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, true>), grid, dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, true>), grid, dim3(256), 0, st, g);
+            if (ak && bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, true, true, true>), grid, dim3(256), 0, st, g);
+            else if (ak) hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, true, false, true>), grid, dim3(256), 0, st, g);
+            else if (bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, false, true, true>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, false, false, true>), grid, dim3(256), 0, st, g);
             return;
         }
     }
-    if (ak && bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, false>), grid, dim3(256), 0, st, g);
-    else if (ak) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, false>), grid, dim3(256), 0, st, g);
-    else if (bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, false>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, false>), grid, dim3(256), 0, st, g);
+    if (ak && bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, true, true, false>), grid, dim3(256), 0, st, g);
+    else if (ak) hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, true, false, false>), grid, dim3(256), 0, st, g);
+    else if (bk) hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, false, true, false>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, false, false, false>), grid, dim3(256), 0, st, g);
 }
 
-static void pick_tile(int64_t M, int64_t N, int& bm, int& bn) {
-    if (M > 64 && N > 64) { bm = 128; bn = 128; }
-    else if (N <= 32 && M > 64) { bm = 128; bn = 32; }
-    else if (M <= 32 && N > 64) { bm = 32; bn = 128; }
-    else { bm = 64; bn = 64; }
+// K step of a launch: 32 when the grid leaves CUs idle anyway (every workgroup has a CU and its LDS to itself) and there are
+// at least two such steps to make; TN_GEMM_BK=16 / 32 forces one form (A/B measurements)
+static int pick_bkt(int64_t wgs, int64_t kchunk) {
+    static const int forced = [] { const char* e = getenv("TN_GEMM_BK"); return e ? atoi(e) : 0; }();
+    if (forced == 16 || forced == 32) return forced;
+    return (wgs <= 256 && kchunk >= 64) ? 32 : 16;
 }
 
-static int pick_splitk(int64_t M, int64_t N, int64_t K, int64_t batch) {
-    int bm, bn;
-    pick_tile(M, N, bm, bn);
-    const int64_t tiles = cdiv(M, bm) * cdiv(N, bn) * batch;
-    if (tiles >= 192 || K < 512) return 1;
-    int64_t s = cdiv(512, tiles);
-    const int64_t smax = K / 128;     // keep at least 128 of K per split
-    if (s > smax) s = smax;
-    if (s > 64) s = 64;
-    return s < 2 ? 1 : (int)s;
+// ---- launch plan --------------------------------------------------------------------------------------------------
+// Almost every product of a sweep is small: its tiles fill a few of the 256 CUs, and one CU makes 64 x 64 x 16 of fp64 MFMA work
+// in ~0.9 us (a 128 x 128 tile: ~1.9 us), so the time of such a product is (K steps per workgroup) x that, plus the launches.
+// Products of less than TN_GEMM_SMALLWORK (2^30) multiply-adds are therefore spread over about one workgroup per CU: 64 x 64
+// tiles instead of 128 x 128 while those would leave half the chip idle, and K split down to chunks of TN_GEMM_MINCHUNK (32, at most TN_GEMM_SMAX = 32 of them),
+// the partial sums added up by splitk_reduce_kernel (an in-kernel reduction by the last workgroup of a tile to arrive was
+// measured slower: it pulls all the partials of a tile through one CU, 22 us against 12 us for the two launches at 64 x 64 x 1024).
+// Larger products are bound by MFMA throughput: big tiles, K split only to fill the chip, chunks of at least 128.
+struct GemmPlan { int bm, bn, s; };
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int64_t batch) {
+    static const int64_t small_work = (int64_t)1 << env_int("TN_GEMM_SMALLWORK_LOG2", 30);
+    static const int big_tiles = env_int("TN_GEMM_BIGTILES", 128);     // small products: 128 x 128 tiles from this many workgroups on
+    static const int target_wg = env_int("TN_GEMM_TARGETWG", 256);
+    static const int min_chunk = env_int("TN_GEMM_MINCHUNK", 32);
+    static const int smax = env_int("TN_GEMM_SMAX", 32);
+    const bool small = (double)M * (double)N * (double)K * (double)batch < (double)small_work;
+    GemmPlan p;
+    if (M > 64 && N > 64) {
+        const bool big = !small || cdiv(M, 128) * cdiv(N, 128) * batch >= big_tiles;
+        p.bm = p.bn = big ? 128 : 64;
+    } else if (N <= 32 && M > 64) { p.bm = 128; p.bn = 32; }
+    else if (M <= 32 && N > 64) { p.bm = 32; p.bn = 128; }
+    else { p.bm = 64; p.bn = 64; }
+    const int64_t wgs = cdiv(M, p.bm) * cdiv(N, p.bn) * batch;
+    p.s = 1;
+    if (small) {
+        if (wgs < target_wg * 3 / 4 && K >= 2 * min_chunk) {
+            int64_t s = cdiv(target_wg, wgs);
+            if (s > K / min_chunk) s = K / min_chunk;
+            if (s > smax) s = smax;
+            p.s = s < 2 ? 1 : (int)s;
+        }
+    } else if (wgs < 192 && K >= 512) {
+        int64_t s = cdiv(512, wgs);
+        if (s > K / 128) s = K / 128;
+        if (s > 64) s = 64;
+        p.s = s < 2 ? 1 : (int)s;
+    }
+    return p;
 }
 
 int64_t gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch) {
-    const int s = pick_splitk(M, N, K, batch);
-    return s > 1 ? (int64_t)s * batch * M * N * 8 : 0;
+    const GemmPlan p = plan_gemm(M, N, K, batch);
+    return p.s > 1 ? (int64_t)p.s * batch * M * N * 8 : 0;
 }
 
 int gemm(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
@@ -296,7 +339,7 @@ int gemm_ex(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    const int sk = (x && x->force_splitk > 0) ? x->force_splitk : pick_splitk(M, N, K, batch);
+    const int sk = (x && x->force_splitk > 0) ? x->force_splitk : plan_gemm(M, N, K, batch).s;
     std::lock_guard<std::mutex> lk(g_trace.mu);
     ShapeStat& ss = g_trace.tab[std::make_tuple(M, N, K, batch, (csa == 1 && rsa != 1) ? 1 : 0, (rsb == 1 && csb != 1) ? 1 : 0, (x && x->pairs) ? -sk : sk)];
     ss.ms += ms;
@@ -315,16 +358,19 @@ static int gemm_ex_impl(hipStream_t st, int64_t M, int64_t N, int64_t K, double 
     g.bsa = bsa; g.bsb = bsb; g.bsc = bsc; g.alpha = alpha; g.beta = beta; g.ws = ws;
     g.pairs = x ? x->pairs : nullptr; g.skip = x ? x->skip : nullptr;
     g.pw = x ? x->pw : 0; g.mapA = x ? x->mapA : 0; g.mapB = x ? x->mapB : 0; g.mapC = x ? x->mapC : 0;
-    int bm, bn;
-    pick_tile(M, N, bm, bn);
+    const GemmPlan pl = plan_gemm(M, N, K, batch);
+    const int bm = pl.bm, bn = pl.bn;
     TN_CHECK_ARG(g.pairs == nullptr || (bm == 64 && bn == 64), "block-pair indirection is built for the 64 x 64 tile only");
     g.tiles_m = (int)cdiv(M, bm); g.tiles_n = (int)cdiv(N, bn);
-    int s = (x && x->force_splitk > 0) ? x->force_splitk : pick_splitk(M, N, K, batch);
-    if (s > 1 && (ws == nullptr || ws_bytes < (int64_t)s * batch * M * N * 8)) s = 1;
+    int s = (x && x->force_splitk > 0) ? x->force_splitk : pl.s;
+    if (s > 1) {                                   // a smaller scratch than gemm_ws_bytes asks for: as many splits as fit
+        const int64_t fit = ws ? ws_bytes / (batch * M * N * 8) : 0;
+        if (fit < s) s = fit < 2 ? 1 : (int)fit;
+    }
     const bool raw = x && x->raw_partials;
     TN_CHECK_ARG(!raw || ws != nullptr, "raw partials need a workspace");
     g.splitk = s;
-    g.kchunk = s > 1 ? align_up(cdiv(K, s), BK) : (K > 0 ? align_up(K, BK) : BK);
+    g.kchunk = s > 1 ? align_up(cdiv(K, s), 2 * BK) : (K > 0 ? align_up(K, 2 * BK) : 2 * BK);      // whole steps of either K depth
     if (s > 1) g.splitk = s = (int)cdiv(K, g.kchunk);
     if (raw && s == 1) g.splitk = -1;          // single "partial": still written to ws (handled below)
     if (x && x->splitk_used) *x->splitk_used = s;
@@ -344,10 +390,18 @@ static int gemm_ex_impl(hipStream_t st, int64_t M, int64_t N, int64_t K, double 
     const int fam = (bm == 128 && bn == 128) ? PROF_GEMM_128x128 : (bm == 128) ? PROF_GEMM_128x32
                     : (bm == 32) ? PROF_GEMM_32x128 : PROF_GEMM_64x64;
     prof_begin(st, fam);
-    if (bm == 128 && bn == 128) launch_tile<128, 128>(st, g, grid, ak, bk);
-    else if (bm == 128 && bn == 32) launch_tile<128, 32>(st, g, grid, ak, bk);
-    else if (bm == 32 && bn == 128) launch_tile<32, 128>(st, g, grid, ak, bk);
-    else launch_tile<64, 64>(st, g, grid, ak, bk);
+    const int bkt = pick_bkt((int64_t)grid.x * grid.z, g.kchunk);
+    if (bkt == 32) {
+        if (bm == 128 && bn == 128) launch_tile<128, 128, 32>(st, g, grid, ak, bk);
+        else if (bm == 128 && bn == 32) launch_tile<128, 32, 32>(st, g, grid, ak, bk);
+        else if (bm == 32 && bn == 128) launch_tile<32, 128, 32>(st, g, grid, ak, bk);
+        else launch_tile<64, 64, 32>(st, g, grid, ak, bk);
+    } else {
+        if (bm == 128 && bn == 128) launch_tile<128, 128, 16>(st, g, grid, ak, bk);
+        else if (bm == 128 && bn == 32) launch_tile<128, 32, 16>(st, g, grid, ak, bk);
+        else if (bm == 32 && bn == 128) launch_tile<32, 128, 16>(st, g, grid, ak, bk);
+        else launch_tile<64, 64, 16>(st, g, grid, ak, bk);
+    }
     TN_CHECK_LAUNCH("gemm_kernel");
     // algorithmic work of SURVEY.md §8d: 2MNK flops, 8(MK + KN + MN) bytes
     prof_end(st, fam, 2.0 * M * N * K * batch, 8.0 * batch * ((double)M * K + (double)K * N + (double)M * N));

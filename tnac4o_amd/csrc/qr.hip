@@ -16,6 +16,9 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "common.h"
@@ -529,38 +532,38 @@ __global__ __launch_bounds__(256) void diag_qr_kernel(const double* __restrict__
     }
 }
 
-// R[i][j]: 0 left of the diagonal block, Tri inside it, Z^T A to the right.
-__global__ __launch_bounds__(256) void assemble_R_kernel(const double* __restrict__ A, int64_t rs, int64_t cs, int nb,
-                                                         int64_t k, int64_t n, const double* __restrict__ Zbuf,
-                                                         const double* __restrict__ Tri, double* __restrict__ R,
-                                                         int64_t rrs, int64_t rcs) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= k * n) return;
-    const int64_t i = e / n, j = e % n;
-    const int64_t p = i / nb, j0 = p * nb;
-    const int b = (int)((k - j0 < nb) ? k - j0 : nb);
-    const int il = (int)(i - j0);
-    double v = 0.0;
-    if (j >= j0 + b) {
-        const double* z = Zbuf + p * nb * nb;
-        for (int r = 0; r < b; ++r) v += z[r * nb + il] * A[(j0 + r) * rs + j * cs];
-    } else if (j >= j0) {
-        v = Tri[p * nb * nb + il * nb + (j - j0)];
+// R[i][j]: 0 left of the diagonal block, Tri inside it, Z^T A to the right;  Q starts as [Z; 0] (block diagonal Z).
+// Both only wait for diag_qr_kernel, so they share one launch: the first nR workgroups write R, the rest Q.
+__global__ __launch_bounds__(256) void assemble_R_init_Q_kernel(const double* __restrict__ A, int64_t rs, int64_t cs, int nb, int64_t k, int64_t n,
+                                                                const double* __restrict__ Zbuf, const double* __restrict__ Tri,
+                                                                double* __restrict__ R, int64_t rrs, int64_t rcs, unsigned nR,
+                                                                double* __restrict__ Q, int64_t qrs, int64_t qcs, int64_t m, int colfast) {
+    if (blockIdx.x < nR) {
+        const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (e >= k * n) return;
+        const int64_t i = e / n, j = e % n;
+        const int64_t p = i / nb, j0 = p * nb;
+        const int b = (int)((k - j0 < nb) ? k - j0 : nb);
+        const int il = (int)(i - j0);
+        double v = 0.0;
+        if (j >= j0 + b) {
+            const double* z = Zbuf + p * nb * nb;
+            for (int r = 0; r < b; ++r) v += z[r * nb + il] * A[(j0 + r) * rs + j * cs];
+        } else if (j >= j0) {
+            v = Tri[p * nb * nb + il * nb + (j - j0)];
+        }
+        R[i * rrs + j * rcs] = v;
+    } else {
+        const int64_t e = (int64_t)(blockIdx.x - nR) * 256 + threadIdx.x;
+        if (e >= m * k) return;
+        const int64_t i = colfast ? e / k : e % m, j = colfast ? e % k : e / m;
+        double v = 0.0;
+        if (i < k && i / nb == j / nb) {
+            const int64_t p = i / nb;
+            v = Zbuf[p * nb * nb + (i - p * nb) * nb + (j - p * nb)];
+        }
+        Q[i * qrs + j * qcs] = v;
     }
-    R[i * rrs + j * rcs] = v;
-}
-
-__global__ __launch_bounds__(256) void init_Q_kernel(double* __restrict__ Q, int64_t rs, int64_t cs, int64_t m, int64_t k,
-                                                     int nb, const double* __restrict__ Zbuf, int colfast) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= m * k) return;
-    const int64_t i = colfast ? e / k : e % m, j = colfast ? e % k : e / m;
-    double v = 0.0;
-    if (i < k && i / nb == j / nb) {
-        const int64_t p = i / nb;
-        v = Zbuf[p * nb * nb + (i - p * nb) * nb + (j - p * nb)];
-    }
-    Q[i * rs + j * cs] = v;
 }
 
 // out[j] = sum_i A(i,j)^2 for the columns of an (m x n) block (the host takes the maximum: no atomics, nothing to pre-zero)
@@ -763,14 +766,14 @@ static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k,
     const int P = (int)cdiv(k, nb);
     TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, Am.p, rs, cs, nb, k, w.Z, w.Tri));
     TN_CHECK_LAUNCH("diag_qr_kernel");
-    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(assemble_R_kernel, dim3((unsigned)cdiv(k * n, 256)), dim3(256), 0, st, Am.p, rs, cs, nb, k, n, w.Z,
-                       w.Tri, R, rrs, rcs));
-    TN_CHECK_LAUNCH("assemble_R_kernel");
     // --- Q = H_blk1 ... H_blkB [Z; 0]:  Q[J0:, J0:] -= Y_blk (T_blk (Y_blk^T Q[J0:, J0:]))
     const int qcolfast = (qcs == 1) ? 1 : 0;
-    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(init_Q_kernel, dim3((unsigned)cdiv(m * k, 256)), dim3(256), 0, st, Q, qrs, qcs, m, k, nb, w.Z,
-                       qcolfast));
-    TN_CHECK_LAUNCH("init_Q_kernel");
+    {
+        const unsigned nR = (unsigned)cdiv(k * n, 256), nQ = (unsigned)cdiv(m * k, 256);
+        TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(assemble_R_init_Q_kernel, dim3(nR + nQ), dim3(256), 0, st, Am.p, rs, cs, nb, k, n, w.Z, w.Tri, R,
+                           rrs, rcs, nR, Q, qrs, qcs, m, qcolfast));
+        TN_CHECK_LAUNCH("assemble_R_init_Q_kernel");
+    }
     Mat Qm = mat(Q, qrs, qcs);
     for (int bi = nblk - 1; bi >= 0; --bi) {
         const int64_t J0 = (int64_t)bi * nbo;
@@ -778,7 +781,8 @@ static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k,
         const int64_t mb = m - J0, nq = k - J0;
         Mat Yb = sub(Ym, J0, J0), Qb = sub(Qm, J0, J0), Z = mat(w.Zo, nq, 1), Z2 = mat(w.Zo2, nq, 1);
         double* Tb = w.Tblk + (int64_t)bi * QR_NBO_MAX * QR_NBO_MAX;
-        if ((rc = gemm(st, bw, nq, mb, 1.0, tr(Yb), Qb, 0.0, Z, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+        // (the last block meets [Z; 0]: only its top bw rows are non-zero, the product over the rest adds zeros)
+        if ((rc = gemm(st, bw, nq, bi == nblk - 1 ? (int64_t)bw : mb, 1.0, tr(Yb), Qb, 0.0, Z, w.gemm_ws, w.gemm_ws_bytes))) return rc;
         if ((rc = gemm(st, bw, nq, bw, 1.0, mat(Tb, bw, 1), Z, 0.0, Z2))) return rc;
         if ((rc = gemm(st, mb, nq, bw, -1.0, Yb, Z2, 1.0, Qb))) return rc;
     }
@@ -807,9 +811,74 @@ struct LookaheadEvents {
     }
 };
 
+// TN_QR_TRACE=1 (diagnostics): every call is timed synchronously with a pair of events and booked under its shape and kind; the
+// table is printed when the process exits.  Perturbs the run (one synchronisation per factorisation).
+namespace {
+struct QrTrace {
+    bool on;
+    std::mutex mu;
+    std::map<std::tuple<int64_t, int64_t, int, int, int>, std::pair<double, long>> tab;
+    std::map<std::tuple<int64_t, int64_t, int, int, int>, double> ranks;
+    double cat_ms[8] = {0}, cat_rank[8] = {0}, cat_m[8] = {0};
+    long cat_calls[8] = {0};
+    QrTrace() { const char* e = getenv("TN_QR_TRACE"); on = e && e[0] == '1'; }
+    ~QrTrace() {
+        if (!on || tab.empty()) return;
+        std::vector<std::pair<double, std::tuple<int64_t, int64_t, int, int, int>>> v;
+        double tot = 0.0;
+        long calls = 0;
+        for (auto& kv : tab) { v.push_back({kv.second.first, kv.first}); tot += kv.second.first; calls += kv.second.second; }
+        std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first > b.first; });
+        fprintf(stderr, "[tn_qr trace] %zu shapes, %ld calls, %.1f ms in total; m n wantQ truncating pivoted : calls, ms, us/call, mean accepted rank\n", v.size(), calls, tot);
+        const char* cn[8] = {"plain, n <= 32", "plain, n <= 64", "plain, n <= 128", "plain, n > 128", "truncating, unpivoted", "pivoted, m <= 8192", "pivoted, m > 8192", ""};
+        for (int c = 0; c < 7; ++c)
+            fprintf(stderr, "  [%s] %ld calls, %.1f ms, mean rows %.0f, mean accepted rank %.1f\n", cn[c], cat_calls[c], cat_ms[c],
+                    cat_calls[c] ? cat_m[c] / cat_calls[c] : 0.0, cat_calls[c] ? cat_rank[c] / cat_calls[c] : 0.0);
+        for (size_t i = 0; i < v.size() && i < 60; ++i) {
+            auto& k = v[i].second;
+            auto& st = tab[k];
+            fprintf(stderr, "  %6lld %6lld  %d %d %d : %6ld  %8.2f  %8.2f  %7.1f\n", (long long)std::get<0>(k), (long long)std::get<1>(k), std::get<2>(k),
+                    std::get<3>(k), std::get<4>(k), st.second, st.first, 1e3 * st.first / st.second, ranks[k] / st.second);
+        }
+    }
+};
+QrTrace g_qr_trace;
+}  // namespace
+
+static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
+                          int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
+                          int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host);
+
 int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
               int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
               int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host) {
+    if (!g_qr_trace.on)
+        return qr_factor_impl(st, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host, aux, dropped2_host, frob_exit,
+                              pivot_perm_host);
+    thread_local hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!e0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+    (void)hipEventRecord(e0, st);
+    const int rc = qr_factor_impl(st, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host, aux, dropped2_host,
+                                  frob_exit, pivot_perm_host);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::lock_guard<std::mutex> lk(g_qr_trace.mu);
+    const auto key = std::make_tuple(m, n, Q ? 1 : 0, (rank_tol > 0.0 && keff_host) ? 1 : 0, pivot_perm_host ? 1 : 0);
+    auto& ss = g_qr_trace.tab[key];
+    ss.first += ms;
+    ss.second += 1;
+    const double kr = keff_host ? (double)*keff_host : (double)(m < n ? m : n);
+    g_qr_trace.ranks[key] += kr;
+    const int c = pivot_perm_host ? (m > 8192 ? 6 : 5) : (rank_tol > 0.0 && keff_host) ? 4 : (n <= 32 ? 0 : n <= 64 ? 1 : n <= 128 ? 2 : 3);
+    g_qr_trace.cat_ms[c] += ms; g_qr_trace.cat_rank[c] += kr; g_qr_trace.cat_calls[c] += 1; g_qr_trace.cat_m[c] += (double)m;
+    return rc;
+}
+
+static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
+                          int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
+                          int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host) {
     TN_CHECK_ARG(m >= 1 && n >= 1, "empty matrix");
     if (dropped2_host) *dropped2_host = 0.0;
     TN_CHECK_ARG(nb == 32 || nb == 64, "nb must be 32 or 64");
@@ -1039,14 +1108,14 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
     TN_CHECK_LAUNCH("diag_qr_kernel");
     dbg_check(st, w.Z, nb, 1, (int64_t)P * nb, nb, "Z", -1, 0);
     dbg_check(st, w.Tri, nb, 1, (int64_t)P * nb, nb, "Tri", -1, 0);
-    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(assemble_R_kernel, dim3((unsigned)cdiv(k * n, 256)), dim3(256), 0, st, A, rs, cs, nb, k, n, w.Z,
-                       w.Tri, R, rrs, rcs));
-    TN_CHECK_LAUNCH("assemble_R_kernel");
     // --- Q = H_1 ... H_P [Z; 0]
     const int qcolfast = (qcs == 1) ? 1 : 0;
-    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(init_Q_kernel, dim3((unsigned)cdiv(m * k, 256)), dim3(256), 0, st, Q, qrs, qcs, m, k, nb, w.Z,
-                       qcolfast));
-    TN_CHECK_LAUNCH("init_Q_kernel");
+    {
+        const unsigned nR = (unsigned)cdiv(k * n, 256), nQ = (unsigned)cdiv(m * k, 256);
+        TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(assemble_R_init_Q_kernel, dim3(nR + nQ), dim3(256), 0, st, A, rs, cs, nb, k, n, w.Z, w.Tri, R, rrs,
+                           rcs, nR, Q, qrs, qcs, m, qcolfast));
+        TN_CHECK_LAUNCH("assemble_R_init_Q_kernel");
+    }
     Mat Qm = mat(Q, qrs, qcs);
     for (int p = P - 1; p >= 0; --p) {
         const int64_t j0 = (int64_t)p * nb;
@@ -1054,7 +1123,8 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
         const int64_t mp = m - j0, nq = k - j0;
         Mat Qp = sub(Qm, j0, j0), Yp = sub(Ym, j0, j0), Wqp = sub(Wqm, j0, j0);
         Mat Xm = mat(w.X, nq, 1);
-        if ((rc = gemm(st, b, nq, mp, 1.0, tr(Yp), Qp, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;     // Y^T Q
+        // Y^T Q (the last panel meets [Z; 0]: only its top b rows are non-zero, the product over the rest adds zeros)
+        if ((rc = gemm(st, b, nq, p == P - 1 ? (int64_t)b : mp, 1.0, tr(Yp), Qp, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
         if ((rc = gemm(st, mp, nq, b, -1.0, Wqp, Xm, 1.0, Qp))) return rc;                                  // Q -= (Y T) (Y^T Q)
     }
     return 0;

@@ -68,7 +68,7 @@ for name, pat in (('eig_small_kernel', 'eig_small_kernel'), ('absorb_kernel', 'a
 # whole-call traffic: tn_qr 16384 x 1024 = every kernel of the QR (the probe runs exactly one such QR under the counters;
 # gemm<128,128,true,false> also contains the 3 plain 16384x1024x1024 products of the probe, which are subtracted)
 qr_names = ['cq_gram_kernel', 'cq_pass_kernel', 'cq_post_kernel', 'cq_fused_kernel', 'diag_qr_kernel',
-            'assemble_R_kernel', 'init_Q_kernel', 'splitk_reduce_kernel', 'gemm_kernel<32, 128, false, false, false>',
+            'assemble_R_kernel', 'init_Q_kernel', 'assemble_R_init_Q_kernel', 'splitk_reduce_kernel', 'gemm_kernel<32, 128, false, false, false>',
             'gemm_kernel<128, 32, true, false, false>']
 qr_bytes = 0.0
 for k in kern:
