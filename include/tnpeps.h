@@ -290,6 +290,40 @@ int tn_compress_mps(int64_t L, const double* const* sites_host, const int64_t* s
 int tn_argsort_desc(const double* w, int64_t n, int64_t* perm_out, void* stream);
 int tn_weighted_sum(const double* a, const double* b, int64_t n, double* w_out, double* sum_out, void* stream);
 
+/* ---- K8 driver: the beam search of search_ground_state walked in C++ (reference tnac4o.py:429-542) -------------------------
+ * One lattice cell (ny, nx) as the search sees it; every pointer is a DEVICE pointer that stays valid for the call:
+ *   F, dmap, rmap, q, nl, nu, pd, br   the PEPS factor of the cell as tn_peps_factor builds it (tnac4o.py:1562-1672)
+ *   down, right (int64[q])             boundary index a cell state sends to the row below / the cell to its right (:1469-1489)
+ *   Es (q), E1 (q x e1cols), E4 (q x e4cols)   energy tables of tnac4o._update_Eng (:1506-1558); E1 / E4 may be NULL in column / row 0
+ *   left_map / up_map (int64)          Ising: state of the left / upper neighbour -> column of E1 / E4 (that neighbour's right / down
+ *                                      table); NULL: the neighbour's state itself is the column
+ *   A, Dl, p, Dr                       site nx of the boundary MPS above the row (rhoT[ny+1]), C-order; p must equal pd */
+typedef struct tn_beam_cell {
+    const double* F;
+    const int32_t* dmap;
+    const int32_t* rmap;
+    const int64_t* down;
+    const int64_t* right;
+    const double* Es;
+    const double* E1;
+    const double* E4;
+    const int64_t* left_map;
+    const int64_t* up_map;
+    const double* A;
+    int64_t q, nl, nu, pd, br, e1cols, e4cols, Dl, p, Dr;
+} tn_beam_cell;
+/* tn_beam_search: rows ny = 0 .. Ny-1, sites nx = 0 .. Nx-1 (cells[ny * Nx + nx], HOST array), at most M branches, candidates cut at
+ * log2 p <= max + log2_cutoff when has_cut, merge window min_dEng, B > every boundary index (radix of the row keys).  Canonical
+ * order of tnac4o_amd/beam.py (ascending candidate index, lexicographic merge groups, first member of minimal energy, stable top M).
+ * Results (DEVICE, room for M branches): states_out (M x Nx*Ny int16, lattice order of this rotation), energy_out, log2p_out, deg_out;
+ * HOST: *nb_host branches returned, *pd_max_host largest log2 p cut or dropped, *globalmin_host smallest conditional-table flag.
+ * Synchronises `stream` four times per site-step (counts).  Needs Dl * nl <= 2048 at every site (tn_env_rr_batched).
+ * Errors: -3 workspace too small, -6 no candidate left. */
+int64_t tn_beam_search_ws_bytes(int64_t Nx, int64_t Ny, int64_t M, int64_t qmax, int64_t max_env, int64_t max_t1, int64_t max_w);
+int tn_beam_search(int64_t Nx, int64_t Ny, const tn_beam_cell* cells, int64_t M, int has_cut, double log2_cutoff, double min_dEng, int64_t B,
+                   int16_t* states_out, double* energy_out, double* log2p_out, int64_t* deg_out, int64_t* nb_host, double* pd_max_host,
+                   double* globalmin_host, void* ws, int64_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,8 +316,9 @@ def _solve_with(mode, make, **kw):
 
 @pytest.mark.parametrize('case', ['L128_1', 'L128_2_rot1', 'L128_3_chi32', 'L512', 'J124', 'rmf'])
 def test_beam_on_device_bit_identical_to_host_merge(case):
-    """a12 (reference tnac4o.py:437-537: cut-off, merge of equal boundary indices, top-M) resident on the GPU (tnac4o_amd/beam.py:
-    torch.unique on packed keys, tn_merge_groups, stable sorts) against the same canonical order evaluated with numpy on the host:
+    """a12 (reference tnac4o.py:437-537: cut-off, merge of equal boundary indices, top-M) resident on the GPU -- walked by the library
+    (tn_beam_search: hipCUB radix sorts, tn_merge_groups) and by the torch driver of tnac4o_amd/beam.py (torch.unique on rank keys,
+    tn_merge_groups, stable sorts) -- against the same canonical order evaluated with numpy on the host:
     energies, degeneracies, log-probabilities, discarded / negative probabilities and the state table must agree bit for bit --
     also on the degenerate J124 instance (degeneracy 1152, ties inside merge groups) and on the dense RMF path."""
     import tnac4o_amd
@@ -341,10 +342,29 @@ def test_beam_on_device_bit_identical_to_host_merge(case):
         from tnac4o_amd.auxx import synthetic_rmf
         make = lambda: tnac4o_amd.tnac4o(mode='RMF', Nx=6, Ny=5, J=synthetic_rmf(6, 5, 4, 77), beta=1.0)
         kw = dict(M=64, relative_P_cutoff=1e-8, Dmax=16)
-    a = _solve_with('device', make, **kw)
+    from tnac4o_amd import beam
+    calls = []
+    orig = beam.search_native
+
+    def spy(*args, **kwargs):
+        out = orig(*args, **kwargs)
+        calls.append(out is not None)
+        return out
+    beam.search_native = spy
+    try:
+        a = _solve_with('device', make, **kw)                    # tn_beam_search (csrc/beamsearch.hip): the whole loop in the library
+    finally:
+        beam.search_native = orig
+    assert calls == [True], 'the library walk was not the path that ran'
+    saved, beam.NATIVE_BEAM = beam.NATIVE_BEAM, False
+    try:
+        t = _solve_with('device', make, **kw)                    # the torch driver of tnac4o_amd/beam.py (what a beam group runs)
+    finally:
+        beam.NATIVE_BEAM = saved
     b = _solve_with('host', make, **kw)
-    assert np.array_equal(a.energy, b.energy) and np.array_equal(a.probability, b.probability)
-    assert int(a.degeneracy) == int(b.degeneracy) and np.array_equal(a.states, b.states) and a.states.dtype == b.states.dtype
-    assert a.discarded_probability == b.discarded_probability and a.negative_probability == b.negative_probability
+    for x in (a, t):
+        assert np.array_equal(x.energy, b.energy) and np.array_equal(x.probability, b.probability)
+        assert int(x.degeneracy) == int(b.degeneracy) and np.array_equal(x.states, b.states) and x.states.dtype == b.states.dtype
+        assert x.discarded_probability == b.discarded_probability and x.negative_probability == b.negative_probability
     if case == 'J124':
         assert a.energy[0] == pytest.approx(-2309.0, abs=1e-9) and int(a.degeneracy) == 1152

@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libtnpeps.so')
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['api.hip', 'gemm_f64.hip', 'small.hip', 'qr.hip', 'svd.hip', 'absorb.hip', 'misc.hip', 'beam.hip', 'prof.hip', 'tsqr.hip', 'cholqr.hip', 'peps.hip', 'env.hip', 'batch.hip', 'site.hip', 'chain.hip']
+SOURCES = ['api.hip', 'gemm_f64.hip', 'small.hip', 'qr.hip', 'svd.hip', 'absorb.hip', 'misc.hip', 'beam.hip', 'prof.hip', 'tsqr.hip', 'cholqr.hip', 'peps.hip', 'env.hip', 'batch.hip', 'site.hip', 'chain.hip', 'beamsearch.hip']
 
 _i64, _f64, _int, _ptr = C.c_int64, C.c_double, C.c_int, C.c_void_p
 
@@ -72,6 +72,9 @@ SIGNATURES = {
                         C.POINTER(_i64), C.POINTER(_f64), _ptr, _i64, _ptr]),
     'tn_argsort_desc': (_int, [_ptr, _i64, _ptr, _ptr]),
     'tn_weighted_sum': (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr]),
+    'tn_beam_search_ws_bytes': (_i64, [_i64] * 7),
+    'tn_beam_search': (_int, [_i64, _i64, _ptr, _i64, _int, _f64, _f64, _i64, _ptr, _ptr, _ptr, _ptr, C.POINTER(_i64), C.POINTER(_f64),
+                       C.POINTER(_f64), _ptr, _i64, _ptr]),
     'tn_profile_enable': (None, [C.c_uint]),
     'tn_profile_reset': (None, []),
     'tn_profile_sample': (None, [C.c_uint]),
@@ -120,7 +123,7 @@ SHORT_CALLS = ('tn_gemm', 'tn_gemm_ws_bytes', 'tn_qr_ws_bytes', 'tn_svd_ws_bytes
                'tn_balance', 'tn_merge_groups', 'tn_svdvals_async', 'tn_rar', 'tn_rar_ws_bytes', 'tn_env_mix', 'tn_env_mix_ws_bytes',
                'tn_apply_truncation', 'tn_apply_truncation_ws_bytes', 'tn_site_qr_ws_bytes', 'tn_gram_weights', 'tn_argsort_desc', 'tn_weighted_sum', 'tn_rows_norm2', 'tn_gather_scale_rows', 'tn_peps_factor', 'tn_mpo_from_factor', 'tn_last_error')
 _lib = None
-ABI_VERSION = 5          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
+ABI_VERSION = 6          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
 
 
 def lib():

@@ -20,6 +20,9 @@ the branch records, energies (table look-ups), unique of the boundary rows throu
 integers per site-step (kept candidates, groups).  With a beam group (several ranks on one rotation) every rank evaluates the tables
 of its slice of the branches, prunes them against the global maximum and only the surviving (index, log2 p) pairs travel.
 """
+import ctypes as C
+import os
+
 import numpy as np
 import torch
 
@@ -218,4 +221,77 @@ def search_device(solver, M, relative_P_cutoff, min_dEng, beam_group=None):
     solver.probability = prob.cpu().numpy()
     solver.discarded_probability = float(pd_max.item())
     solver.negative_probability = min(float(globalmin.item()), 0)
+    return solver.energy
+
+
+# ---------------------------------------------------------------------------------------------------------------- native driver
+class _Cell(C.Structure):
+    """tn_beam_cell of include/tnpeps.h."""
+    _fields_ = ([(n, C.c_void_p) for n in ('F', 'dmap', 'rmap', 'down', 'right', 'Es', 'E1', 'E4', 'left_map', 'up_map', 'A')]
+                + [(n, C.c_int64) for n in ('q', 'nl', 'nu', 'pd', 'br', 'e1cols', 'e4cols', 'Dl', 'p', 'Dr')])
+
+
+NATIVE_BEAM = os.environ.get('TN_NATIVE_BEAM', '1') != '0'      # TN_NATIVE_BEAM=0: the torch driver above (search_device)
+
+
+def search_native(solver, M, relative_P_cutoff, min_dEng):
+    """search_ground_state's loop over rows and sites in ONE library call (tn_beam_search, csrc/beamsearch.hip): this function only
+    builds the per-cell tables (the PEPS factors on the device, the index and energy tables of tnac4o._update_Eng) and hands over
+    pointers.  Same canonical order and the same arithmetic as search_device, hence the same results bit for bit.  Returns None when
+    a site does not fit the library's walk (tn_env_rr_batched holds Dl x (left PEPS bond) <= 2048 accumulators): the caller then takes
+    search_device."""
+    from ._lib import lib
+    Nx, Ny = solver.Nx, solver.Ny
+    dev = solver.rhoT[0].A[0].device
+    maxidx = int(max(np.max(solver.ld), np.max(solver.lr), 2)) - 1
+    ising = solver.mode == 'Ising'
+    tabs = {(ny, nx): SiteTables(solver, ny, nx, dev) for ny in range(Ny) for nx in range(Nx)}
+    cells = (_Cell * (Nx * Ny))()
+    keep = []                                                            # every tensor a pointer was taken from
+    qmax = max_env = max_t1 = max_w = 1
+    for ny in range(Ny):
+        top = solver.rhoT[ny + 1]
+        for nx in range(Nx):
+            tb = tabs[(ny, nx)]
+            F, dm, rm, pd, br = solver._peps_factor_dev(ny, nx)
+            A = top.A[nx].contiguous()
+            keep += [F, dm, rm, A]
+            q, nl, nu = F.shape
+            Dl, p, Dr = A.shape
+            c = cells[ny * Nx + nx]
+            c.F, c.dmap, c.rmap = F.data_ptr(), dm.data_ptr(), rm.data_ptr()
+            c.down, c.right, c.Es = tb.down.data_ptr(), tb.right.data_ptr(), tb.Es.data_ptr()
+            c.E1 = tb.E1.data_ptr() if nx > 0 else None
+            c.E4 = tb.E4.data_ptr() if ny > 0 else None
+            c.left_map = tabs[(ny, nx - 1)].right.data_ptr() if (ising and nx > 0) else None
+            c.up_map = tabs[(ny - 1, nx)].down.data_ptr() if (ising and ny > 0) else None
+            c.A = A.data_ptr()
+            c.q, c.nl, c.nu, c.pd, c.br = q, nl, nu, pd, br
+            c.e1cols = tb.E1.shape[1] if tb.E1.dim() == 2 else 1
+            c.e4cols = tb.E4.shape[1] if tb.E4.dim() == 2 else 1
+            c.Dl, c.p, c.Dr = Dl, p, Dr
+            if Dl * nl > 2048 or q > 32767:
+                return None
+            qmax, max_env = max(qmax, q), max(max_env, Dl * nl, Dr * br)
+            max_t1, max_w = max(max_t1, p * Dr), max(max_w, nl * pd * br * nu)
+    L = lib()
+    wsb = int(L.tn_beam_search_ws_bytes(Nx, Ny, M, qmax, max_env, max_t1, max_w))
+    ws = ops.workspace(wsb, 3)
+    states = torch.empty((M, Nx * Ny), dtype=torch.int16, device=dev)
+    Eng = torch.empty(M, dtype=torch.float64, device=dev)
+    prob = torch.empty(M, dtype=torch.float64, device=dev)
+    deg = torch.empty(M, dtype=torch.int64, device=dev)
+    nb, pdm, gmin = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
+    has_cut = relative_P_cutoff > 0
+    ops.check(L.tn_beam_search(Nx, Ny, C.cast(cells, C.c_void_p), M, 1 if has_cut else 0, float(np.log2(relative_P_cutoff)) if has_cut else 0.0,
+                               float(min_dEng), maxidx + 1, states.data_ptr(), Eng.data_ptr(), prob.data_ptr(), deg.data_ptr(), C.byref(nb),
+                               C.byref(pdm), C.byref(gmin), ws.data_ptr(), wsb, ops._stream()))
+    n = int(nb.value)
+    solver.energy = Eng[:n].cpu().numpy()
+    solver.degeneracy = int(deg[0].item())
+    solver.states = states[:n].cpu().numpy().astype(solver.indtype)[:, solver.order]
+    solver.probability = prob[:n].cpu().numpy()
+    solver.discarded_probability = float(pdm.value)
+    solver.negative_probability = min(float(gmin.value), 0)
+    del keep
     return solver.energy

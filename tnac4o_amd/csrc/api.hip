@@ -73,7 +73,7 @@ using namespace tn;
 
 extern "C" {
 
-int tn_version(void) { return 5; }
+int tn_version(void) { return 6; }
 
 #ifndef TN_SRC_HASH
 #define TN_SRC_HASH "unknown"

@@ -647,12 +647,18 @@ class tnac4o:
             self._setup_rhoT(**kw_sweep)
         else:
             self._setup_rhoT_shared(beam_group, **kw_sweep)
-        # TN_BEAM: 'device' (default) = the beam step resident on the GPU (tnac4o_amd/beam.py); 'host' = the same canonical order
+        # TN_BEAM: 'device' (default) = the beam step resident on the GPU (tn_beam_search / tnac4o_amd/beam.py); 'host' = the same canonical order
         # with the bookkeeping in numpy (used whenever a droplet recorder or a trace wants the intermediate tables on the host);
         # 'numpy' = the host path in numpy's own (unspecified) argpartition / argsort order, as the reference happens to run
         beam_mode = os.environ.get('TN_BEAM', 'device')
         if beam_mode == 'device' and recorder is None and trace is None:
             from . import beam
+            # one rank on the rotation: the whole loop in the library (tn_beam_search); a beam group shares the site-steps through
+            # torch.distributed and keeps the torch driver
+            if beam_group is None and beam.NATIVE_BEAM:
+                E = beam.search_native(self, M, relative_P_cutoff, min_dEng)
+                if E is not None:
+                    return E
             return beam.search_device(self, M, relative_P_cutoff, min_dEng, beam_group=beam_group)
         canonical = beam_mode != 'numpy'
         Nx, Ny = self.Nx, self.Ny
