@@ -72,7 +72,9 @@ int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb);
  * method 0: iterated Cholesky-QR with deferral (csrc/cholqr.hip, what tn_qr uses); 1: Householder TSQR (csrc/tsqr.hip).
  * state9_host / dev_host (both or neither; method 0; synchronises the stream): {ticket counter, done, final_next, passes applied,
  * input exponent, refill mask, deferred pivots, refilled columns, Householder fallback taken} and max|X^T X - I| before each pass.
- * tn_panel_stats: process-wide DIAGNOSTIC counters since the last reset, 16 words: {panels, substitution passes applied, deferred pivots,
+ * tn_panel_stats_stream: DIAGNOSTIC counters of the panels launched on `stream` since its last reset (the library keeps them per
+ * stream, so that concurrent chains do not mix their counts; streams beyond the 64th share one slot); tn_panel_stats: their sum
+ * over all streams (reset clears all).  16 words: {panels, substitution passes applied, deferred pivots,
  * refilled columns, Householder fallbacks, panels with >= 3 passes, panels with >= 4 passes, panel elements x passes applied by the
  * six-launch chain, the same for the single-launch form, panels handled by the single-launch form, 0...}.  They feed bench.py's
  * accounting of the work the passes really did and nothing else; no result depends on them. */
@@ -80,6 +82,7 @@ int64_t tn_panel_orth_ws_bytes(int64_t nrows, int b);
 int tn_panel_orth(const double* X, int64_t rs, int64_t cs, int64_t nrows, int b, double* Y, int64_t yrs, int64_t ycs, int method,
                   int* state9_host, double* dev_host, void* ws, int64_t ws_bytes, void* stream);
 int tn_panel_stats(uint64_t* out16_host, int reset);
+int tn_panel_stats_stream(uint64_t* out16_host, int reset, void* stream);
 /* Strided batch of `batch` equally shaped QR problems (the rotations of examples/e06:97-109 at one site): item i
  * at A + i*bsA, Q + i*bsQ, R + i*bsR, keff_host[i].  ws_bytes >= batch * roundup(tn_qr_ws_bytes(m,n,nb), 256).  A factorisation
  * is a chain of latency-bound single-workgroup kernels, so the items are made CONCURRENT rather than fused: item i is enqueued on

@@ -652,6 +652,35 @@ def test_panel_single_launch_bit_identical_to_chain(ops):
     assert n >= 12
 
 
+def test_panel_statistics_are_kept_per_stream(ops):
+    """tn_panel_stats_stream: the diagnostic counters of the panel step belong to the launching stream (concurrent chains do not mix
+    their counts); tn_panel_stats is their sum over the streams."""
+    g = torch.Generator(device='cpu').manual_seed(3)
+    A = torch.randn(1024, 96, dtype=torch.float64, generator=g).cuda()
+    B = torch.randn(2048, 64, dtype=torch.float64, generator=g).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ops.panel_stats(reset=True)
+    with torch.cuda.stream(s1):
+        ops.qr(A)
+        ops.qr(A)
+    with torch.cuda.stream(s2):
+        ops.qr(B)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        st1 = ops.panel_stats(stream=True)
+    with torch.cuda.stream(s2):
+        st2 = ops.panel_stats(stream=True)
+    tot = ops.panel_stats()
+    assert st1['panels'] == 6 and st2['panels'] == 2 and tot['panels'] == 8
+    for k in ops.PANEL_STAT_KEYS:
+        assert st1[k] + st2[k] == tot[k], k
+    with torch.cuda.stream(s1):
+        ops.panel_stats(reset=True, stream=True)               # resetting one stream leaves the other alone
+        assert ops.panel_stats(stream=True)['panels'] == 0
+    assert ops.panel_stats()['panels'] == 2
+
+
 def test_qr_single_launch_panels_bit_identical_to_chain(ops):
     """tn_qr with the single-launch panel step (orthonormalisation + Householder reconstruction + reflector products in ONE
     kernel per panel) against the six-launch chain: Q and R bit-identical on tall, wide, ragged, rank-deficient and graded

@@ -28,6 +28,7 @@ SIGNATURES = {
     'tn_panel_orth_ws_bytes': (_i64, [_i64, _int]),
     'tn_panel_orth': (_int, [_ptr, _i64, _i64, _i64, _int, _ptr, _i64, _i64, _int, C.POINTER(_int), C.POINTER(_f64), _ptr, _i64, _ptr]),
     'tn_panel_stats': (_int, [C.POINTER(C.c_uint64), _int]),
+    'tn_panel_stats_stream': (_int, [C.POINTER(C.c_uint64), _int, _ptr]),
     'tn_qr_batched': (_int, [_ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _i64, _i64, _int, _f64, C.POINTER(_i64), _i64, _i64, _i64,
                       _i64, _ptr, _i64, _ptr, C.POINTER(_ptr), _int]),
     'tn_svd_trunc': (_int, [_ptr, _i64, _i64, _i64, _i64, _i64, _f64, _ptr, _i64, _i64, _ptr, _ptr, _i64, _i64,

@@ -181,7 +181,11 @@ int tn_panel_orth(const double* X, int64_t rs, int64_t cs, int64_t nrows, int b,
 }
 int tn_panel_stats(uint64_t* out16_host, int reset) {
     TN_CHECK_ARG(out16_host, "null output");
-    return cholqr_stats((unsigned long long*)out16_host, reset);
+    return cholqr_stats((unsigned long long*)out16_host, reset, nullptr, 1);
+}
+int tn_panel_stats_stream(uint64_t* out16_host, int reset, void* stream) {
+    TN_CHECK_ARG(out16_host, "null output");
+    return cholqr_stats((unsigned long long*)out16_host, reset, (hipStream_t)stream, 0);
 }
 
 int tn_svd_trunc(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol, double* U,

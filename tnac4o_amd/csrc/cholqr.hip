@@ -28,6 +28,9 @@
 // deadlock.  A launch that finds the panel converged returns at once (~3 us).
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+
 #include "common.h"
 
 // -DTN_CLOCKS: thread 0 of the last workgroup of a launch records the 100 MHz wall clock at phase boundaries (diagnostics only)
@@ -137,23 +140,27 @@ __device__ __forceinline__ void cq_block_gram(const double* T, double* S, double
     for (int e = tid; e < CQ_PART; e += 256) cq_st(part + e, (S[e] + S[CQ_PART + e]) + (S[2 * CQ_PART + e] + S[3 * CQ_PART + e]));
 }
 
-// process-wide diagnostic counters (tn_panel_stats), one 64-bit word each -- no packed sub-fields that could carry into each other:
+// diagnostic counters (tn_panel_stats / tn_panel_stats_stream), kept PER STREAM -- slot of the launching stream, CQ_STAT_SLOTS for the
+// streams beyond that many; concurrent chains do not mix their counts -- one 64-bit word each, no packed sub-fields that could carry
+// into each other:
 //   [0] panels  [1] substitution passes applied  [2] deferred pivots  [3] refilled columns  [4] Householder fallbacks
 //   [5] panels with >= 3 passes  [6] panels with >= 4 passes  [7] panel elements x passes applied by the six-launch chain (each such
 //   pass reads and writes the panel: 16 bytes per element)  [8] the same for the single-launch form (the tile stays in LDS: flops only)
 //   [9] panels handled by the single-launch form
-__device__ unsigned long long cq_stats[16];
+constexpr int CQ_STAT_SLOTS = 64;
+__device__ unsigned long long cq_stats[(CQ_STAT_SLOTS + 1) * 16];
 // one thread, once per panel; the adds do not return a value, so the wave does not wait for them
-__device__ __forceinline__ void cq_count(int passes, int ndefer, int nrefill, bool fallback, long long elems, bool single_launch = false) {
-    atomicAdd(&cq_stats[0], 1ull);
-    atomicAdd(&cq_stats[1], (unsigned long long)passes);
-    atomicAdd(&cq_stats[single_launch ? 8 : 7], (unsigned long long)passes * (unsigned long long)elems);
-    if (single_launch) atomicAdd(&cq_stats[9], 1ull);
-    if (ndefer > 0) atomicAdd(&cq_stats[2], (unsigned long long)ndefer);
-    if (nrefill > 0) atomicAdd(&cq_stats[3], (unsigned long long)nrefill);
-    if (fallback) atomicAdd(&cq_stats[4], 1ull);
-    if (passes >= 3) atomicAdd(&cq_stats[5], 1ull);
-    if (passes >= 4) atomicAdd(&cq_stats[6], 1ull);
+__device__ __forceinline__ void cq_count(int slot, int passes, int ndefer, int nrefill, bool fallback, long long elems, bool single_launch = false) {
+    unsigned long long* cs = cq_stats + slot * 16;
+    atomicAdd(&cs[0], 1ull);
+    atomicAdd(&cs[1], (unsigned long long)passes);
+    atomicAdd(&cs[single_launch ? 8 : 7], (unsigned long long)passes * (unsigned long long)elems);
+    if (single_launch) atomicAdd(&cs[9], 1ull);
+    if (ndefer > 0) atomicAdd(&cs[2], (unsigned long long)ndefer);
+    if (nrefill > 0) atomicAdd(&cs[3], (unsigned long long)nrefill);
+    if (fallback) atomicAdd(&cs[4], 1ull);
+    if (passes >= 3) atomicAdd(&cs[5], 1ull);
+    if (passes >= 4) atomicAdd(&cs[6], 1ull);
 }
 
 // 256-thread sum through LDS (two barriers); red: >= 4 doubles
@@ -384,7 +391,7 @@ __device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, i
 // Gs: LDS 32 x 33, Rs: LDS 32 x 32 (16-byte aligned).  pass = number of passes applied to the panel whose Gram matrix this is.  Returns 1 when the caller
 // decision (0: factor again, 1: converged, 2: out of passes; all threads get the same value).
 __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int nblk, int b, int pass, CqState* stt, double* Rg, double* Gs,
-                                       double* Rs, int maxpass, int tid, long long elems) {
+                                       double* Rs, int maxpass, int tid, long long elems, int slot) {
     __shared__ int s_dec;
     const int lane = tid & 63;
     // exponents of pass 0: block weights 4^(e_blk - emax); every wave finds emax itself (no barrier)
@@ -456,7 +463,7 @@ __device__ __forceinline__ int cq_tail(const double* part, const int* bexp, int 
                 stt->final_next = 0;
                 stt->dead = 0u;
                 if (dec == 2) stt->fallback = 1;
-                cq_count(pass, stt->ndefer_total, stt->nrefill_total, dec == 2, elems);
+                cq_count(slot, pass, stt->ndefer_total, stt->nrefill_total, dec == 2, elems);
             }
         } else {
             // ---- Cholesky, right-looking.  Lane k holds column k of the trailing matrix; row j of R (lane k: R[j][k]) goes
@@ -560,7 +567,7 @@ __device__ __forceinline__ int cq_load_scaled_tile(const double* __restrict__ X,
 
 // ---- pass 0: Gram matrix of the input panel -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__ X, int64_t rs, int64_t cs, int64_t nrows, int b, int nblk,
-                                                      double* part, int* bexp, CqState* stt, double* Rg) {
+                                                      double* part, int* bexp, CqState* stt, double* Rg, int slot) {
     __shared__ double T[CQ_RB * CQ_P];
     __shared__ double Gs[32 * CQ_P];
     __shared__ __attribute__((aligned(16))) double Rs[32 * 32];
@@ -581,7 +588,7 @@ __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__
     __threadfence();
     if (tid == 0) { stt->counter = 0; stt->done = 0; stt->pass = 0; stt->ndefer_total = 0; stt->nrefill_total = 0; stt->fallback = 0; }
     __syncthreads();
-    cq_tail(part, bexp, nblk, b, 0, stt, Rg, Gs, Rs, CQ_MAXPASS, tid, (long long)nrows * b);
+    cq_tail(part, bexp, nblk, b, 0, stt, Rg, Gs, Rs, CQ_MAXPASS, tid, (long long)nrows * b, slot);
 }
 
 // X <- X R^-1 on the 256-row tile T (LDS), row tid; Rs (LDS, 16-byte aligned): R row-major (1024) + reciprocal diagonal (32).
@@ -658,7 +665,7 @@ __device__ __forceinline__ void cq_store_tile(const double* T, double* Y, int64_
 // first: the source is the caller's panel (scaled by 2^-emax on the way in), later passes work in place on Y.
 __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_t srs, int64_t scs, double* Y, int64_t rs, int64_t cs,
                                                       int64_t nrows, int b, int nblk, int first, int launch_no, double* part, CqState* stt,
-                                                      double* Rg, uint64_t seed, double* lu, double* Tp, int maxpass) {
+                                                      double* Rg, uint64_t seed, double* lu, double* Tp, int maxpass, int slot) {
     __shared__ double T[CQ_RB * CQ_P];
     __shared__ double Gs[32 * CQ_P];
     __shared__ __attribute__((aligned(16))) double Rs[32 * 32 + 32 + 32 * 32];      // factor + reciprocals | Cholesky rows of the tail
@@ -745,12 +752,12 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
     if (fin) {
         if (tid == 0) {
             stt->done = 1; stt->final_next = 0; stt->dead = 0u;
-            cq_count(launch_no, stt->ndefer_total, stt->nrefill_total, false, (long long)nrows * b);
+            cq_count(slot, launch_no, stt->ndefer_total, stt->nrefill_total, false, (long long)nrows * b);
         }
         __syncthreads();
     } else {
         __syncthreads();
-        dec = cq_tail(part, nullptr, nblk, b, launch_no, stt, Rg, Gs, Rs + 1056, maxpass, tid, (long long)nrows * b);
+        dec = cq_tail(part, nullptr, nblk, b, launch_no, stt, Rg, Gs, Rs + 1056, maxpass, tid, (long long)nrows * b, slot);
     }
     CQ_CLK(7);
     if (launch_no <= 2) CQ_CLK_DUMP(12 * (launch_no - 1));
@@ -933,7 +940,7 @@ __device__ __forceinline__ bool cq_grid_barrier(int* counter, int target, int* s
 // (0 factor again, 1 converged, 2 out of passes), [1] final_next, [2] dead-column mask, [3] emax (pass 0).  Only `writer`
 // (workgroup 0) keeps the panel's state block and the statistics.  Ends with a barrier.
 __device__ __forceinline__ void cq_tail_fused(const double* part, const int* bexp, int nblk, int b, int pass, CqState* stt, bool writer, double* Gs,
-                                              double* Rf, int* s_out, int maxpass, int tid, long long elems) {
+                                              double* Rf, int* s_out, int maxpass, int tid, long long elems, int slot) {
     const int lane = tid & 63;
     int emax = 0;
     if (bexp) {
@@ -1003,7 +1010,7 @@ __device__ __forceinline__ void cq_tail_fused(const double* part, const int* bex
                     stt->final_next = 0;
                     stt->dead = 0u;
                     if (dec == 2) stt->fallback = 1;
-                    cq_count(pass, stt->ndefer_total, stt->nrefill_total, dec == 2, elems, true);
+                    cq_count(slot, pass, stt->ndefer_total, stt->nrefill_total, dec == 2, elems, true);
                 }
             }
         }
@@ -1068,7 +1075,7 @@ __device__ __forceinline__ void cq_tail_fused(const double* part, const int* bex
 __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t xrs, int64_t xcs, double* Y, int64_t rs, int64_t cs, int64_t nrows,
                                                        int b, int nblk, double* part, int* bexp, double* topblk, CqState* stt, int base,
                                                        uint64_t seed, double* lu_all, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq,
-                                                       int maxpass) {
+                                                       int maxpass, int slot) {
     __shared__ double T[CQ_RB * CQ_P];
     __shared__ __attribute__((aligned(16))) double GR[3 * 1024];      // Gram 32 x 33 | factor 1024 + 32; later the three S matrices of the post step
     __shared__ __attribute__((aligned(16))) double scr[4 * 32 * 33 + 64];
@@ -1096,7 +1103,7 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
         alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid);
         int dec = 0, tlast = 0;
         if (alive) {
-            cq_tail_fused(part, bexp, nblk, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b);
+            cq_tail_fused(part, bexp, nblk, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot);
             dec = s_out[0];
             const int emax = s_out[3];
             const double scl0 = (ex > -2000 && emax > -2000) ? ldexp(1.0, ex - emax) : 0.0;     // tile is 2^-ex X; the passes work on 2^-emax X
@@ -1121,11 +1128,11 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
                     dec = 1;
                     if (writer && tid == 0) {
                         stt->done = 1; stt->final_next = 0; stt->dead = 0u;
-                        cq_count(t, stt->ndefer_total, stt->nrefill_total, false, (long long)nrows * b, true);
+                        cq_count(slot, t, stt->ndefer_total, stt->nrefill_total, false, (long long)nrows * b, true);
                     }
                     break;
                 }
-                cq_tail_fused(pt, nullptr, nblk, b, t, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b);
+                cq_tail_fused(pt, nullptr, nblk, b, t, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot);
                 dec = s_out[0];
             }
         }
@@ -1196,6 +1203,18 @@ static bool cq_fused_enabled() {
     return !(e && e[0] == '0');
 }
 
+// statistics slot of a stream (first come, first served; the streams beyond CQ_STAT_SLOTS share the last slot)
+static std::mutex cq_slot_mu;
+static std::map<hipStream_t, int> cq_slot_of;
+static int cq_stat_slot(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(cq_slot_mu);
+    auto it = cq_slot_of.find(st);
+    if (it != cq_slot_of.end()) return it->second;
+    const int s = (int)cq_slot_of.size() < CQ_STAT_SLOTS ? (int)cq_slot_of.size() : CQ_STAT_SLOTS;
+    cq_slot_of.emplace(st, s);
+    return s;
+}
+
 // The state block at the head of the workspace must be zero before the first panel of a call (the kernels leave it clean).
 int cholqr_reset(hipStream_t st, void* ws) {
     const hipError_t e = hipMemsetAsync(ws, 0, CQ_STATE_BYTES, st);
@@ -1225,12 +1244,13 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
     double* topblk = (double*)p;
     // TN_PANEL_MAXPASS (1 .. CQ_MAXPASS): fewer substitution passes, to drive the Householder fallback in tests
     static const int maxpass = [] { const char* e = getenv("TN_PANEL_MAXPASS"); const int v = e ? atoi(e) : CQ_MAXPASS; return v >= 1 && v <= CQ_MAXPASS ? v : CQ_MAXPASS; }();
+    const int slot = cq_stat_slot(st);
     if (fits && fused_base && cq_fused_enabled()) {
         // one launch for the whole chain.  Algorithmic bytes: the panel in, the reflectors (and W, Wq) out -- the tile never
         // leaves LDS in between; flops: Gram + post at launch time, the passes are booked from the device counter (cq_stats[3])
         prof_begin(st, PROF_TSQR);
         hipLaunchKernelGGL(cq_fused_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, part, bexp, topblk, stt,
-                           *fused_base, seed, lu, Tp, W, wrs, wcs, Wq, maxpass);
+                           *fused_base, seed, lu, Tp, W, wrs, wcs, Wq, maxpass, slot);
         TN_CHECK_LAUNCH("cq_fused_kernel");
         *fused_base += (maxpass + 1) * nblk;
         const double e = (double)nrows * b;
@@ -1238,13 +1258,13 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
         return 0;
     }
     prof_begin(st, PROF_TSQR);
-    hipLaunchKernelGGL(cq_gram_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, nrows, b, nblk, part, bexp, stt, Rg);
+    hipLaunchKernelGGL(cq_gram_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, nrows, b, nblk, part, bexp, stt, Rg, slot);
     TN_CHECK_LAUNCH("cq_gram_kernel");
     prof_end(st, PROF_TSQR, 2.0 * nrows * b * b, 8.0 * nrows * b);
     for (int t = 1; t <= maxpass; ++t) {
         prof_begin(st, PROF_TSQR);
         hipLaunchKernelGGL(cq_pass_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, t == 1 ? 1 : 0, t, part, stt,
-                           Rg, seed + 0x9E3779B97F4A7C15ULL * (uint64_t)t, lu, Tp, maxpass);
+                           Rg, seed + 0x9E3779B97F4A7C15ULL * (uint64_t)t, lu, Tp, maxpass, slot);
         TN_CHECK_LAUNCH("cq_pass_kernel");
         // (the passes that really run are booked from the device counter cq_stats[7] by the caller of tn_panel_stats:
         //  3 n b^2 flops and 16 n b bytes per applied pass; a launch that finds the panel converged moves nothing)
@@ -1273,14 +1293,28 @@ int cholqr_debug_state(hipStream_t st, const void* ws, int* ints9, double* dev_h
     for (int i = 0; i <= CQ_MAXPASS + 1; ++i) dev_hist[i] = h.dev_hist[i];
     return 0;
 }
-int cholqr_stats(unsigned long long* out16, int reset) {
-    unsigned long long raw[16];
-    hipError_t e = hipMemcpyFromSymbol(raw, HIP_SYMBOL(cq_stats), 16 * sizeof(unsigned long long));
+// st_or_null: the counters of that stream only (as far as it has a slot of its own); NULL with all_streams: the sum over all slots
+int cholqr_stats(unsigned long long* out16, int reset, hipStream_t st_or_null, int all_streams) {
+    static unsigned long long raw[(CQ_STAT_SLOTS + 1) * 16];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    hipError_t e = hipMemcpyFromSymbol(raw, HIP_SYMBOL(cq_stats), sizeof(raw));
     if (e != hipSuccess) return hip_fail(e, "read panel statistics");
-    for (int i = 0; i < 16; ++i) out16[i] = raw[i];
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    if (all_streams) {
+        for (int s = 0; s <= CQ_STAT_SLOTS; ++s)
+            for (int i = 0; i < 16; ++i) out16[i] += raw[s * 16 + i];
+        if (reset) {
+            memset(raw, 0, sizeof(raw));
+            if ((e = hipMemcpyToSymbol(HIP_SYMBOL(cq_stats), raw, sizeof(raw))) != hipSuccess) return hip_fail(e, "reset panel statistics");
+        }
+        return 0;
+    }
+    const int slot = cq_stat_slot(st_or_null);
+    for (int i = 0; i < 16; ++i) out16[i] = raw[slot * 16 + i];
     if (reset) {
         unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if ((e = hipMemcpyToSymbol(HIP_SYMBOL(cq_stats), z, sizeof(z))) != hipSuccess) return hip_fail(e, "reset panel statistics");
+        if ((e = hipMemcpyToSymbol(HIP_SYMBOL(cq_stats), z, sizeof(z), (size_t)slot * sizeof(z))) != hipSuccess) return hip_fail(e, "reset panel statistics");
     }
     return 0;
 }

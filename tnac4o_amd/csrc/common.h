@@ -172,6 +172,6 @@ int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t 
 int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws,
                  int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq, int* fused_base);
 int cholqr_debug_state(hipStream_t st, const void* ws, int* ints9, double* dev_hist);
-int cholqr_stats(unsigned long long* out16, int reset);
+int cholqr_stats(unsigned long long* out16, int reset, hipStream_t st_or_null, int all_streams);
 
 }  // namespace tn

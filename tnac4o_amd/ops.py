@@ -243,10 +243,14 @@ PANEL_STAT_KEYS = ('panels', 'substitution_passes', 'deferred_pivots', 'refilled
                    'panels_with_4_or_more_passes', 'pass_elements_six_launch_chain', 'pass_elements_single_launch', 'single_launch_panels')
 
 
-def panel_stats(reset=False):
-    """Process-wide diagnostic counters of the Cholesky-QR panel step since the last reset (tn_panel_stats): dict."""
+def panel_stats(reset=False, stream=False):
+    """Diagnostic counters of the Cholesky-QR panel step since the last reset: dict.  stream=False: summed over all streams
+    (tn_panel_stats); stream=True: of the panels launched on the current stream only (tn_panel_stats_stream)."""
     st = (C.c_uint64 * 16)()
-    check(lib().tn_panel_stats(st, 1 if reset else 0))
+    if stream:
+        check(lib().tn_panel_stats_stream(st, 1 if reset else 0, _stream()))
+    else:
+        check(lib().tn_panel_stats(st, 1 if reset else 0))
     return {k: int(st[i]) for i, k in enumerate(PANEL_STAT_KEYS)}
 
 
