@@ -652,6 +652,29 @@ def test_panel_single_launch_bit_identical_to_chain(ops):
     assert n >= 12
 
 
+def test_hard_panels_of_a_real_sweep(ops):
+    """tests/golden/g12_hard_panels.npz: the panels of tn_qr that needed FOUR substitution passes in the boundary-MPS sweep of the
+    headline instance (chimera L = 2048, chi = 64, seed 20260004; 11 of 6 025 panels, the nine of <= 4096 rows kept; condition numbers
+    1e16 .. 1e23; captured with tools/capture_panels.py).  Both forms of the panel step must still take them in four passes without
+    the Householder fallback, return an orthonormal basis that spans the panel, and agree bit for bit."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g12_hard_panels.npz'))
+    n = 0
+    while 'panel%d' % n in g:
+        Xh = g['panel%d' % n]
+        X = torch.as_tensor(Xh).cuda()
+        Y1, st1, dev1 = _with_env('TN_PANEL_FUSED', '1', lambda: ops.panel_orth(X, 0, state=True))
+        Y0, st0, dev0 = _with_env('TN_PANEL_FUSED', '0', lambda: ops.panel_orth(X, 0, state=True))
+        assert torch.equal(Y0, Y1), n
+        assert st0[3] == st1[3] == int(g['passes%d' % n][0]) and st0[8] == st1[8] == 0, (n, st0, st1)
+        Y = Y1.cpu().numpy()
+        b = Xh.shape[1]
+        assert np.abs(Y.T @ Y - np.eye(b)).max() < 1e-13, n
+        assert np.linalg.norm(Xh - Y @ (Y.T @ Xh)) <= 1e-13 * np.linalg.norm(Xh), n
+        n += 1
+    assert n == 9
+
+
 def test_panel_statistics_are_kept_per_stream(ops):
     """tn_panel_stats_stream: the diagnostic counters of the panel step belong to the launching stream (concurrent chains do not mix
     their counts); tn_panel_stats is their sum over the streams."""

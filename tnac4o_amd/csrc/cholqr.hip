@@ -30,6 +30,7 @@
 
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -1221,6 +1222,37 @@ int cholqr_reset(hipStream_t st, void* ws) {
     return e == hipSuccess ? 0 : hip_fail(e, "memset panel state");
 }
 
+// TN_PANEL_CAPTURE=<directory> (diagnostics; tools/capture_panels.py): after every panel the stream is synchronised, and the input
+// of a panel that needed at least TN_PANEL_CAPTURE_MIN (4) substitution passes and has at most TN_PANEL_CAPTURE_MAXROWS (4096) rows is
+// written to <directory>/panel_<seq>_<rows>x<b>_p<passes>.f64 (row-major doubles) -- the hard panels of a real sweep, kept as
+// regression inputs under tests/golden/.
+__global__ __launch_bounds__(256) void cq_capture_kernel(const double* X, int64_t rs, int64_t cs, int64_t nrows, int b, double* out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < nrows * b) out[e] = X[(e / b) * rs + (e % b) * cs];
+}
+static void cq_capture(hipStream_t st, const double* X, int64_t irs, int64_t ics, int64_t nrows, int b, const void* ws) {
+    static const char* dir = getenv("TN_PANEL_CAPTURE");
+    if (!dir || !dir[0]) return;
+    static const int min_pass = [] { const char* e = getenv("TN_PANEL_CAPTURE_MIN"); return e ? atoi(e) : 4; }();
+    static const int64_t max_rows = [] { const char* e = getenv("TN_PANEL_CAPTURE_MAXROWS"); return e ? atoll(e) : 4096ll; }();
+    static std::mutex mu;
+    static int seq = 0;
+    CqState h;
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(&h, ws, sizeof(CqState), hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (h.pass < min_pass || nrows > max_rows) return;
+    double* d = nullptr;
+    if (hipMalloc(&d, (size_t)nrows * b * 8) != hipSuccess) return;
+    hipLaunchKernelGGL(cq_capture_kernel, dim3((unsigned)cdiv(nrows * b, 256)), dim3(256), 0, st, X, irs, ics, nrows, b, d);
+    std::vector<double> host((size_t)nrows * b);
+    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(host.data(), d, host.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(mu);
+        char path[1024];
+        snprintf(path, sizeof(path), "%s/panel_%05d_%lldx%d_p%d.f64", dir, seq++, (long long)nrows, b, h.pass);
+        if (FILE* f = fopen(path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+    }
+    (void)hipFree(d);
+}
+
 // One panel step.  Y (nrows x b, strides rs/cs) receives an orthonormal basis Q1 of the column space of the panel X (read
 // only; must not overlap Y).  With reconstruct != 0 the launches go on to the Householder reconstruction (Ballard et al.):
 // on return Y holds the unit lower trapezoidal reflectors, Tp (b x b, pitch b) their T factor, W = Y T^T (nrows x b, strides
@@ -1255,6 +1287,7 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
         *fused_base += (maxpass + 1) * nblk;
         const double e = (double)nrows * b;
         prof_end(st, PROF_TSQR, (2.0 + (reconstruct ? (Wq ? 6.0 : 4.0) : 0.0)) * e * b, (reconstruct ? (Wq ? 32.0 : 24.0) : 16.0) * e);
+        cq_capture(st, X, irs, ics, nrows, b, ws);
         return 0;
     }
     prof_begin(st, PROF_TSQR);
@@ -1274,6 +1307,7 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
     hipLaunchKernelGGL(cq_post_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, stt, lu, Tp, W, wrs, wcs, Wq);
     TN_CHECK_LAUNCH("cq_post_kernel");
     prof_end(st, PROF_TSQR, reconstruct ? (Wq ? 6.0 : 4.0) * nrows * b * b : 0.0, reconstruct ? (Wq ? 32.0 : 24.0) * nrows * b : 0.0);
+    cq_capture(st, X, irs, ics, nrows, b, ws);
     return 0;
 }
 
