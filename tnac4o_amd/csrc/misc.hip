@@ -108,8 +108,43 @@ __global__ __launch_bounds__(256) void scale_by_blockmax_kernel(double* __restri
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) x[i] *= inv;
 }
 
+// ... and in ONE launch for up to 32768 values (the triangular factors and centre matrices of a sweep): a single workgroup of 1024
+// threads keeps its 32 values per thread in registers between the maximum and the scaling (same result bit for bit).
+__global__ __launch_bounds__(1024) void normalize_small_kernel(double* __restrict__ x, int n, double* __restrict__ out2) {
+    __shared__ unsigned long long red[16];
+    const int tid = threadIdx.x;
+    double v[32];
+    unsigned long long m = 0ULL;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const int i = tid + 1024 * u;
+        v[u] = i < n ? x[i] : 0.0;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(v[u]));
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    unsigned long long a = 0ULL;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) a = red[w] > a ? red[w] : a;
+    const double f = ldexp(1.0, (int)((long long)(a >> 52) - 1023)), inv = 1.0 / f;
+    if (tid == 0) { out2[0] = f; out2[1] = inv; }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const int i = tid + 1024 * u;
+        if (i < n) x[i] = v[u] * inv;
+    }
+}
+
 int normalize_pow2(hipStream_t st, double* x, int64_t n, double* out2, void* scratch, int64_t scratch_bytes) {
     TN_CHECK_ARG(n >= 1, "empty input");
+    if (n <= 32768) {
+        TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(normalize_small_kernel, dim3(1), dim3(1024), 0, st, x, (int)n, out2));
+        TN_CHECK_LAUNCH("normalize_small_kernel");
+        return 0;
+    }
     int64_t nb = cdiv(n, 256 * 8);
     if (nb > 1024) nb = 1024;
     TN_CHECK_ARG(scratch_bytes >= nb * 8, "scratch too small (8 KiB always suffices)");

@@ -789,6 +789,36 @@ static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k,
     return 0;
 }
 
+// Selection of the b largest residuals among positions 0 .. ntr-1 by successive swaps (step t: the first maximum of positions
+// t .. ntr-1 goes to position t), through a tournament tree over the positions instead of b linear scans (the scans cost 30 us of
+// host time per panel with the device idle): leaf i = position i, a node keeps the position of the larger value, the left one on
+// ties (= the first maximum of a scan); a placed position is retired with -infinity.  hcn is permuted along; perm (offset j0) too;
+// pairs receives the b swaps (absolute column numbers) for swap_columns_kernel.
+static void select_pivots(double* hcn, int64_t ntr, int b, int64_t j0, int64_t* perm, int* pairs) {
+    int sz = 1;
+    while (sz < ntr) sz <<= 1;
+    thread_local std::vector<int> tree;
+    thread_local std::vector<double> val;
+    tree.assign((size_t)2 * sz, -1);
+    val.assign((size_t)sz, -1.0);                   // squared norms are >= 0: -1 never wins
+    for (int64_t j = 0; j < ntr; ++j) { val[j] = (hcn[j] == hcn[j]) ? hcn[j] : -1.0; tree[sz + j] = (int)j; }   // NaN never wins (as in a scan)
+    auto better = [&](int a, int c) { return (a >= 0 && (c < 0 || val[a] >= val[c])) ? a : c; };
+    for (int i = sz - 1; i >= 1; --i) tree[i] = better(tree[2 * i], tree[2 * i + 1]);
+    auto update = [&](int pos) { for (int i = (sz + pos) >> 1; i >= 1; i >>= 1) tree[i] = better(tree[2 * i], tree[2 * i + 1]); };
+    for (int t = 0; t < b; ++t) {
+        int arg = tree[1];                            // leftmost maximum of the live positions t .. ntr-1
+        if (arg < 0) arg = t;
+        std::swap(hcn[t], hcn[arg]);
+        std::swap(perm[j0 + t], perm[j0 + arg]);
+        pairs[2 * t] = (int)(j0 + t);
+        pairs[2 * t + 1] = (int)(j0 + arg);
+        if (arg != t) { val[arg] = (hcn[arg] == hcn[arg]) ? hcn[arg] : -1.0; update(arg); }
+        val[t] = -2.0;                                // position t is placed
+        tree[sz + t] = -1;
+        update(t);
+    }
+}
+
 // Look-ahead (aux != nullptr, nb = 32): the trailing update of panel p is split.  The columns of the next panel (and the
 // panel's own) are updated on the caller's stream, which then factors panel p+1 right away -- a chain of latency-bound
 // single-workgroup kernels -- while the device-filling update of everything to the right of it runs on `aux`.  Ordering:
@@ -955,33 +985,7 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
             thread_local std::vector<int> pairs_pageable;      // outlives the asynchronous upload below
             int* pairs = (int*)pinned_host((size_t)2 * nb * sizeof(int), 1);
             if (!pairs) { pairs_pageable.assign((size_t)2 * nb, 0); pairs = pairs_pageable.data(); }
-            {   // Selection of the b largest residuals by successive swaps (step t: the first maximum of positions t .. ntr-1 goes to
-                // position t), through a tournament tree over the positions instead of b linear scans (the scans cost 30 us of host
-                // time per panel with the device idle): leaf i = position i, a node keeps the position of the larger value, the
-                // left one on ties (= the first maximum of a scan); a placed position is retired with -infinity.
-                int sz = 1;
-                while (sz < ntr) sz <<= 1;
-                thread_local std::vector<int> tree;
-                thread_local std::vector<double> val;
-                tree.assign((size_t)2 * sz, -1);
-                val.assign((size_t)sz, -1.0);                   // squared norms are >= 0: -1 never wins
-                for (int64_t j = 0; j < ntr; ++j) { val[j] = (hcn[j] == hcn[j]) ? hcn[j] : -1.0; tree[sz + j] = (int)j; }   // NaN never wins (as in a scan)
-                auto better = [&](int a, int c) { return (a >= 0 && (c < 0 || val[a] >= val[c])) ? a : c; };
-                for (int i = sz - 1; i >= 1; --i) tree[i] = better(tree[2 * i], tree[2 * i + 1]);
-                auto update = [&](int pos) { for (int i = (sz + pos) >> 1; i >= 1; i >>= 1) tree[i] = better(tree[2 * i], tree[2 * i + 1]); };
-                for (int t = 0; t < b; ++t) {
-                    int arg = tree[1];                            // leftmost maximum of the live positions t .. ntr-1
-                    if (arg < 0) arg = t;
-                    std::swap(hcn[t], hcn[arg]);
-                    std::swap(pivot_perm_host[j0 + t], pivot_perm_host[j0 + arg]);
-                    pairs[2 * t] = (int)(j0 + t);
-                    pairs[2 * t + 1] = (int)(j0 + arg);
-                    if (arg != t) { val[arg] = (hcn[arg] == hcn[arg]) ? hcn[arg] : -1.0; update(arg); }
-                    val[t] = -2.0;                                // position t is placed
-                    tree[sz + t] = -1;
-                    update(t);
-                }
-            }
+            select_pivots(hcn, ntr, b, j0, pivot_perm_host, pairs);
             int* dpairs = w.pairs;
             if ((he = hipMemcpyAsync(dpairs, pairs, (size_t)2 * b * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(he, "memcpy pairs");
             TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(swap_columns_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, A, rs, cs, m, dpairs, b));
