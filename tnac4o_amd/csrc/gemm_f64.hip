@@ -4,14 +4,14 @@
 // :655-663, _mps_RAR :748-751, projector application :579-580) is a strided view of this kernel, so no
 // transposed copies are ever materialised.
 //
-// Tile: BM x BN per 256-thread workgroup (4 waves as 2 x 2), K step BKT = 16 or 32.  Operands are staged through
-// two LDS stages, k-major (As[k][m], Bs[k][n]) with pitch = B? + 16 doubles and an XOR swizzle of the low column
-// bits by k, which makes both the fragment reads (ds_read_b64, 16 consecutive doubles per k) and the transposed
-// stores of k-contiguous operands bank-conflict free.  The next K-tile is prefetched into registers while the
-// current one is multiplied and lands in the other stage: one barrier per K step.  BKT = 32 serves the launches
-// that do not fill the chip (the chain's small products): there a K step costs one global-memory round trip
-// whatever its depth, so half as many steps is close to half the time; launches with many workgroups per CU keep
-// BKT = 16 (less LDS, more workgroups in flight).  MFMA f64 lane maps (cdna_hip_programming.md §3): A[l&15][l>>4],
+// Tile: BM x BN per 256-thread workgroup (4 waves as 2 x 2), K step BKT = 16.  Operands are staged through two
+// LDS stages, k-major (As[k][m], Bs[k][n]) with pitch = B? + 16 doubles and an XOR swizzle of the low column bits
+// by k, which makes both the fragment reads (ds_read_b64, 16 consecutive doubles per k) and the transposed stores
+// of k-contiguous operands bank-conflict free.  The next K-tile is prefetched into registers while the current one
+// is multiplied and lands in the other stage: one barrier per K step.  (BKT = 32 was measured: a 64 x 64 tile makes
+// 0.43 us of MFMA work per 16 of K on one CU and its global loads are in flight meanwhile, so a deeper step saves
+// next to nothing on the small products -- 31 -> 29 us at 64 x 64 x 416 -- and costs the large ones occupancy:
+// 16384 x 1024 x 1024 drops from 56 to 43 TFLOP/s.)  MFMA f64 lane maps (cdna_hip_programming.md §3): A[l&15][l>>4],
 // B[l>>4][l&15], D reg r -> row (l>>4)+4r, col l&15.
 #include <stdlib.h>
 
@@ -233,19 +233,11 @@ static void launch_tile(hipStream_t st, const GemmP& g, dim3 grid, bool ak, bool
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, false, false, false>), grid, dim3(256), 0, st, g);
 }
 
-// K step of a launch: 32 when the grid leaves CUs idle anyway (every workgroup has a CU and its LDS to itself) and there are
-// at least two such steps to make; TN_GEMM_BK=16 / 32 forces one form (A/B measurements)
-static int pick_bkt(int64_t wgs, int64_t kchunk) {
-    static const int forced = [] { const char* e = getenv("TN_GEMM_BK"); return e ? atoi(e) : 0; }();
-    if (forced == 16 || forced == 32) return forced;
-    return (wgs <= 256 && kchunk >= 64) ? 32 : 16;
-}
-
 // ---- launch plan --------------------------------------------------------------------------------------------------
 // Almost every product of a sweep is small: its tiles fill a few of the 256 CUs, and one CU makes 64 x 64 x 16 of fp64 MFMA work
 // in ~0.9 us (a 128 x 128 tile: ~1.9 us), so the time of such a product is (K steps per workgroup) x that, plus the launches.
 // Products of less than TN_GEMM_SMALLWORK (2^30) multiply-adds are therefore spread over about one workgroup per CU: 64 x 64
-// tiles instead of 128 x 128 while those would leave half the chip idle, and K split down to chunks of TN_GEMM_MINCHUNK (32, at most TN_GEMM_SMAX = 32 of them),
+// tiles instead of 128 x 128 while those would leave half the chip idle, and K split down to chunks of TN_GEMM_MINCHUNK (32, at most TN_GEMM_SMAX = 64 of them),
 // the partial sums added up by splitk_reduce_kernel (an in-kernel reduction by the last workgroup of a tile to arrive was
 // measured slower: it pulls all the partials of a tile through one CU, 22 us against 12 us for the two launches at 64 x 64 x 1024).
 // Larger products are bound by MFMA throughput: big tiles, K split only to fill the chip, chunks of at least 128.
@@ -256,7 +248,7 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int64_t batch) {
     static const int big_tiles = env_int("TN_GEMM_BIGTILES", 128);     // small products: 128 x 128 tiles from this many workgroups on
     static const int target_wg = env_int("TN_GEMM_TARGETWG", 256);
     static const int min_chunk = env_int("TN_GEMM_MINCHUNK", 32);
-    static const int smax = env_int("TN_GEMM_SMAX", 32);
+    static const int smax = env_int("TN_GEMM_SMAX", 64);
     const bool small = (double)M * (double)N * (double)K * (double)batch < (double)small_work;
     GemmPlan p;
     if (M > 64 && N > 64) {
@@ -269,7 +261,9 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int64_t batch) {
     p.s = 1;
     if (small) {
         if (wgs < target_wg * 3 / 4 && K >= 2 * min_chunk) {
-            int64_t s = cdiv(target_wg, wgs);
+            // (up to 16 tiles: the split depends on K alone, so that a product and the same product cut into column ranges -- the
+            //  look-ahead of tn_qr -- add up in the same order)
+            int64_t s = wgs <= 16 ? smax : cdiv(target_wg, wgs);
             if (s > K / min_chunk) s = K / min_chunk;
             if (s > smax) s = smax;
             p.s = s < 2 ? 1 : (int)s;
@@ -390,18 +384,10 @@ static int gemm_ex_impl(hipStream_t st, int64_t M, int64_t N, int64_t K, double 
     const int fam = (bm == 128 && bn == 128) ? PROF_GEMM_128x128 : (bm == 128) ? PROF_GEMM_128x32
                     : (bm == 32) ? PROF_GEMM_32x128 : PROF_GEMM_64x64;
     prof_begin(st, fam);
-    const int bkt = pick_bkt((int64_t)grid.x * grid.z, g.kchunk);
-    if (bkt == 32) {
-        if (bm == 128 && bn == 128) launch_tile<128, 128, 32>(st, g, grid, ak, bk);
-        else if (bm == 128 && bn == 32) launch_tile<128, 32, 32>(st, g, grid, ak, bk);
-        else if (bm == 32 && bn == 128) launch_tile<32, 128, 32>(st, g, grid, ak, bk);
-        else launch_tile<64, 64, 32>(st, g, grid, ak, bk);
-    } else {
-        if (bm == 128 && bn == 128) launch_tile<128, 128, 16>(st, g, grid, ak, bk);
-        else if (bm == 128 && bn == 32) launch_tile<128, 32, 16>(st, g, grid, ak, bk);
-        else if (bm == 32 && bn == 128) launch_tile<32, 128, 16>(st, g, grid, ak, bk);
-        else launch_tile<64, 64, 16>(st, g, grid, ak, bk);
-    }
+    if (bm == 128 && bn == 128) launch_tile<128, 128, 16>(st, g, grid, ak, bk);
+    else if (bm == 128 && bn == 32) launch_tile<128, 32, 16>(st, g, grid, ak, bk);
+    else if (bm == 32 && bn == 128) launch_tile<32, 128, 16>(st, g, grid, ak, bk);
+    else launch_tile<64, 64, 16>(st, g, grid, ak, bk);
     TN_CHECK_LAUNCH("gemm_kernel");
     // algorithmic work of SURVEY.md §8d: 2MNK flops, 8(MK + KN + MN) bytes
     prof_end(st, fam, 2.0 * M * N * K * batch, 8.0 * batch * ((double)M * K + (double)K * N + (double)M * N));

@@ -13,11 +13,9 @@ if [ -z "$PMC_ONLY" ]; then
 echo "== kernel trace of the bench command (4 interleaved chains)" >> $OUT/log.txt
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-search --cpu-rows 0 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 echo "rc=$?" >> $OUT/log.txt
-if ! ls $OUT/kt/*/*kernel_stats.csv $OUT/kt/*kernel_stats.csv > /dev/null 2>&1; then
-  echo "== fallback: kernel trace of the single-chain form" >> $OUT/log.txt
-  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1 -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-search --cpu-rows 0 --concurrent 1 > $OUT/bench_c1_under_rocprof.json 2> $OUT/bench_c1_under_rocprof.err
-  echo "rc=$?" >> $OUT/log.txt
-fi
+echo "== kernel trace of the single-chain form" >> $OUT/log.txt
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1 -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-search --cpu-rows 0 --concurrent 1 > $OUT/bench_c1_under_rocprof.json 2> $OUT/bench_c1_under_rocprof.err
+echo "rc=$?" >> $OUT/log.txt
 fi
 python3 $ROOT/tools/pmc_probe.py 2>/dev/null | grep PROBE_TIMES > $OUT/probe_times.txt
 for ctr in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES SQ_WAIT_INST_LDS"; do
