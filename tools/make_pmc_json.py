@@ -13,12 +13,28 @@ ROUND = os.environ.get('ROUND', 'r03')
 BASE = os.path.join(ROOT, 'gpurun_out', 'prof_' + ROUND)
 
 
+SEG = {}                # tag -> {segment: {kernel: {counter: total}}}
+
+
 def load(tag):
-    out = {}
+    """Per kernel over all segments: counter -> (dispatches, total, mean); the per-segment totals go to SEG[tag]."""
+    out, seg = {}, {}
     with open(os.path.join(BASE, 'pmc_%s_summary.csv' % tag)) as f:
         for r in csv.DictReader(f):
-            out.setdefault(r['Kernel'], {})[r['Counter']] = (int(r['Dispatches']), float(r['Total']), float(r['MeanPerDispatch']))
+            d = out.setdefault(r['Kernel'], {})
+            n0, t0, _ = d.get(r['Counter'], (0, 0.0, 0.0))
+            n, t = n0 + int(r['Dispatches']), t0 + float(r['Total'])
+            d[r['Counter']] = (n, t, t / n)
+            seg.setdefault(int(r.get('Segment', 0) or 0), {}).setdefault(r['Kernel'], {})[r['Counter']] = float(r['Total'])
+    SEG[tag] = seg
     return out
+
+
+def segment_bytes(segment):
+    """HBM bytes of every launch of a segment of tools/pmc_probe.py (FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes), ours or not."""
+    f = sum(v.get('FETCH_SIZE', 0.0) for v in SEG['FETCH_SIZE'].get(segment, {}).values())
+    w = sum(v.get('WRITE_SIZE', 0.0) for v in SEG['WRITE_SIZE'].get(segment, {}).values())
+    return 2.0 * 1024 * f + 1024 * w
 
 
 F, W = load('FETCH_SIZE'), load('WRITE_SIZE')
@@ -59,33 +75,21 @@ for p in range(16):
 fam['panel step (cq_fused / cq_gram / cq_pass / cq_post)'] = {'probe_shape': 'tn_qr 16384 x 1024 (32 panels, six-launch chain) + tn_qr 4096 x 512 (16 panels, single-launch form)', 'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
                                    'traffic_bytes_per_launch': (fb + wb) / n, 'algorithmic_bytes_per_launch': alg / n,
                                    'traffic_over_algorithmic': (fb + wb) / alg}
-for name, pat in (('eig_small_kernel', 'eig_small_kernel'), ('absorb_kernel', 'absorb_mfma_kernel')):
+for name, pat in (('eig_small_kernel', 'eig_small'), ('absorb_kernel', 'absorb_mfma_kernel')):
     ks = [k for k in kern if pat in k]
     if ks:
         k = ks[0]
         fam[name] = dict(kern[k])
 
-# whole-call traffic: tn_qr 16384 x 1024 = every kernel of the QR (the probe runs exactly one such QR under the counters;
-# gemm<128,128,true,false> also contains the 3 plain 16384x1024x1024 products of the probe, which are subtracted)
-qr_names = ['cq_gram_kernel', 'cq_pass_kernel', 'cq_post_kernel', 'cq_fused_kernel', 'diag_qr_kernel',
-            'assemble_R_kernel', 'init_Q_kernel', 'assemble_R_init_Q_kernel', 'splitk_reduce_kernel', 'gemm_kernel<32, 128, false, false, false>',
-            'gemm_kernel<128, 32, true, false, false>']
-qr_bytes = 0.0
-for k in kern:
-    if any(q in k for q in qr_names):
-        qr_bytes += kern[k]['traffic_bytes_per_launch'] * kern[k]['dispatches']
-g = [k for k in kern if 'gemm_kernel<128, 128, true, false, false>' in k]
-plain = 8.0 * (16384 * 1024 * 2 + 1024 * 1024)                  # one 16384x1024x1024 product, compulsory
-if g:
-    tot = kern[g[0]]['traffic_bytes_per_launch'] * kern[g[0]]['dispatches']
-    qr_bytes += max(0.0, tot - 3 * 1.94 * plain)                # the 3 plain products at their measured 1.94x (round 1)
+# whole-call traffic: everything launched between the probe's markers (segment 1 = tn_qr 16384 x 1024, 4 = tn_svd_trunc)
+qr_bytes = segment_bytes(1)
 m, nn = 16384, 1024
 qr_comp = 8.0 * (2 * m * nn + nn * nn)
-whole = {'tn_qr_16384x1024': {'hbm_bytes': qr_bytes, 'compulsory_bytes': qr_comp, 'traffic_over_compulsory': qr_bytes / qr_comp,
+whole = {'tn_qr_4096x512': {'hbm_bytes': segment_bytes(2), 'compulsory_bytes': 8.0 * (2 * 4096 * 512 + 512 * 512),
+                            'traffic_over_compulsory': segment_bytes(2) / (8.0 * (2 * 4096 * 512 + 512 * 512))},
+         'tn_qr_16384x1024': {'hbm_bytes': qr_bytes, 'compulsory_bytes': qr_comp, 'traffic_over_compulsory': qr_bytes / qr_comp,
                               'ms_unprofiled': times.get('qr_16384x1024_ms')}}
-svd_names = ['gemm_kernel<64, 64, false, false, true>', 'gemm_kernel<64, 64, true, true, true>', 'eig_small_kernel', 'svd_init_kernel',
-             'svd_gather_kernel', 'vec_norm2_kernel']
-svd_bytes = sum(kern[k]['traffic_bytes_per_launch'] * kern[k]['dispatches'] for k in kern if any(q in k for q in svd_names))
+svd_bytes = segment_bytes(4)
 svd_comp = 8.0 * (2 * 320 * 1024 + 320 * 320 + 320)
 svd = {'hbm_bytes': svd_bytes, 'compulsory_bytes': svd_comp, 'traffic_over_compulsory': svd_bytes / svd_comp,
        'ms_unprofiled': times.get('svd_trunc_320x1024_ms'), 'sweeps': times.get('svd_sweeps')}
