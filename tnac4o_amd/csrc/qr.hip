@@ -534,10 +534,17 @@ __global__ __launch_bounds__(256) void diag_qr_kernel(const double* __restrict__
 
 // R[i][j]: 0 left of the diagonal block, Tri inside it, Z^T A to the right;  Q starts as [Z; 0] (block diagonal Z).
 // Both only wait for diag_qr_kernel, so they share one launch: the first nR workgroups write R, the rest Q.
+// With fold_b > 0 the LAST panel's reflector is applied on the way (single-level path): its columns of Q are
+//     H_p [Z_p; 0] = [Z_p; 0] - (Y_p T_p) (Ytop_p^T Z_p),
+// a b x b product every workgroup forms for itself in LDS -- two GEMM launches less per factorisation, and for a one-panel
+// factorisation no Q accumulation at all.  Y / Wq: the reflectors and Y T of all panels (strides yrs / ycs), j0f: first column of the
+// last panel.
 __global__ __launch_bounds__(256) void assemble_R_init_Q_kernel(const double* __restrict__ A, int64_t rs, int64_t cs, int nb, int64_t k, int64_t n,
                                                                 const double* __restrict__ Zbuf, const double* __restrict__ Tri,
                                                                 double* __restrict__ R, int64_t rrs, int64_t rcs, unsigned nR,
-                                                                double* __restrict__ Q, int64_t qrs, int64_t qcs, int64_t m, int colfast) {
+                                                                double* __restrict__ Q, int64_t qrs, int64_t qcs, int64_t m, int colfast,
+                                                                const double* __restrict__ Y, const double* __restrict__ Wq, int64_t yrs,
+                                                                int64_t ycs, int64_t j0f, int fold_b) {
     if (blockIdx.x < nR) {
         const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (e >= k * n) return;
@@ -554,6 +561,17 @@ __global__ __launch_bounds__(256) void assemble_R_init_Q_kernel(const double* __
         }
         R[i * rrs + j * rcs] = v;
     } else {
+        __shared__ double Ms[32 * 33];
+        if (fold_b > 0) {                                   // M = Ytop^T Z of the last panel (uniform branch)
+            const double* z = Zbuf + (j0f / nb) * nb * nb;
+            for (int e = threadIdx.x; e < fold_b * fold_b; e += 256) {
+                const int c = e / fold_b, jj = e % fold_b;
+                double acc = 0.0;
+                for (int r = 0; r < fold_b; ++r) acc += Y[(j0f + r) * yrs + (j0f + c) * ycs] * z[r * nb + jj];
+                Ms[c * 33 + jj] = acc;
+            }
+            __syncthreads();
+        }
         const int64_t e = (int64_t)(blockIdx.x - nR) * 256 + threadIdx.x;
         if (e >= m * k) return;
         const int64_t i = colfast ? e / k : e % m, j = colfast ? e % k : e / m;
@@ -561,6 +579,12 @@ __global__ __launch_bounds__(256) void assemble_R_init_Q_kernel(const double* __
         if (i < k && i / nb == j / nb) {
             const int64_t p = i / nb;
             v = Zbuf[p * nb * nb + (i - p * nb) * nb + (j - p * nb)];
+        }
+        if (fold_b > 0 && j >= j0f && i >= j0f) {
+            const int jj = (int)(j - j0f);
+            double acc = 0.0;
+            for (int c = 0; c < fold_b; ++c) acc += Wq[i * yrs + (j0f + c) * ycs] * Ms[c * 33 + jj];
+            v -= acc;
         }
         Q[i * qrs + j * qcs] = v;
     }
@@ -771,7 +795,7 @@ static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k,
     {
         const unsigned nR = (unsigned)cdiv(k * n, 256), nQ = (unsigned)cdiv(m * k, 256);
         TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(assemble_R_init_Q_kernel, dim3(nR + nQ), dim3(256), 0, st, Am.p, rs, cs, nb, k, n, w.Z, w.Tri, R,
-                           rrs, rcs, nR, Q, qrs, qcs, m, qcolfast));
+                           rrs, rcs, nR, Q, qrs, qcs, m, qcolfast, (const double*)nullptr, (const double*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, 0));
         TN_CHECK_LAUNCH("assemble_R_init_Q_kernel");
     }
     Mat Qm = mat(Q, qrs, qcs);
@@ -1112,16 +1136,20 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
     TN_CHECK_LAUNCH("diag_qr_kernel");
     dbg_check(st, w.Z, nb, 1, (int64_t)P * nb, nb, "Z", -1, 0);
     dbg_check(st, w.Tri, nb, 1, (int64_t)P * nb, nb, "Tri", -1, 0);
-    // --- Q = H_1 ... H_P [Z; 0]
+    // --- Q = H_1 ... H_P [Z; 0]; the last panel's reflector is applied by the launch that writes [Z; 0] (nb = 32)
     const int qcolfast = (qcs == 1) ? 1 : 0;
+    const int64_t jf = (int64_t)(P - 1) * nb;
+    // (every workgroup of the Q part recomputes the b x b product: worth it while there are few of them, i.e. for the small
+    //  factorisations whose time is launches; the large ones keep the two GEMMs)
+    const int fold_b = (nb == 32 && P >= 1 && m * k <= 256 * 512) ? (int)(k - jf) : 0;
     {
         const unsigned nR = (unsigned)cdiv(k * n, 256), nQ = (unsigned)cdiv(m * k, 256);
         TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(assemble_R_init_Q_kernel, dim3(nR + nQ), dim3(256), 0, st, A, rs, cs, nb, k, n, w.Z, w.Tri, R, rrs,
-                           rcs, nR, Q, qrs, qcs, m, qcolfast));
+                           rcs, nR, Q, qrs, qcs, m, qcolfast, (const double*)w.Y, (const double*)w.Wq, yrs, ycs, jf, fold_b));
         TN_CHECK_LAUNCH("assemble_R_init_Q_kernel");
     }
     Mat Qm = mat(Q, qrs, qcs);
-    for (int p = P - 1; p >= 0; --p) {
+    for (int p = P - 1 - (fold_b > 0 ? 1 : 0); p >= 0; --p) {
         const int64_t j0 = (int64_t)p * nb;
         const int b = (int)((k - j0 < nb) ? k - j0 : nb);
         const int64_t mp = m - j0, nq = k - j0;
