@@ -63,6 +63,21 @@ expect_neg(L.tn_calc_pn(P, P, P, P, P, P, P, P, P, 4, 256, 1, 1, 64, 512, 64, P,
 expect_neg(L.tn_calc_pn(P, P, P, P, P, P, P, P, P, 4, 16, 1, 1, 1, 1, 1, P, P, P, None, None), 'tn_calc_pn log2p pair')
 expect_neg(L.tn_merge_groups(P, P, P, P, P, -1, 0.0, P, P, P, None), 'tn_merge_groups ngroups')
 expect_neg(L.tn_compress_mps_arena_bytes(0, None, None, 8), 'tn_compress_mps_arena_bytes L')
+class Cell(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('F', 'dmap', 'rmap', 'down', 'right', 'Es', 'E1', 'E4', 'left_map', 'up_map', 'A')] + \
+               [(n, C.c_int64) for n in ('q', 'nl', 'nu', 'pd', 'br', 'e1cols', 'e4cols', 'Dl', 'p', 'Dr')]
+cell = Cell(*([P.value] * 11 + [4, 2, 2, 2, 2, 2, 2, 1, 2, 1]))
+cells = C.cast(C.pointer(cell), C.c_void_p)
+bs = lambda cl, M, ws, wsb, nbp=C.byref(i64): L.tn_beam_search(1, 1, cl, M, 1, -20.0, 1e-12, 4, P, P, P, P, nbp, C.byref(f64), C.byref(f64), ws, wsb, None)
+assert L.tn_beam_search_ws_bytes(4, 4, 64, 16, 64, 64, 256) > 0
+expect_neg(bs(None, 8, P, 1 << 30), 'tn_beam_search cells')
+expect_neg(bs(cells, 0, P, 1 << 30), 'tn_beam_search M')
+expect_neg(bs(cells, 8, P, 1 << 30, None), 'tn_beam_search results')
+expect_neg(bs(cells, 8, P, 1024), 'tn_beam_search ws')
+cell.p = 3
+expect_neg(bs(cells, 8, P, 1 << 30), 'tn_beam_search bond')
+cell.p, cell.Dl, cell.nl = 2, 512, 16
+expect_neg(bs(cells, 8, P, 1 << 30), 'tn_beam_search env')
 expect_neg(L.tn_env_rr_batched(P, P, P, P, P, 4, 512, 16, 64, 16, 16, 16, P, None), 'tn_env_rr acc')
 expect_neg(L.tn_env_rr_batched(P, P, P, P, P, -1, 4, 4, 4, 4, 4, 4, P, None), 'tn_env_rr nk')
 expect_neg(L.tn_env_rl_batched(None, P, P, 4, 4, 4, P, None), 'tn_env_rl null')
