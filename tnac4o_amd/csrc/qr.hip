@@ -61,13 +61,14 @@ static int fill_mat(hipStream_t st, double* D, int64_t drs, int64_t dcs, int64_t
 }
 
 // column swaps of a panel-pivoting step, applied in order to every row: A(r, pairs[2t]) <-> A(r, pairs[2t+1]), t = 0 .. npairs-1
-__global__ __launch_bounds__(256) void swap_columns_kernel(double* __restrict__ A, int64_t rs, int64_t cs, int64_t m,
-                                                           const int* __restrict__ pairs, int npairs) {
+// (the swap list travels by value in the kernel arguments: 256 bytes, no host-to-device copy and no staging buffer to keep alive)
+struct SwapList { int v[64]; };
+__global__ __launch_bounds__(256) void swap_columns_kernel(double* __restrict__ A, int64_t rs, int64_t cs, int64_t m, SwapList pairs, int npairs) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= m) return;
     double* row = A + r * rs;
     for (int t = 0; t < npairs; ++t) {
-        const int64_t i1 = pairs[2 * t], i2 = pairs[2 * t + 1];
+        const int64_t i1 = pairs.v[2 * t], i2 = pairs.v[2 * t + 1];
         if (i1 != i2) { const double x = row[i1 * cs]; row[i1 * cs] = row[i2 * cs]; row[i2 * cs] = x; }
     }
 }
@@ -1006,13 +1007,9 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
                 P = p;
                 break;
             }
-            thread_local std::vector<int> pairs_pageable;      // outlives the asynchronous upload below
-            int* pairs = (int*)pinned_host((size_t)2 * nb * sizeof(int), 1);
-            if (!pairs) { pairs_pageable.assign((size_t)2 * nb, 0); pairs = pairs_pageable.data(); }
-            select_pivots(hcn, ntr, b, j0, pivot_perm_host, pairs);
-            int* dpairs = w.pairs;
-            if ((he = hipMemcpyAsync(dpairs, pairs, (size_t)2 * b * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(he, "memcpy pairs");
-            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(swap_columns_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, A, rs, cs, m, dpairs, b));
+            SwapList sl = {};
+            select_pivots(hcn, ntr, b, j0, pivot_perm_host, sl.v);
+            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(swap_columns_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, A, rs, cs, m, sl, b));
             TN_CHECK_LAUNCH("swap_columns_kernel");
         }
         // --- panel orthonormalisation

@@ -52,15 +52,18 @@ __global__ __launch_bounds__(256) void svd_init_kernel(const double* __restrict_
 
 // One block per kept vector j (source row order[j]):  left[:, j] = sgn * P[row, :],  right[j, :] = sgn * X[row, :] / S_j
 // with the reference's sign gauge: flip when in both vectors the most negative entry outweighs the most positive.
+// Up to 64 kept vectors (every truncation to chi <= 64): their values and rows travel by value in the kernel arguments (`byval`),
+// no host-to-device copy; more: `order` / `Ssorted` in device memory.
+struct GatherList { double S[64]; int order[64]; };
 __global__ __launch_bounds__(256) void svd_gather_kernel(const double* __restrict__ X, int64_t L, const double* __restrict__ P,
                                                          int64_t nv, int64_t pitch, const int* __restrict__ order,
                                                          const double* __restrict__ Ssorted, double* __restrict__ Sout,
                                                          double* __restrict__ left, int64_t lrs, int64_t lcs,
-                                                         double* __restrict__ right, int64_t rrs, int64_t rcs) {
+                                                         double* __restrict__ right, int64_t rrs, int64_t rcs, GatherList gl, int byval) {
     __shared__ double rmin[256], rmax[256];
     __shared__ double sgn;
     const int j = blockIdx.x, tid = threadIdx.x;
-    const int row = order[j];
+    const int row = byval ? gl.order[j] : order[j];
     const double* x = X + (int64_t)row * pitch;
     const double* p = P + (int64_t)row * pitch;
     double xmin = 0.0, xmax = 0.0, pmin = 0.0, pmax = 0.0;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void svd_gather_kernel(const double* __restric
         sgn = (fabs(pmin) > pmax && fabs(xmin) > xmax) ? -1.0 : 1.0;
     }
     __syncthreads();
-    const double s = sgn, sv = Ssorted[j];
+    const double s = sgn, sv = byval ? gl.S[j] : Ssorted[j];
     if (tid == 0) Sout[j] = sv;
     const double inv = sv > 0.0 ? s / sv : 0.0;
     for (int64_t c = tid; c < L; c += 256) right[(int64_t)j * rrs + c * rcs] = x[c] * inv;
@@ -455,27 +458,32 @@ int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t
     if (discarded_out) *discarded_out = std::sqrt(d2) / hS[0];
     if (keep == 0) return 0;
     hipError_t e;
-    // kept singular values and their row order go up in one copy into the (now free) norms | Ssorted area: [S | order]
-    std::vector<char> hpack((size_t)keep * 12);
-    std::memcpy(hpack.data(), hS.data(), (size_t)keep * 8);
-    std::memcpy(hpack.data() + (size_t)keep * 8, hO.data(), (size_t)keep * 4);
+    GatherList gl = {};
+    const int byval = keep <= 64 ? 1 : 0;
     double* dS = w.norms;
     const int* dO = (const int*)((const char*)w.norms + (size_t)keep * 8);
-    if ((rc = upload_slot_guard(st))) return rc;
-    char* stage = (char*)pinned_host(hpack.size(), 3);         // (the schedule uploaded from this slot completed several synchronisations ago)
-    if (stage) std::memcpy(stage, hpack.data(), hpack.size());
-    if ((e = hipMemcpyAsync(w.norms, stage ? stage : hpack.data(), hpack.size(), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy S/order");
+    char* stage = nullptr;
+    if (byval) {
+        for (int64_t i = 0; i < keep; ++i) { gl.S[i] = hS[(size_t)i]; gl.order[i] = hO[(size_t)i]; }
+    } else {
+        // kept singular values and their row order go up in one copy into the (now free) norms | Ssorted area: [S | order]
+        std::vector<char> hpack((size_t)keep * 12);
+        std::memcpy(hpack.data(), hS.data(), (size_t)keep * 8);
+        std::memcpy(hpack.data() + (size_t)keep * 8, hO.data(), (size_t)keep * 4);
+        if ((rc = upload_slot_guard(st))) return rc;
+        stage = (char*)pinned_host(hpack.size(), 3);           // (the schedule uploaded from this slot completed several synchronisations ago)
+        if (stage) std::memcpy(stage, hpack.data(), hpack.size());
+        if ((e = hipMemcpyAsync(w.norms, stage ? stage : hpack.data(), hpack.size(), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "memcpy S/order");
+        if (!stage && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync S/order");      // pageable source: must outlive the copy
+    }
     // rows: left = U (k x keep), right = Vt.  columns (C^T was factored): left = Vt^T, right = U^T.
     if (rows)
         TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, dO, dS, S,
-                           U, urs, ucs, Vt, vrs, vcs));
+                           U, urs, ucs, Vt, vrs, vcs, gl, byval));
     else
         TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_gather_kernel, dim3((unsigned)keep), dim3(256), 0, st, w.X, L, w.P, nv, L + nv, dO, dS, S,
-                           Vt, vcs, vrs, U, ucs, urs));
+                           Vt, vcs, vrs, U, ucs, urs, gl, byval));
     TN_CHECK_LAUNCH("svd_gather_kernel");
-    // the upload above reads the thread's page-locked slot, which is not rewritten before the next call's first synchronisation;
-    // only a pageable source (allocation failure) has to outlive the copy
-    if (!stage && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync gather");
     return 0;
 }
 
