@@ -1216,6 +1216,47 @@ static int cq_stat_slot(hipStream_t st) {
     return s;
 }
 
+// The panel state of a factorisation lives in a block of its own per stream (a stream's calls do not overlap), NOT in the shared
+// scratch: it is zero when a call starts because the call before it ended by clearing it (the first launch after the last panel --
+// diag_qr_kernel of tn_qr -- zeroes the block), so no memset launch per factorisation.  A call that fails half-way leaves its
+// stream's block marked dirty on the host and the next call clears it with a memset.  Streams beyond CQ_STAT_SLOTS fall back to the
+// state block at the head of the workspace and a memset per call.
+__device__ char cq_state_pool[CQ_STAT_SLOTS * CQ_STATE_BYTES];
+static bool cq_dirty[CQ_STAT_SLOTS];
+int cholqr_begin(hipStream_t st, void* ws, void** state_out) {
+    const int slot = cq_stat_slot(st);
+    if (slot >= CQ_STAT_SLOTS) {
+        *state_out = ws;
+        const hipError_t e = hipMemsetAsync(ws, 0, CQ_STATE_BYTES, st);
+        return e == hipSuccess ? 0 : hip_fail(e, "memset panel state");
+    }
+    static char* base = nullptr;
+    static std::mutex mu;
+    bool dirty;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!base) {
+            void* p = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(cq_state_pool));
+            if (e != hipSuccess) return hip_fail(e, "panel state pool");
+            base = (char*)p;
+        }
+        dirty = cq_dirty[slot];
+        cq_dirty[slot] = true;
+    }
+    *state_out = base + (size_t)slot * CQ_STATE_BYTES;
+    if (dirty) {
+        const hipError_t e = hipMemsetAsync(*state_out, 0, CQ_STATE_BYTES, st);
+        if (e != hipSuccess) return hip_fail(e, "memset panel state");
+    }
+    return 0;
+}
+// the launch that clears the state block has been enqueued: the next call on this stream finds it clean
+void cholqr_end_ok(hipStream_t st) {
+    const int slot = cq_stat_slot(st);
+    if (slot < CQ_STAT_SLOTS) cq_dirty[slot] = false;
+}
+
 // The state block at the head of the workspace must be zero before the first panel of a call (the kernels leave it clean).
 int cholqr_reset(hipStream_t st, void* ws) {
     const hipError_t e = hipMemsetAsync(ws, 0, CQ_STATE_BYTES, st);
@@ -1259,7 +1300,8 @@ static void cq_capture(hipStream_t st, const double* X, int64_t irs, int64_t ics
 // wrs/wcs) and, when Wq != NULL, Wq = Y T (strides of Y), i.e. what lu_reconstruct_kernel + rows_times_small3 of qr.hip produce,
 // in the launch slots that would otherwise return at once.
 int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws,
-                 int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq, int* fused_base) {
+                 int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq, int* fused_base,
+                 void* state) {
     TN_CHECK_ARG(b >= 1 && b <= 32, "panel width must be <= 32");
     TN_CHECK_ARG(nrows >= b, "panel must have at least b rows");
     TN_CHECK_ARG(ws_bytes >= cholqr_ws_bytes(nrows, b), "workspace too small");
@@ -1267,7 +1309,7 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
     TN_CHECK_ARG(!reconstruct || (Tp && W), "reconstruction needs T and W");
     const int nblk = (int)cdiv(nrows, CQ_RB);
     char* p = (char*)ws;
-    CqState* stt = (CqState*)p; p += CQ_STATE_BYTES;
+    CqState* stt = (CqState*)(state ? state : ws); p += CQ_STATE_BYTES;       // (state: the stream's own block, see cholqr_begin)
     double* Rg = (double*)p; p += align_up((1024 + 32) * 8, 256);
     const bool fits = cq_fused_fits(nblk);
     double* part = (double*)p; p += align_up((int64_t)(fits ? 2 * nblk : nblk) * CQ_PART * 8, 256);
@@ -1287,7 +1329,7 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
         *fused_base += (maxpass + 1) * nblk;
         const double e = (double)nrows * b;
         prof_end(st, PROF_TSQR, (2.0 + (reconstruct ? (Wq ? 6.0 : 4.0) : 0.0)) * e * b, (reconstruct ? (Wq ? 32.0 : 24.0) : 16.0) * e);
-        cq_capture(st, X, irs, ics, nrows, b, ws);
+        cq_capture(st, X, irs, ics, nrows, b, stt);
         return 0;
     }
     prof_begin(st, PROF_TSQR);
@@ -1307,13 +1349,13 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
     hipLaunchKernelGGL(cq_post_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, stt, lu, Tp, W, wrs, wcs, Wq);
     TN_CHECK_LAUNCH("cq_post_kernel");
     prof_end(st, PROF_TSQR, reconstruct ? (Wq ? 6.0 : 4.0) * nrows * b * b : 0.0, reconstruct ? (Wq ? 32.0 : 24.0) * nrows * b : 0.0);
-    cq_capture(st, X, irs, ics, nrows, b, ws);
+    cq_capture(st, X, irs, ics, nrows, b, stt);
     return 0;
 }
 
 int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows,
-                          int b, void* ws, int64_t ws_bytes, uint64_t seed, int* fused_base) {
-    return cholqr_panel(st, X, irs, ics, Y, rs, cs, nrows, b, ws, ws_bytes, seed, 0, nullptr, nullptr, 0, 0, nullptr, fused_base);
+                          int b, void* ws, int64_t ws_bytes, uint64_t seed, int* fused_base, void* state) {
+    return cholqr_panel(st, X, irs, ics, Y, rs, cs, nrows, b, ws, ws_bytes, seed, 0, nullptr, nullptr, 0, 0, nullptr, fused_base, state);
 }
 
 // diagnostics: state block of the last panel (synchronises the stream) and the process-wide counters

@@ -164,13 +164,19 @@ int tsqr_orthonormalize(hipStream_t st, const double* Xin, int64_t irs, int64_t 
 
 // ---- iterated Cholesky-QR panel orthonormalisation (cholqr.hip), the default panel step -------------------------------
 int64_t cholqr_ws_bytes(int64_t nrows, int b);
-int cholqr_reset(hipStream_t st, void* ws);          // zero the state block once per call, before the first panel
-// fused_base: host counter of the call (0 after cholqr_reset) for the single-launch form of small panels; NULL = six-launch chain
+int cholqr_reset(hipStream_t st, void* ws);          // zero the state block at the head of ws once per call, before the first panel
+// the stream's own state block (zero on return; see cholqr.hip) -- *state_out goes to the panel calls of this factorisation; the
+// caller's first launch after the last panel clears the block (CQ_STATE_BYTES) and then tells cholqr_end_ok
+int cholqr_begin(hipStream_t st, void* ws, void** state_out);
+void cholqr_end_ok(hipStream_t st);
+// fused_base: host counter of the call (0 at its start) for the single-launch form of small panels; NULL = six-launch chain
+// state: the block from cholqr_begin, or NULL = the head of ws (cleared with cholqr_reset)
 int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows,
-                          int b, void* ws, int64_t ws_bytes, uint64_t seed, int* fused_base);
+                          int b, void* ws, int64_t ws_bytes, uint64_t seed, int* fused_base, void* state = nullptr);
 // the whole panel step: orthonormal basis, and with reconstruct != 0 the Householder reconstruction (Y, T, W = Y T^T, Wq = Y T)
 int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws,
-                 int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq, int* fused_base);
+                 int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq, int* fused_base,
+                 void* state = nullptr);
 int cholqr_debug_state(hipStream_t st, const void* ws, int* ints9, double* dev_hist);
 int cholqr_stats(unsigned long long* out16, int reset, hipStream_t st_or_null, int all_streams);
 

@@ -417,8 +417,11 @@ __global__ __launch_bounds__(256) void rows_times_small3_mfma_kernel(double* __r
 // One workgroup per diagonal block: Householder QR  D = Z Tri  with diag(Tri) >= 0.
 template <int NB>
 __global__ __launch_bounds__(256) void diag_qr_kernel(const double* __restrict__ A, int64_t rs, int64_t cs, int nb,
-                                                      int64_t k, double* __restrict__ Zbuf, double* __restrict__ Tri) {
+                                                      int64_t k, double* __restrict__ Zbuf, double* __restrict__ Tri, int* clear64) {
     constexpr int P = NB + 1;
+    // the first launch after the last panel of the factorisation: leaves the stream's panel state block (64 words) clean for the
+    // next call (cholqr_begin)
+    if (clear64 && blockIdx.x == 0 && threadIdx.x < 64) clear64[threadIdx.x] = 0;
     __shared__ double D[NB * P];
     __shared__ double Z[NB * P];
     __shared__ double tau[NB];
@@ -633,9 +636,9 @@ static bool panel_tsqr() {
     return e && e[0] == 't';
 }
 static int panel_orthonormalize(hipStream_t st, const double* Xin, int64_t irs, int64_t ics, double* X, int64_t rs, int64_t cs, int64_t nrows,
-                                int b, void* ws, int64_t ws_bytes, bool tsqr, uint64_t seed, int* fused_base) {
+                                int b, void* ws, int64_t ws_bytes, bool tsqr, uint64_t seed, int* fused_base, void* state) {
     if (tsqr) return tsqr_orthonormalize(st, Xin, irs, ics, X, rs, cs, nrows, b, ws, ws_bytes);
-    return cholqr_orthonormalize(st, Xin, irs, ics, X, rs, cs, nrows, b, ws, ws_bytes, seed, fused_base);
+    return cholqr_orthonormalize(st, Xin, irs, ics, X, rs, cs, nrows, b, ws, ws_bytes, seed, fused_base, state);
 }
 
 constexpr int QR_NBO_MAX = 256;       // widest outer block of the two-level factorisation
@@ -648,6 +651,7 @@ struct QrWs {
     int64_t gemm_ws_bytes;
     void* tsqr_ws;
     int64_t tsqr_bytes;
+    void* cq_state = nullptr;      // the stream's panel state block (cholqr_begin), or NULL = head of tsqr_ws
 };
 
 static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
@@ -743,10 +747,10 @@ static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k,
             if (!use_tsqr) {
                 // orthonormalisation + Householder reconstruction + the tall products in one chain of launches (cholqr.hip)
                 if ((rc = cholqr_panel(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, (uint64_t)p + 1, 1, Tp, Wp.p, wrs, wcs,
-                                       nullptr, fused_base)))
+                                       nullptr, fused_base, w.cq_state)))
                     return rc;
             } else {
-            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1, fused_base))) return rc;
+            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1, fused_base, w.cq_state))) return rc;
             // Wq_top goes to a scratch corner of the (otherwise unused here) Wq buffer: only Y, T and W = Y T^T are needed
             TN_PROF_LAUNCH(st, PROF_LU, hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT,
                                w.UTq, Wp.p, wrs, wcs, w.Wq));
@@ -789,8 +793,9 @@ static int qr_two_level(hipStream_t st, Mat Am, int64_t m, int64_t n, int64_t k,
     }
     // --- triangularise the diagonal blocks, assemble R (as in the single-level path)
     const int P = (int)cdiv(k, nb);
-    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, Am.p, rs, cs, nb, k, w.Z, w.Tri));
+    TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, Am.p, rs, cs, nb, k, w.Z, w.Tri, (int*)w.cq_state));
     TN_CHECK_LAUNCH("diag_qr_kernel");
+    if (w.cq_state) cholqr_end_ok(st);
     // --- Q = H_blk1 ... H_blkB [Z; 0]:  Q[J0:, J0:] -= Y_blk (T_blk (Y_blk^T Q[J0:, J0:]))
     const int qcolfast = (qcs == 1) ? 1 : 0;
     {
@@ -963,7 +968,7 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
     Mat Am = mat(A, rs, cs), Ym = mat(w.Y, yrs, ycs), Wqm = mat(w.Wq, yrs, ycs);
     int rc;
     const bool use_tsqr = panel_tsqr();
-    if (nb == 32 && !use_tsqr && (rc = cholqr_reset(st, w.tsqr_ws))) return rc;
+    if (nb == 32 && !use_tsqr && (rc = cholqr_begin(st, w.tsqr_ws, &w.cq_state))) return rc;
     int fbase = 0;                            // arrivals booked by the single-launch panel steps of this call (cholqr.hip)
     {   // two-level blocking for the plain factorisation of matrices with several outer blocks (TN_QR_NBO = 0 disables it)
         const char* e_nbo = getenv("TN_QR_NBO");                      // read per call: the tests switch it
@@ -1018,10 +1023,10 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
             double* Tpf = w.T + (int64_t)p * nb * nb;
             Mat Wqf = sub(Wqm, j0, j0), Wpf = mat((lookahead && (p & 1)) ? w.W2 : w.W, wrs, wcs);
             if ((rc = cholqr_panel(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, (uint64_t)p + 1, 1, Tpf, Wpf.p, wrs, wcs,
-                                   Wqf.p, &fbase)))
+                                   Wqf.p, &fbase, w.cq_state)))
                 return rc;
         } else if (nb == 32) {
-            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1, &fbase))) return rc;
+            if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1, &fbase, w.cq_state))) return rc;
         } else {
             if ((rc = copy_mat(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b))) return rc;
             const int nchunk = gram_nchunk(mp);
@@ -1128,9 +1133,10 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
     if ((rc = join_wide())) return rc;
     if (keff_host) *keff_host = k;
     // --- triangularise the diagonal blocks, assemble R
-    if (nb == 32) TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri));
-    else TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<64>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri));
+    if (nb == 32) TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri, (int*)w.cq_state));
+    else TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<64>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri, (int*)nullptr));
     TN_CHECK_LAUNCH("diag_qr_kernel");
+    if (w.cq_state) cholqr_end_ok(st);
     dbg_check(st, w.Z, nb, 1, (int64_t)P * nb, nb, "Z", -1, 0);
     dbg_check(st, w.Tri, nb, 1, (int64_t)P * nb, nb, "Tri", -1, 0);
     // --- Q = H_1 ... H_P [Z; 0]; the last panel's reflector is applied by the launch that writes [Z; 0] (nb = 32)
