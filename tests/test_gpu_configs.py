@@ -314,7 +314,7 @@ def _solve_with(mode, make, **kw):
             os.environ['TN_BEAM'] = saved
 
 
-@pytest.mark.parametrize('case', ['L128_1', 'L128_2_rot1', 'L128_3_chi32', 'L512', 'J124', 'rmf'])
+@pytest.mark.parametrize('case', ['L128_1', 'L128_2_rot1', 'L128_3_chi32', 'L512', 'J124', 'rmf', 'L128_nocut', 'L128_M1'])
 def test_beam_on_device_bit_identical_to_host_merge(case):
     """a12 (reference tnac4o.py:437-537: cut-off, merge of equal boundary indices, top-M) resident on the GPU -- walked by the library
     (tn_beam_search: hipCUB radix sorts, tn_merge_groups) and by the torch driver of tnac4o_amd/beam.py (torch.unique on rank keys,
@@ -328,6 +328,10 @@ def test_beam_on_device_bit_identical_to_host_merge(case):
         make = lambda: gpu_solver()
     elif case == 'L128_2_rot1':
         make = lambda: gpu_solver(ins=2, rot=1)
+    elif case == 'L128_nocut':                                    # no probability cut-off: every candidate reaches the merge, top-M does the pruning
+        make, kw = (lambda: gpu_solver(ins=2, rot=3)), dict(M=48, relative_P_cutoff=0.0, Dmax=8)
+    elif case == 'L128_M1':                                       # greedy descent: one branch
+        make, kw = (lambda: gpu_solver()), dict(M=1, relative_P_cutoff=1e-3, Dmax=8)
     elif case == 'L128_3_chi32':
         make, kw = (lambda: gpu_solver(ins=3, rot=2)), dict(M=1024, relative_P_cutoff=1e-8, Dmax=32)
     elif case == 'L512':
