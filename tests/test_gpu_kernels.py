@@ -652,6 +652,35 @@ def test_panel_single_launch_bit_identical_to_chain(ops):
     assert n >= 12
 
 
+def test_tiny_qr_single_workgroup(ops):
+    """tn_qr on matrices of at most 4096 elements with min(m, n) <= 32 runs in ONE workgroup (tiny_qr_kernel: Householder in LDS):
+    Q orthonormal, Q R = A, R upper triangular with diag(R) >= 0 -- on full-rank, rank-deficient, zero and badly scaled inputs -- and
+    the same factors as the blocked path (TN_QR_TINY=0) where they are unique."""
+    g = torch.Generator(device='cpu').manual_seed(11)
+    rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g)
+    dup = rn(200, 12)
+    dup[:, 5] = dup[:, 2]
+    dup[:, 9] = 0.0
+    cases = [('1x1', rn(1, 1)), ('1x1 negative', -rn(1, 1).abs()), ('1x300', rn(1, 300)), ('300x1', rn(300, 1)), ('16x16', rn(16, 16)),
+             ('256x16', rn(256, 16)), ('128x32', rn(128, 32)), ('5x700', rn(5, 700)), ('32x128', rn(32, 128)), ('4096x1', rn(4096, 1)),
+             ('dependent', dup), ('zero', torch.zeros(40, 8, dtype=torch.float64)), ('scaled', rn(100, 20) * 1e150),
+             ('small', rn(100, 20) * 1e-150), ('transposed view', rn(24, 150).t())]
+    for name, Th in cases:
+        T = Th.cuda()
+        m, n = T.shape
+        k = min(m, n)
+        Q, R = ops.qr(T)
+        Qh, Rh, A = Q.cpu().numpy(), R.cpu().numpy(), Th.numpy()
+        sc = max(np.abs(A).max(), 1e-300)
+        assert np.abs(Qh.T @ Qh - np.eye(k)).max() < 1e-13, name
+        assert np.abs(Qh @ Rh - A).max() <= 1e-13 * sc, name
+        assert np.abs(np.tril(Rh, -1)).max() == 0.0 and (np.diag(Rh) >= 0).all(), name
+        if name not in ('dependent', 'zero'):
+            Q0, R0 = _with_env('TN_QR_TINY', '0', lambda: ops.qr(T))
+            assert np.abs(R0.cpu().numpy() - Rh).max() <= 1e-12 * sc, name
+            assert np.abs(Q0.cpu().numpy() - Qh).max() <= 1e-11, name
+
+
 def test_hard_panels_of_a_real_sweep(ops):
     """tests/golden/g12_hard_panels.npz: the panels of tn_qr that needed FOUR substitution passes in the boundary-MPS sweep of the
     headline instance (chimera L = 2048, chi = 64, seed 20260004; 11 of 6 025 panels, the nine of <= 4096 rows kept; condition numbers

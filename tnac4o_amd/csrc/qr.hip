@@ -616,6 +616,136 @@ __global__ __launch_bounds__(256) void colnorm2_kernel(const double* __restrict_
     if (tid == 0) out[j] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- tiny factorisations in ONE workgroup -----------------------------------------------------------------------------------
+// A sweep makes ~450 factorisations of at most 4096 elements (1 x 1 edge sites, 16 x 16, 256 x 16 ...): through the blocked path
+// each is a dozen launches, ~100 us of pure launch latency.  Here: the matrix in LDS, Householder QR column by column with all 256
+// threads (thread (c, g) = column c, row group g; per column one pass gives sum_{r>j} a_rj a_rc for every c, from which the
+// reflector and its action follow -- the scheme of diag_qr_kernel), backward accumulation of Q = H_0 ... H_{k-1} [I; 0], signs
+// chosen so that diag(R) >= 0.  Entries are first scaled into [0.5, 1) by a power of two.  m n <= 4096, k = min(m, n) <= 32.
+__global__ __launch_bounds__(256) void tiny_qr_kernel(const double* __restrict__ A, int64_t rs, int64_t cs, int m, int n, double* __restrict__ Q,
+                                                      int64_t qrs, int64_t qcs, double* __restrict__ R, int64_t rrs, int64_t rcs) {
+    __shared__ double As[4096];          // m x n, pitch n; below the diagonal: the reflectors (unit diagonal implied)
+    __shared__ double Qs[4096];          // m x k, pitch k
+    __shared__ double scol[4096];        // per column: sum over the rows below the pivot row
+    __shared__ double part[256];
+    __shared__ double taus[32];
+    __shared__ double dscale_s;
+    const int tid = threadIdx.x;
+    const int k = m < n ? m : n;
+    {
+        double mx = 0.0;
+        for (int e = tid; e < m * n; e += 256) {
+            const double x = A[(int64_t)(e / n) * rs + (int64_t)(e % n) * cs];
+            As[e] = x;
+            const double a = fabs(x);
+            mx = (a == a) ? fmax(mx, a) : 1.7e308;
+        }
+        part[tid] = mx;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if (tid < h) part[tid] = fmax(part[tid], part[tid + h]);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            int ex = 0;
+            if (part[0] > 0.0 && part[0] < 1.7e308) frexp(part[0], &ex);
+            dscale_s = ldexp(1.0, ex);
+        }
+        __syncthreads();
+        const double scl = 1.0 / dscale_s;
+        for (int e = tid; e < m * n; e += 256) As[e] *= scl;
+        __syncthreads();
+    }
+    // columns over NC thread-columns (a power of two >= n, at most 256), rows over NG = 256 / NC groups
+    int NC = 16;
+    while (NC < n && NC < 256) NC <<= 1;
+    const int NG = 256 / NC;
+    const int cc = tid % NC, g = tid / NC;
+    for (int j = 0; j < k; ++j) {
+        for (int c = cc; c < n; c += NC) {
+            double acc = 0.0;
+            if (c >= j)
+                for (int r = j + 1 + g; r < m; r += NG) acc += As[r * n + j] * As[r * n + c];
+            if (NG > 1) part[g * NC + cc] = acc;             // (NG > 1 means n <= NC: one column per thread-column)
+            else scol[c] = acc;
+        }
+        __syncthreads();
+        if (NG > 1 && g == 0 && cc < n) {
+            double acc = 0.0;
+            for (int h = 0; h < NG; ++h) acc += part[h * NC + cc];
+            scol[cc] = acc;
+        }
+        __syncthreads();
+        const double alpha = As[j * n + j], sigma = scol[j];
+        double tau = 0.0, beta = alpha, inv = 0.0;
+        if (sigma > 0.0 && alpha * alpha + sigma > 1e-290) {     // nothing below the diagonal -> H = I (like dlarfg)
+            const double nrm = sqrt(alpha * alpha + sigma);
+            beta = -copysign(nrm, alpha);
+            tau = (beta - alpha) / beta;
+            inv = 1.0 / (alpha - beta);
+        }
+        double wreg[16];                                          // w_c of this thread's columns (n <= 4096 = 16 x 256)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = cc + NC * u;
+            wreg[u] = (c < n && c > j) ? tau * (As[j * n + c] + inv * scol[c]) : 0.0;
+        }
+        __syncthreads();                                          // row j is rewritten below
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = cc + NC * u;
+            if (c < n && c > j && tau != 0.0) {
+                const double w = wreg[u];
+                for (int r = j + 1 + g; r < m; r += NG) As[r * n + c] -= As[r * n + j] * inv * w;
+                if (g == 0) As[j * n + c] -= w;
+            }
+        }
+        __syncthreads();                                          // column j was read unscaled by the updates above
+        for (int r = j + 1 + tid; r < m; r += 256) As[r * n + j] *= inv;
+        if (tid == 0) { As[j * n + j] = beta; taus[j] = tau; }
+        __syncthreads();
+    }
+    // Q = H_0 ... H_{k-1} [I; 0]
+    for (int e = tid; e < m * k; e += 256) Qs[e] = (e / k == e % k) ? 1.0 : 0.0;
+    __syncthreads();
+    int NQ = 16;
+    while (NQ < k) NQ <<= 1;
+    const int NGq = 256 / NQ, cq = tid % NQ, gq = tid / NQ;
+    for (int j = k - 1; j >= 0; --j) {
+        const double tau = taus[j];
+        if (tau != 0.0) {                                         // uniform
+            double acc = 0.0;
+            if (cq >= j && cq < k)
+                for (int r = j + 1 + gq; r < m; r += NGq) acc += As[r * n + j] * Qs[r * k + cq];
+            part[gq * NQ + cq] = acc;
+            __syncthreads();
+            double w = 0.0;
+            if (cq >= j && cq < k) {
+                for (int h = 0; h < NGq; ++h) w += part[h * NQ + cq];
+                w = tau * (Qs[j * k + cq] + w);
+            }
+            __syncthreads();
+            if (cq >= j && cq < k) {
+                for (int r = j + 1 + gq; r < m; r += NGq) Qs[r * k + cq] -= As[r * n + j] * w;
+                if (gq == 0) Qs[j * k + cq] -= w;
+            }
+            __syncthreads();
+        }
+    }
+    const double ds = dscale_s;
+    for (int e = tid; e < k * n; e += 256) {
+        const int i = e / n, c = e % n;
+        const double sg = (As[i * n + i] < 0.0) ? -1.0 : 1.0;
+        R[(int64_t)i * rrs + (int64_t)c * rcs] = (c >= i) ? sg * As[i * n + c] * ds : 0.0;
+    }
+    if (Q)
+        for (int e = tid; e < m * k; e += 256) {
+            const int r = e / k, j = e % k;
+            const double sg = (As[j * n + j] < 0.0) ? -1.0 : 1.0;
+            Q[(int64_t)r * qrs + (int64_t)j * qcs] = sg * Qs[e];
+        }
+}
+
 // ------------------------------------------------------------------------------------------ driver
 // TN_DEBUG=1: synchronise after each stage and report the first non-finite intermediate (diagnostics only)
 static bool dbg_on() { static int v = -1; if (v < 0) { const char* e = getenv("TN_DEBUG"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
@@ -894,7 +1024,8 @@ struct QrTrace {
         for (int c = 0; c < 7; ++c)
             fprintf(stderr, "  [%s] %ld calls, %.1f ms, mean rows %.0f, mean accepted rank %.1f\n", cn[c], cat_calls[c], cat_ms[c],
                     cat_calls[c] ? cat_m[c] / cat_calls[c] : 0.0, cat_calls[c] ? cat_rank[c] / cat_calls[c] : 0.0);
-        for (size_t i = 0; i < v.size() && i < 60; ++i) {
+        static const size_t rows = [] { const char* e = getenv("TN_QR_TRACE_ROWS"); return e ? (size_t)atol(e) : (size_t)60; }();
+        for (size_t i = 0; i < v.size() && i < rows; ++i) {
             auto& k = v[i].second;
             auto& st = tab[k];
             fprintf(stderr, "  %6lld %6lld  %d %d %d : %6ld  %8.2f  %8.2f  %7.1f\n", (long long)std::get<0>(k), (long long)std::get<1>(k), std::get<2>(k),
@@ -943,9 +1074,20 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
     if (dropped2_host) *dropped2_host = 0.0;
     TN_CHECK_ARG(nb == 32 || nb == 64, "nb must be 32 or 64");
     TN_CHECK_ARG(ws_bytes >= qr_ws_bytes(m, n, nb), "workspace too small");
+    int64_t k = m < n ? m : n;
+    {   // tiny matrices: the whole factorisation in one workgroup (TN_QR_TINY=0: the blocked path; read per call: the tests switch it)
+        const char* e_tiny = getenv("TN_QR_TINY");
+        const bool tiny_on = !(e_tiny && e_tiny[0] == '0');
+        if (tiny_on && nb == 32 && pivot_perm_host == nullptr && m * n <= 4096 && k <= 32) {
+            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(tiny_qr_kernel, dim3(1), dim3(256), 0, st, (const double*)A, rs, cs, (int)m, (int)n, Q, qrs, qcs,
+                               R, rrs, rcs));
+            TN_CHECK_LAUNCH("tiny_qr_kernel");
+            if (keff_host) *keff_host = k;
+            return 0;
+        }
+    }
     QrWs w;
     qr_layout(m, n, nb, (char*)ws, &w);
-    int64_t k = m < n ? m : n;
     int P = (int)cdiv(k, nb);
     const int64_t kfull = k;
     double scale2 = -1.0;                                            // largest squared column norm of the input (lazily read back)
