@@ -11,6 +11,9 @@
 // Rotations are exactly orthogonal to rounding; the Gram matrix only steers them, so small singular values keep the
 // one-sided Jacobi accuracy.  Host syncs: one for deflation, one per sweep (convergence), one for the kept rank.
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -432,9 +435,59 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
 
 // C is k x n (element strides crs, ccs).  U: k x keep (urs, ucs), Vt: keep x n (vrs, vcs), S: keep values.
 // keep_out / discarded_out / hostS_out are host pointers.
+// TN_SVD_CENSUS=1 (diagnostics): every tn_svd_trunc call is timed synchronously and booked under its shape; table at exit.
+namespace {
+struct SvdCensus {
+    bool on;
+    std::mutex mu;
+    std::map<std::pair<int64_t, int64_t>, std::tuple<double, long, double>> tab;       // (k, n) -> ms, calls, sweeps
+    SvdCensus() { const char* e = getenv("TN_SVD_CENSUS"); on = e && e[0] == '1'; }
+    ~SvdCensus() {
+        if (!on || tab.empty()) return;
+        std::vector<std::pair<double, std::pair<int64_t, int64_t>>> v;
+        double tot = 0.0;
+        long calls = 0;
+        for (auto& kv : tab) { v.push_back({std::get<0>(kv.second), kv.first}); tot += std::get<0>(kv.second); calls += std::get<1>(kv.second); }
+        std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first > b.first; });
+        fprintf(stderr, "[tn_svd census] %zu shapes, %ld calls, %.1f ms in total; k n : calls, ms, us/call, mean sweeps\n", v.size(), calls, tot);
+        for (auto& e : v) {
+            auto& t = tab[e.second];
+            fprintf(stderr, "  %5lld %5lld : %5ld  %8.2f  %8.2f  %5.2f\n", (long long)e.second.first, (long long)e.second.second, std::get<1>(t), std::get<0>(t),
+                    1e3 * std::get<0>(t) / std::get<1>(t), std::get<2>(t) / std::get<1>(t));
+        }
+    }
+};
+SvdCensus g_svd_census;
+}  // namespace
+
+static int svd_trunc_impl(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol,
+                          double* U, int64_t urs, int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_out,
+                          double* discarded_out, int* sweeps_out, int* info, void* ws, int64_t ws_bytes);
+
 int svd_trunc(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol,
               double* U, int64_t urs, int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_out,
               double* discarded_out, int* sweeps_out, int* info, void* ws, int64_t ws_bytes) {
+    if (!g_svd_census.on)
+        return svd_trunc_impl(st, C, crs, ccs, k, n, Dmax, tol, U, urs, ucs, S, Vt, vrs, vcs, keep_out, discarded_out, sweeps_out, info, ws, ws_bytes);
+    thread_local hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!e0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+    int sw = 0;
+    (void)hipEventRecord(e0, st);
+    const int rc = svd_trunc_impl(st, C, crs, ccs, k, n, Dmax, tol, U, urs, ucs, S, Vt, vrs, vcs, keep_out, discarded_out, &sw, info, ws, ws_bytes);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    if (sweeps_out) *sweeps_out = sw;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::lock_guard<std::mutex> lk(g_svd_census.mu);
+    auto& t = g_svd_census.tab[{k, n}];
+    std::get<0>(t) += ms; std::get<1>(t) += 1; std::get<2>(t) += sw;
+    return rc;
+}
+
+static int svd_trunc_impl(hipStream_t st, const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol,
+                          double* U, int64_t urs, int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_out,
+                          double* discarded_out, int* sweeps_out, int* info, void* ws, int64_t ws_bytes) {
     TN_CHECK_ARG(k >= 1 && n >= 1 && Dmax >= 1, "bad dimensions");
     TN_CHECK_ARG(ws_bytes >= svd_ws_bytes(k, n, 1), "workspace too small");
     const bool rows = k <= n;
