@@ -652,6 +652,41 @@ def test_panel_single_launch_bit_identical_to_chain(ops):
     assert n >= 12
 
 
+def test_small_truncated_svd_single_launch(ops):
+    """tn_svd_trunc with both dimensions <= 64 runs in ONE launch (svd_trunc_small_kernel: Hestenes sweeps with the rotations kept
+    beside the vectors, truncation rule, sign gauge and outputs in the same workgroup): factors orthonormal, U S Vt = C to rounding,
+    and kept rank / values / discarded weight as the block path (TN_SVD_SMALL=0) gives them -- square, wide, tall, rank-deficient,
+    graded, 1 x 1 and strided inputs, with and without a truncation to Dmax."""
+    g = torch.Generator(device='cpu').manual_seed(21)
+    rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g)
+    graded = (rn(60, 60) * torch.logspace(0, -18, 60, dtype=torch.float64)[None, :]) @ torch.linalg.qr(rn(60, 60))[0]
+    lowrank = rn(40, 7) @ rn(7, 33)
+    cases = [('1x1', rn(1, 1), 64), ('16x16', rn(16, 16), 64), ('64x64', rn(64, 64), 64), ('64x64 Dmax 20', rn(64, 64), 20), ('15x60', rn(15, 60), 64),
+             ('60x15', rn(60, 15), 8), ('graded', graded, 64), ('low rank', lowrank, 64), ('view', rn(50, 90)[:40, 10:70:2], 64),
+             ('scaled', rn(30, 30) * 1e120, 64)]
+    for name, Ch, Dmax in cases:
+        Cm = Ch.cuda()
+        k, n = Cm.shape
+        U, S, Vt, keep, disc, info = ops.svd_trunc(Cm, Dmax, 1e-16)
+        Sh = S.cpu().numpy()
+        if name != 'scaled':            # (entries of 1e120: the block path's Gram matrices overflow; the single launch scales its input)
+            U0, S0, Vt0, keep0, disc0, info0 = _with_env('TN_SVD_SMALL', '0', lambda: ops.svd_trunc(Cm, Dmax, 1e-16))
+            assert keep == keep0, (name, keep, keep0)
+            S0h = S0.cpu().numpy()
+            assert np.abs(Sh - S0h).max() <= 1e-13 * S0h[0], name
+            assert abs(disc - disc0) <= 1e-12 * max(disc0, 1e-300) + 1e-15, (name, disc, disc0)
+        Uh, Vh = U.cpu().numpy(), Vt.cpu().numpy()
+        assert np.abs(Uh.T @ Uh - np.eye(keep)).max() < 1e-13 and np.abs(Vh @ Vh.T - np.eye(keep)).max() < 1e-13, name
+        full = np.linalg.svd(Ch.numpy(), compute_uv=False)
+        assert np.abs(Sh - full[:keep]).max() <= 1e-13 * full[0], name
+        err = np.abs((Uh * Sh[None, :]) @ Vh - Ch.numpy()).max()
+        tail = full[keep] if keep < full.size else 0.0
+        assert err <= 1e-12 * full[0] + 1.01 * tail, (name, err, tail)
+        # the reference's sign gauge holds on both sides
+        flip = (np.abs(Uh.min(0)) > Uh.max(0)) & (np.abs(Vh.min(1)) > Vh.max(1))
+        assert not flip.any(), name
+
+
 def test_tiny_qr_single_workgroup(ops):
     """tn_qr on matrices of at most 4096 elements with min(m, n) <= 32 runs in ONE workgroup (tiny_qr_kernel: Householder in LDS):
     Q orthonormal, Q R = A, R upper triangular with diag(R) >= 0 -- on full-rank, rank-deficient, zero and badly scaled inputs -- and

@@ -239,6 +239,184 @@ __global__ __launch_bounds__(256) void svd_vals_small_batched_kernel(const int64
     svd_vals_small_body(reinterpret_cast<const double*>(d[0]), d[1], d[2], (int)d[3], (int)d[4], out + 66 * (int64_t)blockIdx.x, X, nrm, flags);
 }
 
+// ---- truncated SVD of a small centre matrix (both dimensions <= 64) in ONE launch ---------------------------------------------
+// A sweep truncates ~150 centre matrices of at most 64 x 64 (the bonds next to the edges of the boundary MPS: 1 x 1, 16 x 16,
+// 60 x 60 ...); through the block path each costs a dozen launches and four read-backs, 80-330 us of pure latency.  Here: the
+// Hestenes sweeps of svd_vals_small_body with the accumulated rotations kept beside the vectors (Pm starts as the identity and is
+// rotated along: U = Pm^T), then -- all in the same workgroup -- the values sorted by rank counting, the truncation rule of
+// mps.py:805-806 (keep S > S0 max(eps, tol), at most Dmax; discarded weight added up from the smallest value as the host does),
+// the reference's sign gauge (mps.py:35-39) and the three outputs.  res (DEVICE, 4 doubles): keep, discarded, sweeps, converged.
+__global__ __launch_bounds__(256) void svd_trunc_small_kernel(const double* __restrict__ M, int64_t vs, int64_t es, int nv, int L, int Dmax, double t,
+                                                              double* __restrict__ Sout, double* __restrict__ left, int64_t lrs, int64_t lcs,
+                                                              double* __restrict__ right, int64_t rrs, int64_t rcs, double* __restrict__ res) {
+    constexpr int NV = 64, P = 66;
+    __shared__ double X[NV * P];
+    __shared__ double Pm[NV * P];
+    __shared__ double nrm[NV];
+    __shared__ double ssort[NV];
+    __shared__ int order[NV];
+    __shared__ int flags[2];
+    __shared__ int s_keep;
+    const int tid = threadIdx.x, slot = tid >> 3, sub = tid & 7;
+    double relevant2 = 0.0, dscale = 1.0;
+    {
+        double xv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u, r = e >> 6, c = e & 63;
+            xv[u] = (r < nv && c < L) ? M[(int64_t)r * vs + (int64_t)c * es] : 0.0;
+        }
+        // entries scaled into [0.5, 1) by a power of two (squares of squares must neither overflow nor underflow); NaN / Inf pass
+        // through to the norm check below
+        double mx = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const double a = fabs(xv[u]); mx = (a == a) ? fmax(mx, a) : mx; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+        if ((tid & 63) == 0) nrm[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmax(fmax(nrm[0], nrm[1]), fmax(nrm[2], nrm[3]));
+        int ex = 0;
+        if (mx > 0.0 && mx < 1.7e308) frexp(mx, &ex);
+        dscale = ldexp(1.0, ex);
+        const double scl = ldexp(1.0, -ex);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u, r = e >> 6, c = e & 63;
+            X[r * P + c] = xv[u] * scl;
+            Pm[r * P + c] = (r == c) ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    auto seg_dot3 = [&](const double* xp, const double* xq, double& a, double& b, double& g) {
+        a = 0.0; b = 0.0; g = 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a += xp[e] * xp[e]; b += xq[e] * xq[e]; g += xp[e] * xq[e]; }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); g += __shfl_xor(g, o, 64); }
+    };
+    {   // squared norms of rows 2 slot, 2 slot + 1; rows below 2^-56 of the largest are dropped (as jacobi_core does)
+        double xp[8], xq[8], a, b, g;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xp[e] = X[(2 * slot) * P + sub * 8 + e]; xq[e] = X[(2 * slot + 1) * P + sub * 8 + e]; }
+        seg_dot3(xp, xq, a, b, g);
+        if (sub == 0) { nrm[2 * slot] = a; nrm[2 * slot + 1] = b; }
+        __syncthreads();
+        double nmax = 0.0;
+        bool bad = false;
+        for (int r = 0; r < NV; ++r) { nmax = fmax(nmax, nrm[r]); bad = bad || !(nrm[r] == nrm[r]) || nrm[r] > 1.7e308; }
+        if (bad) {                                               // non-finite input (uniform): reported through a NaN discarded weight
+            if (tid == 0) { res[0] = 0.0; res[1] = __longlong_as_double(0x7ff8000000000000LL); res[2] = 0.0; res[3] = 0.0; }
+            return;
+        }
+        const double thr = nmax * 1.9259299443872359e-34;       // (2^-56)^2
+        relevant2 = nmax * 3.0814879110195774e-33;              // (2^-54)^2
+        if (!(a > thr)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) X[(2 * slot) * P + sub * 8 + e] = 0.0;
+        }
+        if (!(b > thr)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) X[(2 * slot + 1) * P + sub * 8 + e] = 0.0;
+        }
+    }
+    const double tol2 = 7.888609052210118e-31;                   // (2^-50)^2
+    const double conv2 = 1.6e-29;                                // (4e-15)^2
+    int sweeps = 0, converged = 0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        if (tid < 2) flags[tid] = 0;
+        __syncthreads();
+        int any = 0, big = 0;
+        for (int s = 0; s < NV - 1; ++s) {
+            int p, q;
+            rr_pair64(s, slot, p, q);
+            double xp[8], xq[8], a, b, g;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xp[e] = X[p * P + sub * 8 + e]; xq[e] = X[q * P + sub * 8 + e]; }
+            seg_dot3(xp, xq, a, b, g);
+            const double g2 = g * g, ab = a * b;
+            if (g2 > tol2 * ab) {
+                const double d = b - a;
+                const double rh = fast_rsqrt(d * d + 4.0 * g2);
+                const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+                const double rcv = fast_rsqrt(c2);
+                const double sabs = fabs(g) * rh * rcv;
+                if (sabs <= 1.0 && c2 <= 1.0000000000000002) {
+                    const double c = c2 * rcv, sn = ((d >= 0.0) == (g >= 0.0)) ? sabs : -sabs;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        X[p * P + sub * 8 + e] = c * xp[e] - sn * xq[e];
+                        X[q * P + sub * 8 + e] = sn * xp[e] + c * xq[e];
+                        const double up = Pm[p * P + sub * 8 + e], uq = Pm[q * P + sub * 8 + e];
+                        Pm[p * P + sub * 8 + e] = c * up - sn * uq;
+                        Pm[q * P + sub * 8 + e] = sn * up + c * uq;
+                    }
+                    any = 1;
+                    if (g2 > conv2 * ab && fmin(a, b) > relevant2) big = 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (any && sub == 0) atomicOr(&flags[0], 1);
+        if (big && sub == 0) atomicOr(&flags[1], 1);
+        __syncthreads();
+        ++sweeps;
+        const int f1 = flags[1];
+        __syncthreads();
+        if (!f1) { converged = 1; break; }
+    }
+    {   // singular values = row norms, sorted descending by rank counting (ties: the lower row first)
+        double xp[8], xq[8], a, b, g;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xp[e] = X[(2 * slot) * P + sub * 8 + e]; xq[e] = X[(2 * slot + 1) * P + sub * 8 + e]; }
+        seg_dot3(xp, xq, a, b, g);
+        if (sub == 0) { nrm[2 * slot] = a; nrm[2 * slot + 1] = b; }
+        __syncthreads();
+        if (tid < NV) {
+            const double mine = nrm[tid];
+            int rank = 0;
+            for (int r = 0; r < NV; ++r) rank += (nrm[r] > mine || (nrm[r] == mine && r < tid)) ? 1 : 0;
+            ssort[rank] = sqrt(mine);
+            order[rank] = tid;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double s0 = ssort[0];
+            int keep = 0;
+            for (int i = 0; i < nv; ++i) keep += (ssort[i] > s0 * t) ? 1 : 0;
+            if (keep > Dmax) keep = Dmax;
+            double d2 = 0.0;
+            for (int i = nv - 1; i >= keep; --i) d2 += ssort[i] * ssort[i];
+            s_keep = keep;
+            res[0] = (double)keep;
+            res[1] = s0 > 0.0 ? sqrt(d2) / s0 : 0.0;
+            res[2] = (double)sweeps;
+            res[3] = (double)converged;
+        }
+        __syncthreads();
+    }
+    // kept vector j (source row order[j]): 8 threads per vector, two rounds of 32 vectors
+    const int keep = s_keep;
+    for (int j = slot; j < keep; j += 32) {
+        const int row = order[j];
+        const double sv = ssort[j];
+        double xmin = 1e308, xmax = -1e308, pmin = 1e308, pmax = -1e308;
+        for (int c = sub; c < L; c += 8) { const double v = X[row * P + c]; xmin = fmin(xmin, v); xmax = fmax(xmax, v); }
+        for (int c = sub; c < nv; c += 8) { const double v = Pm[row * P + c]; pmin = fmin(pmin, v); pmax = fmax(pmax, v); }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            xmin = fmin(xmin, __shfl_xor(xmin, o, 64)); xmax = fmax(xmax, __shfl_xor(xmax, o, 64));
+            pmin = fmin(pmin, __shfl_xor(pmin, o, 64)); pmax = fmax(pmax, __shfl_xor(pmax, o, 64));
+        }
+        const double sg = (fabs(pmin) > pmax && fabs(xmin) > xmax) ? -1.0 : 1.0;
+        const double inv = sv > 0.0 ? sg / sv : 0.0;
+        if (sub == 0) Sout[j] = sv * dscale;
+        for (int c = sub; c < L; c += 8) right[(int64_t)j * rrs + (int64_t)c * rcs] = X[row * P + c] * inv;
+        for (int c = sub; c < nv; c += 8) left[(int64_t)c * lrs + (int64_t)j * lcs] = Pm[row * P + c] * sg;
+    }
+}
+
 // Page-locked slot 3 stages the asynchronous uploads of this file (tournament schedule, kept values / order).  An upload is only
 // guaranteed to have been consumed once ITS stream has passed a synchronisation; a thread that moves on to another stream must not
 // overwrite the slot while the previous stream may still be waiting to read it.
@@ -493,6 +671,34 @@ static int svd_trunc_impl(hipStream_t st, const double* C, int64_t crs, int64_t 
     const bool rows = k <= n;
     const int64_t nv = rows ? k : n, L = rows ? n : k;
     const int64_t vs = rows ? crs : ccs, es = rows ? ccs : crs;
+    {   // both dimensions <= 64: the whole truncated SVD in one launch and one read-back (TN_SVD_SMALL=0: the block path; read per call)
+        const char* e_small = getenv("TN_SVD_SMALL");
+        if (k <= 64 && n <= 64 && !(e_small && e_small[0] == '0')) {
+            const double eps = 2.220446049250313e-16;
+            const double t = tol > eps ? tol : eps;
+            double* res = (double*)ws;
+            // rows: left = U (k x keep), right = Vt.  columns (C^T was factored): left = Vt^T, right = U^T.
+            if (rows)
+                TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_trunc_small_kernel, dim3(1), dim3(256), 0, st, C, vs, es, (int)nv, (int)L, (int)std::min<int64_t>(Dmax, 64), t,
+                                   S, U, urs, ucs, Vt, vrs, vcs, res));
+            else
+                TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_trunc_small_kernel, dim3(1), dim3(256), 0, st, C, vs, es, (int)nv, (int)L, (int)std::min<int64_t>(Dmax, 64), t,
+                                   S, Vt, vcs, vrs, U, ucs, urs, res));
+            TN_CHECK_LAUNCH("svd_trunc_small_kernel");
+            double h[4] = {0.0, 0.0, 0.0, 0.0};
+            double* stage = (double*)pinned_host(sizeof(h), 2);
+            hipError_t e;
+            if ((e = hipMemcpyAsync(stage ? stage : h, res, sizeof(h), hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy result");
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync result");
+            if (stage) std::memcpy(h, stage, sizeof(h));
+            if (!(h[1] == h[1])) { set_error("svd: non-finite input"); return -2; }
+            if (keep_out) *keep_out = (int64_t)h[0];
+            if (discarded_out) *discarded_out = h[1];
+            if (sweeps_out) *sweeps_out = (int)h[2];
+            if (info) *info = h[3] != 0.0 ? 0 : 1;
+            return 0;
+        }
+    }
     SvdWs w;
     svd_layout(nv, L, true, (char*)ws, &w);
     std::vector<double> hS;
