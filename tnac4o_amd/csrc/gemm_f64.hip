@@ -346,6 +346,13 @@ static int gemm_ex_impl(hipStream_t st, int64_t M, int64_t N, int64_t K, double 
                         int64_t bsa, int64_t bsb, int64_t bsc, double* ws, int64_t ws_bytes, const GemmExtra* x) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     TN_CHECK_ARG(K >= 0, "negative K");
+    // Column-major C (unit ROW stride): the MFMA result layout puts 16 consecutive COLUMNS of a row in the lanes of a store, i.e.
+    // 16 separate 32-byte pieces per instruction there.  The transposed product C^T = B^T A^T is the same arithmetic in the same
+    // order (element by element: the same K sequence, the same splits) with C^T row-major -- full 128-byte segments.  Not for the
+    // block-pair indirection / raw partials of the Jacobi SVD, whose index maps and partial layout are tied to the operand roles.
+    static const bool swap_on = [] { const char* e = getenv("TN_GEMM_SWAP"); return !(e && e[0] == '0'); }();
+    if (swap_on && rsc == 1 && csc != 1 && N > 1 && !(x && (x->pairs || x->raw_partials || x->skip)))
+        return gemm_ex_impl(st, N, M, K, alpha, B, csb, rsb, A, csa, rsa, beta, C, csc, rsc, batch, bsb, bsa, bsc, ws, ws_bytes, x);
     GemmP g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
     g.rsa = rsa; g.csa = csa; g.rsb = rsb; g.csb = csb; g.rsc = rsc; g.csc = csc;

@@ -23,6 +23,8 @@ SHAPES = [
     (16384, 128, 1024, 1, 0, 0), (16384, 256, 1024, 1, 0, 0), (16384, 1024, 128, 1, 0, 0), (16384, 1024, 256, 1, 0, 0),
     (1024, 1024, 16384, 1, 1, 0), (16384, 1024, 1024, 1, 0, 0),
 ]
+# the rank-32 trailing update of a column-major matrix (A -= W X: C, A column-major): M N K
+COLMAJOR = [(8704, 1024, 32), (16384, 992, 32), (2048, 64, 32), (8704, 512, 128)]
 
 print('%6s %6s %6s %5s tA tB : %9s %8s   max|err|' % ('M', 'N', 'K', 'batch', 'us/call', 'TFLOP/s'))
 for (M, N, K, b, ta, tb) in SHAPES:
@@ -47,3 +49,21 @@ for (M, N, K, b, ta, tb) in SHAPES:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print('%6d %6d %6d %5d  %d  %d : %9.2f %8.2f   %.2e' % (M, N, K, b, ta, tb, 1e6 * dt, 2.0 * M * N * K * b / dt / 1e12, err), flush=True)
+
+print('column-major C and A (the QR of a transposed site):')
+for (M, N, K) in COLMAJOR:
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn((K, M), generator=g, dtype=torch.float64, device=dev).t()             # M x K, column-major
+    B = torch.randn((K, N), generator=g, dtype=torch.float64, device=dev)
+    Cc = torch.randn((N, M), generator=g, dtype=torch.float64, device=dev).t()            # M x N, column-major
+    ref = Cc - A @ B
+    out = Cc.clone().t().contiguous().t()
+    ops.mm(A, B, out=out, alpha=-1.0, beta=1.0)
+    err = float((out - ref).abs().max())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ops.mm(A, B, out=out, alpha=-1.0, beta=1.0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print('%6d %6d %6d : %9.2f us  %6.2f TFLOP/s  %7.1f GB/s (C read + written)   %.2e' % (M, N, K, 1e6 * dt, 2.0 * M * N * K / dt / 1e12, 16.0 * M * N / dt / 1e9, err), flush=True)
