@@ -61,16 +61,35 @@ static int fill_mat(hipStream_t st, double* D, int64_t drs, int64_t dcs, int64_t
 }
 
 // column swaps of a panel-pivoting step, applied in order to every row: A(r, pairs[2t]) <-> A(r, pairs[2t+1]), t = 0 .. npairs-1
-// (the swap list travels by value in the kernel arguments: 256 bytes, no host-to-device copy and no staging buffer to keep alive)
-struct SwapList { int v[64]; };
-__global__ __launch_bounds__(256) void swap_columns_kernel(double* __restrict__ A, int64_t rs, int64_t cs, int64_t m, SwapList pairs, int npairs) {
+// The swaps of a pivoting step as ONE gather / scatter: the host composes the sequence of swaps into "column dst[i] receives the
+// old column src[i]" over the (at most 64) columns they touch; a thread fetches its row's values of all those columns together and
+// then stores them (the swaps applied one after the other cost two dependent round trips each: 12 us per panel).  The list travels
+// by value in the kernel arguments: no host-to-device copy, no staging buffer to keep alive.
+struct SwapList { int n; int dst[64]; int src[64]; };
+__global__ __launch_bounds__(256) void swap_columns_kernel(double* __restrict__ A, int64_t rs, int64_t cs, int64_t m, SwapList sl) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= m) return;
     double* row = A + r * rs;
+    double v[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = (i < sl.n) ? row[(int64_t)sl.src[i] * cs] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i)
+        if (i < sl.n) row[(int64_t)sl.dst[i] * cs] = v[i];
+}
+// pairs: npairs swaps (a, b) applied in order -> the moves they amount to
+static void compose_swaps(const int* pairs, int npairs, SwapList& sl) {
+    int cols[64], from[64], nc = 0;                  // touched columns and, for each, the ORIGINAL column whose data it holds now
+    auto slot = [&](int c) { for (int i = 0; i < nc; ++i) if (cols[i] == c) return i; cols[nc] = c; from[nc] = c; return nc++; };
     for (int t = 0; t < npairs; ++t) {
-        const int64_t i1 = pairs.v[2 * t], i2 = pairs.v[2 * t + 1];
-        if (i1 != i2) { const double x = row[i1 * cs]; row[i1 * cs] = row[i2 * cs]; row[i2 * cs] = x; }
+        const int a = pairs[2 * t], b = pairs[2 * t + 1];
+        if (a == b) continue;
+        const int ia = slot(a), ib = slot(b);
+        const int tmp = from[ia]; from[ia] = from[ib]; from[ib] = tmp;
     }
+    sl.n = 0;
+    for (int i = 0; i < nc; ++i)
+        if (from[i] != cols[i]) { sl.dst[sl.n] = cols[i]; sl.src[sl.n] = from[i]; ++sl.n; }
 }
 
 __device__ __forceinline__ double hash_unit(uint64_t x) {
@@ -1154,9 +1173,12 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
                 P = p;
                 break;
             }
+            int pairs[64];
+            select_pivots(hcn, ntr, b, j0, pivot_perm_host, pairs);
             SwapList sl = {};
-            select_pivots(hcn, ntr, b, j0, pivot_perm_host, sl.v);
-            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(swap_columns_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, A, rs, cs, m, sl, b));
+            compose_swaps(pairs, b, sl);
+            if (sl.n > 0)
+                TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(swap_columns_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, A, rs, cs, m, sl));
             TN_CHECK_LAUNCH("swap_columns_kernel");
         }
         // --- panel orthonormalisation
