@@ -180,32 +180,43 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 16) ? 2 : 1)
         // beta != 0: the old values of a 16-row slab are fetched TOGETHER before any of them is used (a load whose value is consumed
         // right away costs a memory round trip per element: 64 in a row for a 128 x 128 tile, which made the rank-32 updates
         // A -= W X latency-bound in their epilogue)
-        double cv[2][TN][4];
-        auto fetch = [&](int i, int buf) {
+        if (hb) {
+            double cv[2][TN][4];
+            auto fetch = [&](int i, int buf) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = tm0 + wm * WM + i * 16 + lk + 4 * r, col = tn0 + wn * WN + j * 16 + lr;
-                    cv[buf][j][r] = (row < g.M && col < g.N) ? C[((MAPPED && g.mapC) ? remap(row) : row) * g.rsc + col * g.csc] : 0.0;
-                }
-        };
-        if (hb) fetch(0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (hb && i + 1 < TM) fetch(i + 1, (i + 1) & 1);       // the next slab's values are in flight while this one is stored
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = tm0 + wm * WM + i * 16 + lk + 4 * r, col = tn0 + wn * WN + j * 16 + lr;
-                    if (row < g.M && col < g.N) {
-                        double* c = C + ((MAPPED && g.mapC) ? remap(row) : row) * g.rsc + col * g.csc;
-                        double v = g.alpha * acc[i][j][r];
-                        if (hb) v += g.beta * cv[i & 1][j][r];
-                        *c = v;
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = tm0 + wm * WM + i * 16 + lk + 4 * r, col = tn0 + wn * WN + j * 16 + lr;
+                        cv[buf][j][r] = (row < g.M && col < g.N) ? C[((MAPPED && g.mapC) ? remap(row) : row) * g.rsc + col * g.csc] : 0.0;
                     }
-                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i + 1 < TM) fetch(i + 1, (i + 1) & 1);       // the next slab's values are in flight while this one is stored
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = tm0 + wm * WM + i * 16 + lk + 4 * r, col = tn0 + wn * WN + j * 16 + lr;
+                        if (row < g.M && col < g.N) {
+                            double v = g.alpha * acc[i][j][r];
+                            v += g.beta * cv[i & 1][j][r];
+                            C[((MAPPED && g.mapC) ? remap(row) : row) * g.rsc + col * g.csc] = v;
+                        }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = tm0 + wm * WM + i * 16 + lk + 4 * r, col = tn0 + wn * WN + j * 16 + lr;
+                        if (row < g.M && col < g.N) C[((MAPPED && g.mapC) ? remap(row) : row) * g.rsc + col * g.csc] = g.alpha * acc[i][j][r];
+                    }
         }
     }
 }
