@@ -768,6 +768,43 @@ def test_panel_statistics_are_kept_per_stream(ops):
     assert ops.panel_stats()['panels'] == 2
 
 
+TALL_PANEL_CHILD = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+from tnac4o_amd import ops
+g = torch.Generator(device='cpu').manual_seed(5)
+ok = True
+for rows in (16384, 12000, 8200):
+    X = (torch.randn(rows, 32, dtype=torch.float64, generator=g) * torch.logspace(0, -9, 32, dtype=torch.float64)[None, :]).cuda()
+    res = {}
+    for big in ('1', '0'):
+        os.environ['TN_PANEL_FUSED_BIG'] = big
+        ops.panel_stats(reset=True)
+        Q, R = ops.qr(X)
+        torch.cuda.synchronize()
+        res[big] = (Q, R, ops.panel_stats())
+    ok &= torch.equal(res['1'][0], res['0'][0]) and torch.equal(res['1'][1], res['0'][1])
+    ok &= res['1'][2]['single_launch_panels'] == 1 and res['0'][2]['single_launch_panels'] == 0
+    ok &= float((res['1'][0].t() @ res['1'][0] - torch.eye(32, dtype=torch.float64, device='cuda')).abs().max()) < 1e-13
+print('TALL_OK' if ok else 'TALL_FAIL')
+'''
+
+
+def test_tall_panels_single_launch_when_admitted(ops):
+    """Panels of more than 8192 rows (up to 64 workgroups) take the single-launch form when the co-residency budget admits them
+    (csrc/cholqr.hip: cq_big_admit): in a fresh process with one stream they always are -- same bits as the six-launch chain
+    (TN_PANEL_FUSED_BIG=0), and the statistics show which form ran."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop('TN_PANEL_FUSED_BIG', None)
+    out = subprocess.run([sys.executable, '-c', TALL_PANEL_CHILD % dict(root=root)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'TALL_OK' in out.stdout, out.stdout[-2000:]
+
+
 def test_qr_single_launch_panels_bit_identical_to_chain(ops):
     """tn_qr with the single-launch panel step (orthonormalisation + Householder reconstruction + reflector products in ONE
     kernel per panel) against the six-launch chain: Q and R bit-identical on tall, wide, ragged, rank-deficient and graded

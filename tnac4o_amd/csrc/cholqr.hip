@@ -1189,7 +1189,9 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
 // ---- host driver ---------------------------------------------------------------------------------------------------
 // layout: state | R (1024 + 32) | partial Gram matrices (x 2 for the single-launch form) | block exponents |
 //         reconstruction buffers (one per workgroup for the single-launch form) | top block of the panel (x 2)
-static inline bool cq_fused_fits(int64_t nblk) { return nblk <= CQ_FUSED_MAXBLK; }
+// workspace layout: as for the single-launch form up to 2 x CQ_FUSED_MAXBLK workgroups (whether a launch of more than CQ_FUSED_MAXBLK
+// takes that form is decided per call, see cq_big_admit)
+static inline bool cq_fused_fits(int64_t nblk) { return nblk <= 2 * CQ_FUSED_MAXBLK; }
 int64_t cholqr_ws_bytes(int64_t nrows, int b) {
     (void)b;
     const int64_t nblk = cdiv(nrows, CQ_RB);
@@ -1214,6 +1216,42 @@ static int cq_stat_slot(hipStream_t st) {
     const int s = (int)cq_slot_of.size() < CQ_STAT_SLOTS ? (int)cq_slot_of.size() : CQ_STAT_SLOTS;
     cq_slot_of.emplace(st, s);
     return s;
+}
+
+// Co-residency budget of the single-launch form (see cq_fused_kernel): a workgroup of it needs a whole CU and waits only for
+// workgroups of its own launch, so launches in flight cannot deadlock while together they ask for at most the 256 CUs of the chip.
+// At most 8 launches run at once (the 8 hardware queues the package asks for): 8 x CQ_FUSED_MAXBLK = 256 covers the panels of up to
+// 8192 rows unconditionally.  A taller panel (up to 64 workgroups) is admitted only while the budget still holds with it:
+//     64 B + 32 (S - B) <= 256,   S = min(streams of this process that have run panels, 8),  B = tall launches in flight (this one included),
+// i.e. B <= 8 - S: all four chains of a solve when nothing else runs panels, three of them with a fifth stream around, none with
+// eight.  In-flight tall launches are tracked with one event per stream (recorded behind the launch, queried before the next
+// admission, all under one mutex that also covers the launch itself).  A panel that is not admitted takes the six-launch chain: the
+// result is the same bit for bit.  TN_PANEL_FUSED_BIG=0: never admit.
+struct CqBigTrack {
+    hipEvent_t ev[CQ_STAT_SLOTS + 1] = {};
+    bool pending[CQ_STAT_SLOTS + 1] = {};
+};
+static CqBigTrack cq_big;
+static std::mutex cq_big_mu;
+static bool cq_big_enabled() {                                      // read per call: the tests switch it
+    const char* e = getenv("TN_PANEL_FUSED_BIG");
+    return !(e && e[0] == '0');
+}
+// call with cq_big_mu held
+static bool cq_big_admit(int slot, int nslots) {
+    if (slot >= CQ_STAT_SLOTS) return false;                       // streams without a slot of their own are not tracked
+    int inflight = 0;
+    for (int s = 0; s < CQ_STAT_SLOTS; ++s) {
+        if (s == slot || !cq_big.pending[s]) continue;            // (an earlier tall launch of THIS stream is not concurrent with the new one)
+        if (hipEventQuery(cq_big.ev[s]) == hipSuccess) cq_big.pending[s] = false;
+        else ++inflight;
+    }
+    const int S = nslots < 8 ? nslots : 8;
+    return inflight + 1 <= 8 - S;
+}
+static void cq_big_launched(hipStream_t st, int slot) {
+    if (!cq_big.ev[slot] && hipEventCreateWithFlags(&cq_big.ev[slot], hipEventDisableTiming) != hipSuccess) { cq_big.ev[slot] = nullptr; return; }
+    if (hipEventRecord(cq_big.ev[slot], st) == hipSuccess) cq_big.pending[slot] = true;
 }
 
 // The panel state of a factorisation lives in a block of its own per stream (a stream's calls do not overlap), NOT in the shared
@@ -1319,13 +1357,27 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
     // TN_PANEL_MAXPASS (1 .. CQ_MAXPASS): fewer substitution passes, to drive the Householder fallback in tests
     static const int maxpass = [] { const char* e = getenv("TN_PANEL_MAXPASS"); const int v = e ? atoi(e) : CQ_MAXPASS; return v >= 1 && v <= CQ_MAXPASS ? v : CQ_MAXPASS; }();
     const int slot = cq_stat_slot(st);
-    if (fits && fused_base && cq_fused_enabled()) {
+    const bool tall = nblk > CQ_FUSED_MAXBLK;
+    std::unique_lock<std::mutex> big_lock(cq_big_mu, std::defer_lock);
+    bool admitted = true;
+    if (fits && tall) {
+        admitted = false;
+        if (fused_base && cq_fused_enabled() && cq_big_enabled()) {
+            int nslots;
+            { std::lock_guard<std::mutex> lk(cq_slot_mu); nslots = (int)cq_slot_of.size(); }
+            big_lock.lock();
+            admitted = cq_big_admit(slot, nslots);
+            if (!admitted) big_lock.unlock();
+        }
+    }
+    if (fits && fused_base && cq_fused_enabled() && admitted) {
         // one launch for the whole chain.  Algorithmic bytes: the panel in, the reflectors (and W, Wq) out -- the tile never
         // leaves LDS in between; flops: Gram + post at launch time, the passes are booked from the device counter (cq_stats[3])
         prof_begin(st, PROF_TSQR);
         hipLaunchKernelGGL(cq_fused_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, part, bexp, topblk, stt,
                            *fused_base, seed, lu, Tp, W, wrs, wcs, Wq, maxpass, slot);
         TN_CHECK_LAUNCH("cq_fused_kernel");
+        if (tall) { cq_big_launched(st, slot); big_lock.unlock(); }
         *fused_base += (maxpass + 1) * nblk;
         const double e = (double)nrows * b;
         prof_end(st, PROF_TSQR, (2.0 + (reconstruct ? (Wq ? 6.0 : 4.0) : 0.0)) * e * b, (reconstruct ? (Wq ? 32.0 : 24.0) : 16.0) * e);
