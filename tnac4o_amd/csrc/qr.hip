@@ -578,7 +578,18 @@ __global__ __launch_bounds__(256) void assemble_R_init_Q_kernel(const double* __
         double v = 0.0;
         if (j >= j0 + b) {
             const double* z = Zbuf + p * nb * nb;
-            for (int r = 0; r < b; ++r) v += z[r * nb + il] * A[(j0 + r) * rs + j * cs];
+            if (nb == 32) {                                  // fixed trip count: the 2 x 32 loads go out together (one round trip, not 32)
+                double zv[32], av[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    zv[r] = (r < b) ? z[r * 32 + il] : 0.0;
+                    av[r] = (r < b) ? A[(j0 + r) * rs + j * cs] : 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < 32; ++r) v += zv[r] * av[r];
+            } else {
+                for (int r = 0; r < b; ++r) v += z[r * nb + il] * A[(j0 + r) * rs + j * cs];
+            }
         } else if (j >= j0) {
             v = Tri[p * nb * nb + il * nb + (j - j0)];
         }
@@ -589,8 +600,15 @@ __global__ __launch_bounds__(256) void assemble_R_init_Q_kernel(const double* __
             const double* z = Zbuf + (j0f / nb) * nb * nb;
             for (int e = threadIdx.x; e < fold_b * fold_b; e += 256) {
                 const int c = e / fold_b, jj = e % fold_b;
+                double yv[32], zv[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    yv[r] = (r < fold_b) ? Y[(j0f + r) * yrs + (j0f + c) * ycs] : 0.0;
+                    zv[r] = (r < fold_b) ? z[r * nb + jj] : 0.0;
+                }
                 double acc = 0.0;
-                for (int r = 0; r < fold_b; ++r) acc += Y[(j0f + r) * yrs + (j0f + c) * ycs] * z[r * nb + jj];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) acc += yv[r] * zv[r];
                 Ms[c * 33 + jj] = acc;
             }
             __syncthreads();
@@ -605,8 +623,12 @@ __global__ __launch_bounds__(256) void assemble_R_init_Q_kernel(const double* __
         }
         if (fold_b > 0 && j >= j0f && i >= j0f) {
             const int jj = (int)(j - j0f);
+            double wv[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) wv[c] = (c < fold_b) ? Wq[i * yrs + (j0f + c) * ycs] : 0.0;      // together: one round trip
             double acc = 0.0;
-            for (int c = 0; c < fold_b; ++c) acc += Wq[i * yrs + (j0f + c) * ycs] * Ms[c * 33 + jj];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) acc += wv[c] * ((c < fold_b) ? Ms[c * 33 + jj] : 0.0);
             v -= acc;
         }
         Q[i * qrs + j * qcs] = v;
