@@ -675,11 +675,20 @@ __global__ __launch_bounds__(256) void tiny_qr_kernel(const double* __restrict__
     const int k = m < n ? m : n;
     {
         double mx = 0.0;
-        for (int e = tid; e < m * n; e += 256) {
-            const double x = A[(int64_t)(e / n) * rs + (int64_t)(e % n) * cs];
-            As[e] = x;
-            const double a = fabs(x);
-            mx = (a == a) ? fmax(mx, a) : 1.7e308;
+        double xv[16];                                       // m n <= 4096 = 16 x 256: one memory round trip for the whole matrix
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            xv[u] = (e < m * n) ? A[(int64_t)(e / n) * rs + (int64_t)(e % n) * cs] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            if (e < m * n) {
+                As[e] = xv[u];
+                const double a = fabs(xv[u]);
+                mx = (a == a) ? fmax(mx, a) : 1.7e308;
+            }
         }
         part[tid] = mx;
         __syncthreads();
