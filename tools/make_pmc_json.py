@@ -66,13 +66,14 @@ wb = sum(kern[k]['write_bytes_per_launch'] * kern[k]['dispatches'] for k in ts)
 # substitution pass reads and writes it (16 B), the post launch reads it and writes Y and W (24 B); two passes per panel assumed
 # (the six-launch chain of the 16384 x 1024 QR); the single-launch form of the 4096 x 512 QR moves the panel in and Y, W out (24 B)
 alg = 0.0
+six_launch = any('cq_gram_kernel' in k for k in kern)          # (a lone stream is always admitted to the single-launch form, cq_big_admit)
 for p in range(32):
     rows = 16384 - 32 * p
-    alg += (8.0 + 2 * 16.0 + 24.0) * rows * 32
+    alg += ((8.0 + 2 * 16.0 + 24.0) if six_launch else 24.0) * rows * 32
 for p in range(16):
     rows = 4096 - 32 * p
     alg += 24.0 * rows * 32
-fam['panel step (cq_fused / cq_gram / cq_pass / cq_post)'] = {'probe_shape': 'tn_qr 16384 x 1024 (32 panels, six-launch chain) + tn_qr 4096 x 512 (16 panels, single-launch form)', 'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
+fam['panel step (cq_fused / cq_gram / cq_pass / cq_post)'] = {'probe_shape': 'tn_qr 16384 x 1024 (32 panels, %s) + tn_qr 4096 x 512 (16 panels, single-launch form)' % ('six-launch chain' if six_launch else 'single-launch form: 64 workgroups'), 'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
                                    'traffic_bytes_per_launch': (fb + wb) / n, 'algorithmic_bytes_per_launch': alg / n,
                                    'traffic_over_algorithmic': (fb + wb) / alg}
 for name, pat in (('eig_small_kernel', 'eig_small'), ('absorb_kernel', 'absorb_mfma_kernel')):
@@ -111,7 +112,7 @@ for k in kern:
                    'mfma_busy_over_wave_cycles': a['SQ_VALU_MFMA_BUSY_CYCLES'][2] / max(1.0, b.get('SQ_WAVE_CYCLES', (0, 0, 1))[2])}
 out = {'source': 'rocprofv3 --pmc (separate passes: FETCH_SIZE; WRITE_SIZE; SQ MFMA counters) over tools/pmc_probe.py on MI355X, '
                  '%s; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md); KB -> bytes' % ROUND,
-       'shapes': 'tn_qr 16384 x 1024 (nb=32, 32 panels x 6 launches of the Cholesky-QR panel chain), tn_qr 4096 x 512 (16 panels in the single-launch form), tn_svd_trunc 320 x 1024 (leading rows of the triangular factor of a graded rank-300 matrix), tn_absorb bulk '
+       'shapes': 'tn_qr 16384 x 1024 (nb=32, 32 panels), tn_qr 4096 x 512 (16 panels), both in the single-launch form of the Cholesky-QR panel step when admitted, tn_svd_trunc 320 x 1024 (leading rows of the triangular factor of a graded rank-300 matrix), tn_absorb bulk '
                  'site, tn_gemm 16384 x 1024 x 1024',
        'families': fam, 'kernels': kern, 'whole_call': whole, 'svd_step': svd,
        'mfma_counters': {'file': 'profiles/%s_pmc_traffic.json (mfma_counters.kernels)' % ROUND, 'kernels': mfma,
