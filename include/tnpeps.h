@@ -83,6 +83,19 @@ int tn_panel_orth(const double* X, int64_t rs, int64_t cs, int64_t nrows, int b,
                   int* state9_host, double* dev_host, void* ws, int64_t ws_bytes, void* stream);
 int tn_panel_stats(uint64_t* out16_host, int reset);
 int tn_panel_stats_stream(uint64_t* out16_host, int reset, void* stream);
+/* Factorisations of up to 64 columns (m >= n, at most 32 workgroups of rows, no pivoting) -- the plain `qr` of mps.py:43-59 as the
+ * variational sweeps (mps.py:238-279) and the canonisation passes (mps.py:202-236) call it on 1024 x 64-class site matrices -- run as
+ * ONE launch inside tn_qr / tn_site_qr (csrc/smallqr.hip: explicit-Q iterated Cholesky-QR, the triangular factors multiplied up, the
+ * norm factor of mps.py:76-85 taken in the same launch); TN_QR_SMALL=0 keeps the blocked path.  DIAGNOSTIC counters of `stream`:
+ * {factorisations, substitution passes applied, Householder fallbacks, launches that gave up at an in-kernel barrier}.
+ * tn_fused_timeouts: the launches with in-kernel barriers (this one and the single-launch panel step) rely on their workgroups being
+ * co-resident; the budget is derived from the device's CU count, GPU_MAX_HW_QUEUES and TN_PANEL_CU_BUDGET (the CUs this process may
+ * count on when the card is shared).  A launch that gives up all the same poisons its outputs with NaN and is counted; every entry
+ * point that used such launches asks before it returns (tn_compress_mps: once per call) and redoes the work through the six-launch
+ * panel chain / the blocked path (same bits), or fails with -7 when its input was overwritten.  The hook reports how many launches of
+ * `stream` gave up since the last check (synchronises the stream; a positive count takes the stream off these launch forms). */
+int tn_smallqr_stats(uint64_t* out4_host, int reset, void* stream);
+int tn_fused_timeouts(int* count_host, void* stream);
 /* Strided batch of `batch` equally shaped QR problems (the rotations of examples/e06:97-109 at one site): item i
  * at A + i*bsA, Q + i*bsQ, R + i*bsR, keff_host[i].  ws_bytes >= batch * roundup(tn_qr_ws_bytes(m,n,nb), 256).  A factorisation
  * is a chain of latency-bound single-workgroup kernels, so the items are made CONCURRENT rather than fused: item i is enqueued on

@@ -744,7 +744,7 @@ def test_panel_statistics_are_kept_per_stream(ops):
     their counts); tn_panel_stats is their sum over the streams."""
     g = torch.Generator(device='cpu').manual_seed(3)
     A = torch.randn(1024, 96, dtype=torch.float64, generator=g).cuda()
-    B = torch.randn(2048, 64, dtype=torch.float64, generator=g).cuda()
+    B = torch.randn(2048, 80, dtype=torch.float64, generator=g).cuda()        # (more than 64 columns: the panel path)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     ops.panel_stats(reset=True)
@@ -759,13 +759,13 @@ def test_panel_statistics_are_kept_per_stream(ops):
     with torch.cuda.stream(s2):
         st2 = ops.panel_stats(stream=True)
     tot = ops.panel_stats()
-    assert st1['panels'] == 6 and st2['panels'] == 2 and tot['panels'] == 8
+    assert st1['panels'] == 6 and st2['panels'] == 3 and tot['panels'] == 9
     for k in ops.PANEL_STAT_KEYS:
         assert st1[k] + st2[k] == tot[k], k
     with torch.cuda.stream(s1):
         ops.panel_stats(reset=True, stream=True)               # resetting one stream leaves the other alone
         assert ops.panel_stats(stream=True)['panels'] == 0
-    assert ops.panel_stats()['panels'] == 2
+    assert ops.panel_stats()['panels'] == 3
 
 
 TALL_PANEL_CHILD = r'''
@@ -824,8 +824,9 @@ def test_qr_single_launch_panels_bit_identical_to_chain(ops):
                 R = torch.zeros((k, nn), dtype=torch.float64, device='cuda')
                 _, _, ke = ops.qr_into(T, Q, R, rank_tol=tol)
                 return Q[:, :ke].clone(), R[:ke].clone(), ke
-            Q1, R1, k1 = _with_env('TN_PANEL_FUSED', '1', run)
-            Q0, R0, k0 = _with_env('TN_PANEL_FUSED', '0', run)
+            # (TN_QR_SMALL=0: matrices of up to 64 columns would otherwise take the one-launch factorisation, not the panel step)
+            Q1, R1, k1 = _with_env('TN_QR_SMALL', '0', lambda: _with_env('TN_PANEL_FUSED', '1', run))
+            Q0, R0, k0 = _with_env('TN_QR_SMALL', '0', lambda: _with_env('TN_PANEL_FUSED', '0', run))
             assert k0 == k1 and torch.equal(Q0, Q1) and torch.equal(R0, R1), (tuple(T.shape), tol, k0, k1)
             if float(T.abs().max()) > 0:
                 rel = ((Q1 @ R1 - T).norm(dim=0) / T.norm(dim=0).clamp_min(1e-300)).max().item()
@@ -873,3 +874,168 @@ def test_qr_single_launch_panels_under_uneven_load(ops):
     assert not err, err
     for i in range(4):
         assert torch.equal(out[i][0], ref[i][0]) and torch.equal(out[i][1], ref[i][1]), i
+
+
+# ------------------------------------------------------------------------------------------------ one-launch factorisation (smallqr.hip)
+def _smallqr_cases():
+    g = torch.Generator(device='cpu').manual_seed(31)
+    rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g)
+    dep = rn(900, 64)
+    dep[:, 7] = dep[:, 2]
+    dep[:, 40] = 0.0
+    dep[:, 50:58] = dep[:, 10:18] @ rn(8, 8)
+    graded = rn(1024, 64) * torch.logspace(0, -14, 64, dtype=torch.float64)[None, :]
+    illc = rn(2000, 48) @ (torch.linalg.qr(rn(48, 48))[0] * torch.logspace(0, -12, 48, dtype=torch.float64)[None, :]) @ torch.linalg.qr(rn(48, 48))[0]
+    return [('1024x64', rn(1024, 64)), ('1000x60', rn(1000, 60)), ('129x64', rn(129, 64)), ('64x64', rn(64, 64)), ('65x33', rn(65, 33)),
+            ('4096x64', rn(4096, 64)), ('4000x37', rn(4000, 37)), ('256x16', rn(256, 16)), ('300x32', rn(300, 32)), ('8192x32', rn(8192, 32)),
+            ('7000x20', rn(7000, 20)), ('130x1', rn(130, 1) + 3.0), ('column-major', rn(64, 1500).t()), ('column-major 24', rn(24, 5000).t()),
+            ('dependent', dep), ('zero', torch.zeros(700, 40, dtype=torch.float64)), ('ones', torch.ones(900, 64, dtype=torch.float64)),
+            ('graded', graded), ('ill-conditioned', illc), ('scaled up', rn(1500, 50) * 1e150), ('scaled down', rn(1500, 50) * 1e-150),
+            ('row graded', rn(2048, 64) * torch.logspace(0, -200, 2048, dtype=torch.float64)[:, None])]
+
+
+def test_smallqr_single_launch(ops):
+    """tn_qr on matrices of up to 64 columns (m >= n, at most 32 workgroups of rows) runs as ONE launch (csrc/smallqr.hip: explicit-Q
+    iterated Cholesky-QR across workgroups that meet at in-kernel barriers): Q orthonormal, Q R = A column-wise to rounding, R upper
+    triangular with diag(R) >= 0 on full-rank, dependent, zero, graded, ill-conditioned, badly scaled and strided inputs; the same R as
+    the blocked Householder path (TN_QR_SMALL=0) where it is unique; bit-reproducible; the input untouched."""
+    ops.smallqr_stats(reset=True)
+    ncall = 0
+    for name, Th in _smallqr_cases():
+        T = Th.cuda()
+        keep = T.clone()
+        m, n = T.shape
+        Q, R = ops.qr(T)
+        ncall += 0 if (m * n <= 4096 and n <= 32) else 1          # (the tiniest ones stay with tiny_qr_kernel)
+        assert torch.equal(T, keep), name
+        Qh, Rh, A = Q.cpu().numpy(), R.cpu().numpy(), Th.numpy()
+        cn = np.sqrt((A * A).sum(0))
+        cn[cn == 0] = 1.0
+        assert np.abs(Qh.T @ Qh - np.eye(n)).max() < 2e-14, name
+        assert (np.abs(Qh @ Rh - A) / cn).max() < 5e-14, name
+        assert np.abs(np.tril(Rh, -1)).max() == 0.0 and (np.diag(Rh) >= 0).all(), name
+        Q2, R2 = ops.qr(T)
+        ncall += 0 if (m * n <= 4096 and n <= 32) else 1
+        assert torch.equal(Q, Q2) and torch.equal(R, R2), name
+        if name not in ('dependent', 'zero', 'ones', 'ill-conditioned', 'graded'):
+            Q0, R0 = _with_env('TN_QR_SMALL', '0', lambda: ops.qr(T))
+            sc = np.abs(A).max()
+            assert np.abs(R0.cpu().numpy() - Rh).max() <= 1e-12 * sc, name
+            assert np.abs(Q0.cpu().numpy() - Qh).max() <= 1e-11, name
+    st = ops.smallqr_stats()
+    # (63 exact copies of one column -- 'ones' -- is the one case whose passes run out: Householder fallback, valid factors all the same)
+    assert st['calls'] == ncall and st['householder_fallbacks'] <= 2 and st['timeouts'] == 0, st
+    assert st['passes'] <= 2.0 * ncall, st
+
+
+def test_smallqr_fused_normalisation_in_site_qr(ops):
+    """tn_site_qr on a site whose matrix takes the one-launch path: the triangular factor comes out divided by its power-of-two norm
+    factor (mps.py:76-85) from the same launch -- same Q, R and factor as the blocked path followed by tn_normalize_pow2 give up to
+    rounding, and the factor is the exact power of two."""
+    g = torch.Generator(device='cpu').manual_seed(32)
+    for side, shape, cshape in ((0, (64, 16, 64), None), (1, (64, 16, 64), None), (0, (48, 16, 60), (40, 48)), (1, (60, 16, 48), (48, 40))):
+        A = (torch.randn(*shape, dtype=torch.float64, generator=g) * 37.0).cuda()
+        Cm = torch.randn(*cshape, dtype=torch.float64, generator=g).cuda() if cshape else None
+        Q1, R1, k1, nf1 = ops.site_qr(side, A.clone(), Cm)
+        Q0, R0, k0, nf0 = _with_env('TN_QR_SMALL', '0', lambda: ops.site_qr(side, A.clone(), Cm))
+        assert k1 == k0
+        assert float(nf1[0]) == float(nf0[0]) and float(nf1[0] * nf1[1]) == 1.0
+        assert float((R1 - R0).abs().max()) < 1e-12 and float((Q1 - Q0).abs().max()) < 1e-11
+        assert 0.5 <= float(R1.abs().max()) and float(R1.abs().max()) < 2.0
+
+
+SMALLQR_CHILD = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+from tnac4o_amd import ops
+g = torch.Generator(device='cpu').manual_seed(7)
+ok = True
+for shape in ((1024, 64), (3000, 40), (200, 64), (5000, 17)):
+    # condition number 1e9 that no column scaling removes: one substitution pass cannot orthonormalise these
+    Th = torch.randn(*shape, dtype=torch.float64, generator=g) @ (torch.logspace(0, -9, shape[1], dtype=torch.float64)[:, None] * torch.randn(shape[1], shape[1], dtype=torch.float64, generator=g))
+    T = Th.cuda()
+    Q, R = ops.qr(T)
+    Qh, Rh, A = Q.cpu().numpy(), R.cpu().numpy(), Th.numpy()
+    cn = np.sqrt((A * A).sum(0))
+    ok &= bool(np.abs(Qh.T @ Qh - np.eye(shape[1])).max() < 1e-13 and (np.abs(Qh @ Rh - A) / cn).max() < 1e-13)
+    ok &= bool(np.abs(np.tril(Rh, -1)).max() == 0.0 and (np.diag(Rh) >= 0).all())
+    ok &= bool(np.isfinite(Qh).all() and np.isfinite(Rh).all())
+st = ops.smallqr_stats()
+print('STATS', st)
+print('CHILD_OK' if ok else 'CHILD_FAIL')
+'''
+
+
+def _run_child(code, env_extra):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, '-c', code % dict(root=root)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_smallqr_householder_fallback():
+    """TN_PANEL_MAXPASS=1 leaves the passes no chance on graded inputs: workgroup 0 of the launch redoes the factorisation with
+    Householder reflections (sq_fallback_householder) -- valid factors all the same, and the counter shows the path ran."""
+    out = _run_child(SMALLQR_CHILD, {'TN_PANEL_MAXPASS': '1'})
+    assert 'CHILD_OK' in out, out
+    assert "'householder_fallbacks': 0" not in out, out
+
+
+def test_barrier_timeouts_are_recovered_not_returned():
+    """TN_PANEL_SPIN_LIMIT=0 makes every in-kernel barrier with more than one workgroup give up at once (what happens when the
+    co-residency budget does not hold: another tenant on the card): the launch poisons its outputs and books the time-out, the entry
+    point notices at its read-back and redoes the factorisation through the blocked path -- the caller never sees NaN, and the
+    counters show that launches did give up."""
+    out = _run_child(SMALLQR_CHILD, {'TN_PANEL_SPIN_LIMIT': '0'})
+    assert 'CHILD_OK' in out, out
+    assert "'timeouts': 0" not in out, out
+
+
+def test_smallqr_under_uneven_load(ops):
+    """The in-kernel barriers and hand-offs of the one-launch factorisation under uneven load: four chains factor 1024 x 64-class
+    matrices on four streams while a fifth keeps the device full of large GEMMs; every result equals the one obtained alone, bit for
+    bit (Guideline 16 of the MI355X guide: hand-offs must be tested with busy, L1-warm consumers, every word checked)."""
+    import threading
+    g = torch.Generator(device='cpu').manual_seed(41)
+    rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g).cuda()
+    mats = [rn(1024, 64), rn(4096, 64) * torch.logspace(0, -8, 64, dtype=torch.float64).cuda()[None, :], rn(3000, 48), rn(8192, 32)]
+    ref = [ops.qr(T) for T in mats]
+    torch.cuda.synchronize()
+    big_a, big_b = rn(4096, 4096), rn(4096, 4096)
+    streams = [torch.cuda.Stream() for _ in range(5)]
+    bad, err = [0] * 4, []
+    stop = threading.Event()
+
+    def chain(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(40):
+                    Q, R = ops.qr(mats[i])
+                    if not (torch.equal(Q, ref[i][0]) and torch.equal(R, ref[i][1])):
+                        bad[i] += 1
+                streams[i].synchronize()
+        except BaseException as e:          # noqa: BLE001
+            err.append(e)
+
+    def load():
+        with torch.cuda.stream(streams[4]):
+            while not stop.is_set():
+                ops.mm(big_a, big_b)
+                streams[4].synchronize()
+    th = [threading.Thread(target=chain, args=(i,)) for i in range(4)]
+    tl = threading.Thread(target=load)
+    tl.start()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    stop.set()
+    tl.join()
+    assert not err, err
+    assert bad == [0, 0, 0, 0], bad

@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libtnpeps.so')
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['api.hip', 'gemm_f64.hip', 'small.hip', 'qr.hip', 'svd.hip', 'absorb.hip', 'misc.hip', 'beam.hip', 'prof.hip', 'tsqr.hip', 'cholqr.hip', 'peps.hip', 'env.hip', 'batch.hip', 'site.hip', 'chain.hip', 'beamsearch.hip']
+SOURCES = ['api.hip', 'gemm_f64.hip', 'small.hip', 'qr.hip', 'svd.hip', 'absorb.hip', 'misc.hip', 'beam.hip', 'prof.hip', 'tsqr.hip', 'cholqr.hip', 'smallqr.hip', 'peps.hip', 'env.hip', 'batch.hip', 'site.hip', 'chain.hip', 'beamsearch.hip']
 
 _i64, _f64, _int, _ptr = C.c_int64, C.c_double, C.c_int, C.c_void_p
 
@@ -29,6 +29,8 @@ SIGNATURES = {
     'tn_panel_orth': (_int, [_ptr, _i64, _i64, _i64, _int, _ptr, _i64, _i64, _int, C.POINTER(_int), C.POINTER(_f64), _ptr, _i64, _ptr]),
     'tn_panel_stats': (_int, [C.POINTER(C.c_uint64), _int]),
     'tn_panel_stats_stream': (_int, [C.POINTER(C.c_uint64), _int, _ptr]),
+    'tn_smallqr_stats': (_int, [C.POINTER(C.c_uint64), _int, _ptr]),
+    'tn_fused_timeouts': (_int, [C.POINTER(_int), _ptr]),
     'tn_qr_batched': (_int, [_ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _i64, _i64, _int, _f64, C.POINTER(_i64), _i64, _i64, _i64,
                       _i64, _ptr, _i64, _ptr, C.POINTER(_ptr), _int]),
     'tn_svd_trunc': (_int, [_ptr, _i64, _i64, _i64, _i64, _i64, _f64, _ptr, _i64, _i64, _ptr, _ptr, _i64, _i64,
@@ -99,12 +101,48 @@ def source_hash():
 
 def build(verbose=False):
     """Compile libtnpeps.so in-tree for gfx950 (hipcc cross-compiles without a GPU).  The hash of the sources is compiled
-    in (tn_build_id) so that lib() can refuse a library that does not match the sources next to it."""
+    in (tn_build_id) so that lib() can refuse a library that does not match the sources next to it.  Every .hip file is a
+    translation unit of its own (no relocatable device code): the objects are compiled in parallel and cached under
+    build/obj keyed by the content of the file, of every header of csrc/ and include/, and of the flags, so that an edit
+    recompiles one file."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DTN_SRC_HASH="%s"' % source_hash(),
-           '-o', LIB_PATH] + os.environ.get('TN_EXTRA_HIPCC_FLAGS', '').split() + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + os.environ.get('TN_EXTRA_HIPCC_FLAGS', '').split()
+    objdir = os.path.join(HERE, '..', 'build', 'obj')
+    os.makedirs(objdir, exist_ok=True)
+    hh = hashlib.sha256(' '.join(flags).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith('.h'):
+            hh.update(open(os.path.join(CSRC, f), 'rb').read())
+    hh.update(open(os.path.join(HERE, '..', 'include', 'tnpeps.h'), 'rb').read())
+    src_hash = source_hash()
+
+    def one(s):
+        src = os.path.join(CSRC, s)
+        h = hh.copy()
+        h.update(open(src, 'rb').read())
+        extra = []
+        if s == 'api.hip':           # the only file that sees the build id
+            extra = ['-DTN_SRC_HASH="%s"' % src_hash]
+            h.update(src_hash.encode())
+        obj = os.path.join(objdir, '%s.%s.o' % (s[:-4], h.hexdigest()[:16]))
+        if not os.path.exists(obj):
+            for old in os.listdir(objdir):
+                if old.startswith(s[:-4] + '.') and old.endswith('.o'):
+                    os.unlink(os.path.join(objdir, old))
+            cmd = [hipcc] + flags + extra + ['-c', src, '-o', obj + '.tmp']
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            os.replace(obj + '.tmp', obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=int(os.environ.get('TN_BUILD_JOBS', '6'))) as ex:
+        objs = list(ex.map(one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
     if verbose:
-        print(' '.join(cmd))
+        print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return LIB_PATH
 
@@ -124,7 +162,7 @@ SHORT_CALLS = ('tn_gemm', 'tn_gemm_ws_bytes', 'tn_qr_ws_bytes', 'tn_svd_ws_bytes
                'tn_balance', 'tn_merge_groups', 'tn_svdvals_async', 'tn_rar', 'tn_rar_ws_bytes', 'tn_env_mix', 'tn_env_mix_ws_bytes',
                'tn_apply_truncation', 'tn_apply_truncation_ws_bytes', 'tn_site_qr_ws_bytes', 'tn_gram_weights', 'tn_argsort_desc', 'tn_weighted_sum', 'tn_rows_norm2', 'tn_gather_scale_rows', 'tn_peps_factor', 'tn_mpo_from_factor', 'tn_last_error')
 _lib = None
-ABI_VERSION = 6          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
+ABI_VERSION = 7          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
 
 
 def lib():

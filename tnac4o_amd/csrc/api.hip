@@ -21,7 +21,8 @@ int absorb(hipStream_t, const double*, const double*, double*, int64_t, int64_t,
            int64_t, int64_t, int64_t);
 int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
               void*, int64_t, double, int64_t*, hipStream_t, double* dropped2_host = nullptr, int frob_exit = 0,
-              int64_t* pivot_perm_host = nullptr);
+              int64_t* pivot_perm_host = nullptr, double* nf_out2 = nullptr,
+              int* nf_done = nullptr);
 int64_t qr_ws_bytes(int64_t, int64_t, int);
 int svd_trunc(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double, double*, int64_t, int64_t, double*,
               double*, int64_t, int64_t, int64_t*, double*, int*, int*, void*, int64_t);
@@ -65,6 +66,7 @@ int qr_batched(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*
 int svd_trunc_batched(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double, double*, int64_t, int64_t, double*,
                       double*, int64_t, int64_t, int64_t*, double*, int*, int*, int64_t, int64_t, int64_t, int64_t, int64_t, void*, int64_t);
 int svd_vals_batched(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, double*, int*, int*, int64_t, int64_t, void*, int64_t);
+int smallqr_stats(hipStream_t st, unsigned long long* out4, int reset);
 
 }  // namespace tn
 
@@ -73,7 +75,7 @@ using namespace tn;
 
 extern "C" {
 
-int tn_version(void) { return 6; }
+int tn_version(void) { return 7; }
 
 #ifndef TN_SRC_HASH
 #define TN_SRC_HASH "unknown"
@@ -114,6 +116,7 @@ int tn_stream_create_masked(const uint32_t* mask_host, int nwords, void** stream
     hipStream_t st = nullptr;
     const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask_host);
     if (e != hipSuccess) return hip_fail(e, "hipExtStreamCreateWithCUMask");
+    fused_forms_disable(st);        // launches with in-kernel barriers count on whole-chip co-residency: not on a masked stream
     *stream_out = (void*)st;
     return 0;
 }
@@ -160,6 +163,18 @@ int tn_qr(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, in
     return qr_factor(ST, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host, (hipStream_t)aux_stream);
 }
 int64_t tn_qr_ws_bytes(int64_t m, int64_t n, int nb) { return qr_ws_bytes(m, n, nb); }
+
+int tn_smallqr_stats(uint64_t* out4_host, int reset, void* stream) {
+    TN_CHECK_ARG(out4_host, "null output");
+    unsigned long long o[4];
+    const int rc = smallqr_stats(ST, o, reset);
+    for (int i = 0; i < 4; ++i) out4_host[i] = o[i];
+    return rc;
+}
+int tn_fused_timeouts(int* count_host, void* stream) {
+    TN_CHECK_ARG(count_host, "null output");
+    return fused_timeouts(ST, count_host);
+}
 
 int64_t tn_panel_orth_ws_bytes(int64_t nrows, int b) {
     const int64_t a = tsqr_ws_bytes(nrows, b), c = cholqr_ws_bytes(nrows, b);

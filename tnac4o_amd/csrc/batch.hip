@@ -13,7 +13,8 @@ namespace tn {
 
 int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
               void*, int64_t, double, int64_t*, hipStream_t, double* dropped2_host = nullptr, int frob_exit = 0,
-              int64_t* pivot_perm_host = nullptr);
+              int64_t* pivot_perm_host = nullptr, double* nf_out2 = nullptr,
+              int* nf_done = nullptr);
 int64_t qr_ws_bytes(int64_t, int64_t, int);
 int svd_trunc(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double, double*, int64_t, int64_t, double*,
               double*, int64_t, int64_t, int64_t*, double*, int*, int*, void*, int64_t);

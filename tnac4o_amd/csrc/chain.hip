@@ -29,7 +29,8 @@ namespace tn {
 int absorb(hipStream_t, const double*, const double*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int64_t,
            int64_t, int64_t, int64_t);
 int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int, void*,
-              int64_t, double, int64_t*, hipStream_t, double* dropped2_host = nullptr, int frob_exit = 0, int64_t* pivot_perm_host = nullptr);
+              int64_t, double, int64_t*, hipStream_t, double* dropped2_host = nullptr, int frob_exit = 0, int64_t* pivot_perm_host = nullptr, double* nf_out2 = nullptr,
+              int* nf_done = nullptr);
 int64_t qr_ws_bytes(int64_t, int64_t, int);
 int copy_mat(hipStream_t, const double*, int64_t, int64_t, double*, int64_t, int64_t, int64_t, int64_t);
 int svd_trunc(hipStream_t, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double, double*, int64_t, int64_t, double*, double*,
@@ -317,10 +318,10 @@ public:
         out = s.p;
         return 0;
     }
-    double* next_nf() {                      // slot of the next [nf, 1/nf] pair in the caller's table (the last slot is reused when full)
-        const int64_t i = nfs_count < nfs_cap ? nfs_count : nfs_cap - 1;
-        if (nfs_count < nfs_cap) ++nfs_count;
-        return nfs_dev + 2 * i;
+    bool nfs_overflow = false;               // the caller's table was too small: the call fails (checked at its end)
+    double* next_nf() {                      // slot of the next [nf, 1/nf] pair in the caller's table
+        if (nfs_count >= nfs_cap) { nfs_overflow = true; return nfs_dev + 2 * (nfs_cap - 1); }
+        return nfs_dev + 2 * (nfs_count++);
     }
 
     // ---- GEMM wrappers (ops.mm / ops.bmm) ----
@@ -969,8 +970,51 @@ int64_t tn_compress_mps_arena_bytes(int64_t L, const int64_t* site_dims_host, co
     return 3 * total + (10 + 2 * bmax) * biggest + (int64_t)512 * 1024 * 1024;
 }
 
+static int compress_mps_once(int64_t L, const double* const* sites_host, const int64_t* site_dims_host, const double* const* mpo_host,
+                    const int64_t* mpo_dims_host, int hconj, int64_t Dmax, double tolS, double tolV, int max_sweeps, int graduate, int flags,
+                    double* out, int64_t out_slot, int64_t* out_dims_host, double* overlap_host, double* discarded_host, double* schmidt_host,
+                    int64_t schmidt_pitch, int64_t* schmidt_len_host, double* nfs_dev, int64_t nfs_cap, int64_t* nfs_count_host, double* info_host,
+                    void* arena, int64_t arena_bytes, void* stream);
+
 // apply_mpo (when mpo_host[n] != NULL) + compress_mps of one boundary MPS.  See include/tnpeps.h.
+// The row's factorisations use launches with in-kernel barriers (cholqr.hip, smallqr.hip); instead of asking after each of them, the
+// row asks ONCE, at its end (or when a step fails on the NaN a launch that gave up leaves behind), whether any of them gave up
+// (fused_timeouts: 16 bytes read back).  If so the whole row is redone from its untouched inputs -- the stream has been taken off
+// those launch forms by then, so the second attempt runs the six-launch panel chain and the blocked small factorisations, whose
+// results are the same bit for bit; info_host[6] counts the redone attempts.
 int tn_compress_mps(int64_t L, const double* const* sites_host, const int64_t* site_dims_host, const double* const* mpo_host,
+                    const int64_t* mpo_dims_host, int hconj, int64_t Dmax, double tolS, double tolV, int max_sweeps, int graduate, int flags,
+                    double* out, int64_t out_slot, int64_t* out_dims_host, double* overlap_host, double* discarded_host, double* schmidt_host,
+                    int64_t schmidt_pitch, int64_t* schmidt_len_host, double* nfs_dev, int64_t nfs_cap, int64_t* nfs_count_host, double* info_host,
+                    void* arena, int64_t arena_bytes, void* stream) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc;
+        {
+            FusedDeferCheck defer;
+            rc = compress_mps_once(L, sites_host, site_dims_host, mpo_host, mpo_dims_host, hconj, Dmax, tolS, tolV, max_sweeps, graduate, flags, out, out_slot,
+                                   out_dims_host, overlap_host, discarded_host, schmidt_host, schmidt_pitch, schmidt_len_host, nfs_dev, nfs_cap,
+                                   nfs_count_host, info_host, arena, arena_bytes, stream);
+        }
+        if (rc == -1) return rc;                                   // argument error: nothing was launched
+        int gave_up = 0;
+        if (fused_check_needed()) {
+            char keep[512];
+            strncpy(keep, get_error(), sizeof(keep) - 1);          // (the check may overwrite the row's own error text)
+            keep[sizeof(keep) - 1] = 0;
+            const int rc2 = fused_timeouts((hipStream_t)stream, &gave_up);
+            if (rc2) return rc2;
+            if (gave_up == 0 && rc) set_error("%s", keep);
+        }
+        if (gave_up == 0) {
+            if (rc == 0 && info_host) info_host[6] = (double)attempt;
+            return rc;
+        }
+    }
+    set_error("tn_compress_mps: launches with in-kernel barriers gave up twice in a row");
+    return -7;
+}
+
+static int compress_mps_once(int64_t L, const double* const* sites_host, const int64_t* site_dims_host, const double* const* mpo_host,
                     const int64_t* mpo_dims_host, int hconj, int64_t Dmax, double tolS, double tolV, int max_sweeps, int graduate, int flags,
                     double* out, int64_t out_slot, int64_t* out_dims_host, double* overlap_host, double* discarded_host, double* schmidt_host,
                     int64_t schmidt_pitch, int64_t* schmidt_len_host, double* nfs_dev, int64_t nfs_cap, int64_t* nfs_count_host, double* info_host,
@@ -1075,6 +1119,10 @@ int tn_compress_mps(int64_t L, const double* const* sites_host, const int64_t* s
             schmidt_len_host[i] = s.has ? len : -1;
             for (int64_t j = 0; j < len; ++j) schmidt_host[i * schmidt_pitch + j] = s.val[j];
         }
+    }
+    if (ch.nfs_overflow) {
+        set_error("tn_compress_mps: the table of normalisation factors is too small (%lld pairs): size it (2 max_sweeps + 16) L + 64", (long long)nfs_cap);
+        return -3;
     }
     if (nfs_count_host) *nfs_count_host = ch.nfs_count;
     if (info_host) {

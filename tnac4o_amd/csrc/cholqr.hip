@@ -147,7 +147,7 @@ __device__ __forceinline__ void cq_block_gram(const double* T, double* S, double
 //   [0] panels  [1] substitution passes applied  [2] deferred pivots  [3] refilled columns  [4] Householder fallbacks
 //   [5] panels with >= 3 passes  [6] panels with >= 4 passes  [7] panel elements x passes applied by the six-launch chain (each such
 //   pass reads and writes the panel: 16 bytes per element)  [8] the same for the single-launch form (the tile stays in LDS: flops only)
-//   [9] panels handled by the single-launch form
+//   [9] panels handled by the single-launch form  [10] single-launch panels that gave up at an in-kernel barrier (time-outs)
 constexpr int CQ_STAT_SLOTS = 64;
 __device__ unsigned long long cq_stats[(CQ_STAT_SLOTS + 1) * 16];
 // one thread, once per panel; the adds do not return a value, so the wave does not wait for them
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void cq_post_kernel(const double* X, int64_t x
 constexpr int CQ_FUSED_MAXBLK = 32;
 constexpr unsigned CQ_SPIN_LIMIT = 1u << 22;
 
-__device__ __forceinline__ bool cq_grid_barrier(int* counter, int target, int* s_flag, int tid) {
+__device__ __forceinline__ bool cq_grid_barrier(int* counter, int target, int* s_flag, int tid, unsigned spin_limit = CQ_SPIN_LIMIT) {
     cq_publish_wait();                                     // every wave: its agent-scope stores have completed
     __syncthreads();
     if (tid == 0) {
@@ -928,7 +928,7 @@ __device__ __forceinline__ bool cq_grid_barrier(int* counter, int target, int* s
         unsigned spins = 0;
         while (cq_ldi(counter) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > CQ_SPIN_LIMIT) { ok = 0; break; }
+            if (++spins > spin_limit) { ok = 0; break; }
         }
         *s_flag = ok;
     }
@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void cq_tail_fused(const double* part, const int* bex
 __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t xrs, int64_t xcs, double* Y, int64_t rs, int64_t cs, int64_t nrows,
                                                        int b, int nblk, double* part, int* bexp, double* topblk, CqState* stt, int base,
                                                        uint64_t seed, double* lu_all, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq,
-                                                       int maxpass, int slot) {
+                                                       int maxpass, int slot, unsigned spin_limit) {
     __shared__ double T[CQ_RB * CQ_P];
     __shared__ __attribute__((aligned(16))) double GR[3 * 1024];      // Gram 32 x 33 | factor 1024 + 32; later the three S matrices of the post step
     __shared__ __attribute__((aligned(16))) double scr[4 * 32 * 33 + 64];
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
         const int ex = cq_load_scaled_tile(X, xrs, xcs, r0, nr, b, T, red, tid);
         cq_block_gram(T, scr, part + (int64_t)blk * CQ_PART, tid);
         if (tid == 0) cq_sti(bexp + blk, ex);
-        alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid);
+        alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid, spin_limit);
         int dec = 0, tlast = 0;
         if (alive) {
             cq_tail_fused(part, bexp, nblk, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot);
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
                     for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; cq_st(tb + e, T[(e >> 5) * CQ_P + (e & 31)]); }
                 }
                 if (writer && tid == 0) stt->pass = t;
-                alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid);
+                alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid, spin_limit);
                 if (!alive) break;
                 tlast = t;
                 if (fin) {
@@ -1175,7 +1175,12 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
         }
     }
     if (!alive) {                                            // a barrier gave up (or an earlier launch of this call did): poison the output
-        if (tid == 0) cq_sti(&stt->timeout, 1);
+        if (tid == 0) {
+            cq_sti(&stt->timeout, 1);
+            // sticky per-stream count (survives the clearing of the state block at the end of the call): the host compares it
+            // with the value it saw last (fused_timeouts) and redoes the work with the six-launch chain
+            atomicAdd(&cq_stats[slot * 16 + 10], 1ull);
+        }
         const double bad = __longlong_as_double(0x7ff8000000000000LL);
         for (int e = tid; e < nr * b; e += 256) {
             const int i = e / b, j = e % b;
@@ -1218,16 +1223,59 @@ static int cq_stat_slot(hipStream_t st) {
     cq_slot_of.emplace(st, s);
     return s;
 }
+int cholqr_stream_slot(hipStream_t st) { return cq_stat_slot(st); }      // (smallqr.hip shares the numbering)
 
-// Co-residency budget of the single-launch form (see cq_fused_kernel): a workgroup of it needs a whole CU and waits only for
-// workgroups of its own launch, so launches in flight cannot deadlock while together they ask for at most the 256 CUs of the chip.
-// At most 8 launches run at once (the 8 hardware queues the package asks for): 8 x CQ_FUSED_MAXBLK = 256 covers the panels of up to
-// 8192 rows unconditionally.  A taller panel (up to 64 workgroups) is admitted only while the budget still holds with it:
-//     64 B + 32 (S - B) <= 256,   S = min(streams of this process that have run panels, 8),  B = tall launches in flight (this one included),
-// i.e. B <= 8 - S: all four chains of a solve when nothing else runs panels, three of them with a fifth stream around, none with
+// Co-residency budget of the launches with in-kernel barriers (cq_fused_kernel here, sq_kernel in smallqr.hip): a workgroup of them
+// needs a whole CU and waits only for workgroups of its own launch, so launches in flight cannot deadlock while together they ask
+// for no more CUs than this process may count on.  Nothing about that is assumed: the budget is derived at first use from
+//   * the device (hipDeviceAttributeMultiprocessorCount), or TN_PANEL_CU_BUDGET when several processes share the card (the CUs this
+//     process may count on: half the chip for two tenants ...; 0 keeps every panel on the six-launch chain),
+//   * the number of hardware queues the runtime multiplexes the streams onto (GPU_MAX_HW_QUEUES as the runtime itself reads it at
+//     initialisation; 4 when unset): at most that many kernels of the process are in flight,
+// which gives  maxblk = min(32, budget / queues)  workgroups for an ordinary launch (32 with the package's 8 queues on an MI355X).  A
+// taller panel (up to 2 maxblk workgroups) is admitted only while the budget still holds with it:
+//     2 maxblk B + maxblk (S - B) <= budget,   S = min(streams of this process that have run panels, queues),  B = tall launches in
+// flight (this one included): all four chains of a solve when nothing else runs panels, three with a fifth stream around, none with
 // eight.  In-flight tall launches are tracked with one event per stream (recorded behind the launch, queried before the next
-// admission, all under one mutex that also covers the launch itself).  A panel that is not admitted takes the six-launch chain: the
-// result is the same bit for bit.  TN_PANEL_FUSED_BIG=0: never admit.
+// admission, all under one mutex that also covers the launch itself).  Streams created with a CU mask (tn_stream_create_masked) and
+// streams on which a launch has ever given up at a barrier (fused_timeouts) are taken off these forms for good.  A panel that is not
+// admitted takes the six-launch chain: the result is the same bit for bit.  TN_PANEL_FUSED_BIG=0: never admit tall panels.
+struct FusedBudget { int cus = 0, queues = 4, maxblk = 0; bool ready = false; };
+static FusedBudget cq_budget_of[16];
+static std::mutex cq_budget_mu;
+static FusedBudget fused_budget() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return FusedBudget(); }
+    std::lock_guard<std::mutex> lk(cq_budget_mu);
+    FusedBudget& b = cq_budget_of[dev];
+    if (!b.ready) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
+        if (const char* e = getenv("TN_PANEL_CU_BUDGET")) { const int v = atoi(e); if (v >= 0 && v < cus) cus = v; }
+        int q = 4;
+        if (const char* e = getenv("GPU_MAX_HW_QUEUES")) { const int v = atoi(e); if (v >= 1) q = v; }
+        b.cus = cus; b.queues = q;
+        b.maxblk = cus / q < CQ_FUSED_MAXBLK ? cus / q : CQ_FUSED_MAXBLK;
+        b.ready = true;
+    }
+    return b;
+}
+static std::map<hipStream_t, bool> cq_stream_off;                  // (guarded by cq_slot_mu)
+void fused_forms_disable(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(cq_slot_mu);
+    cq_stream_off[st] = true;
+}
+static bool cq_stream_is_off(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(cq_slot_mu);
+    return cq_stream_off.count(st) != 0;
+}
+// may a launch of nwg workgroups with in-kernel barriers go out on this stream?
+bool fused_forms_allowed(hipStream_t st, int nwg) {
+    if (!cq_fused_enabled() || cq_stream_is_off(st)) return false;
+    if (cq_stat_slot(st) >= CQ_STAT_SLOTS) return false;
+    return nwg <= fused_budget().maxblk;
+}
+
 struct CqBigTrack {
     hipEvent_t ev[CQ_STAT_SLOTS + 1] = {};
     bool pending[CQ_STAT_SLOTS + 1] = {};
@@ -1241,18 +1289,74 @@ static bool cq_big_enabled() {                                      // read per 
 // call with cq_big_mu held
 static bool cq_big_admit(int slot, int nslots) {
     if (slot >= CQ_STAT_SLOTS) return false;                       // streams without a slot of their own are not tracked
+    const FusedBudget b = fused_budget();
+    if (b.maxblk < 1) return false;
     int inflight = 0;
     for (int s = 0; s < CQ_STAT_SLOTS; ++s) {
         if (s == slot || !cq_big.pending[s]) continue;            // (an earlier tall launch of THIS stream is not concurrent with the new one)
         if (hipEventQuery(cq_big.ev[s]) == hipSuccess) cq_big.pending[s] = false;
         else ++inflight;
     }
-    const int S = nslots < 8 ? nslots : 8;
-    return inflight + 1 <= 8 - S;
+    const int S = nslots < b.queues ? nslots : b.queues;
+    return inflight + 1 <= b.cus / b.maxblk - S;
 }
 static void cq_big_launched(hipStream_t st, int slot) {
     if (!cq_big.ev[slot] && hipEventCreateWithFlags(&cq_big.ev[slot], hipEventDisableTiming) != hipSuccess) { cq_big.ev[slot] = nullptr; return; }
     if (hipEventRecord(cq_big.ev[slot], st) == hipSuccess) cq_big.pending[slot] = true;
+}
+
+// ---- time-outs of the launches with in-kernel barriers ----------------------------------------------------------------------
+// A launch that gives up at a barrier poisons its outputs with NaN and adds to a sticky per-stream device counter (cq_stats[10]
+// here, sq_stats[3] in smallqr.hip).  Every caller that has enqueued such launches asks fused_timeouts before it hands results
+// back: one 16-byte read-back and a synchronisation.  A positive answer means: the results of the stream since the previous
+// check are invalid, the stream has been taken off the single-launch forms (the co-residency the spins rely on evidently does
+// not hold: another tenant on the card, a debugger, ...), its barrier state is cleared, and the caller must redo the work -- which
+// now takes the six-launch chain / the blocked path, bit-identical results.  Callers that own many factorisations (tn_compress_mps)
+// defer the check to the end of their call (FusedDeferCheck).
+int smallqr_stats(hipStream_t st, unsigned long long* out4, int reset);
+int smallqr_reset_state(hipStream_t st);
+static void cq_dirty_mark(int slot);
+static thread_local long cq_fused_launches = 0;                    // launches with in-kernel barriers enqueued by this thread since its last check
+static thread_local int cq_defer_depth = 0;
+void fused_note_launch() { ++cq_fused_launches; }
+void fused_defer_push() { ++cq_defer_depth; }
+void fused_defer_pop() { --cq_defer_depth; }
+bool fused_check_deferred() { return cq_defer_depth > 0; }
+bool fused_check_needed() { return cq_fused_launches > 0; }
+static unsigned long long cq_timeouts_seen[CQ_STAT_SLOTS + 1][2];  // last values of the two counters per slot (guarded by cq_slot_mu)
+int fused_timeouts(hipStream_t st, int* count_out) {
+    *count_out = 0;
+    cq_fused_launches = 0;
+    const int slot = cq_stat_slot(st);
+    if (slot >= CQ_STAT_SLOTS) return 0;                           // such streams never take these forms
+    unsigned long long* h = (unsigned long long*)pinned_host(64, 7);
+    unsigned long long tmp[8];
+    if (!h) h = tmp;
+    hipError_t e = hipMemcpyFromSymbolAsync(h, HIP_SYMBOL(cq_stats), 8, ((size_t)slot * 16 + 10) * 8, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return hip_fail(e, "read panel time-outs");
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync panel time-outs");
+    const unsigned long long a = h[0];
+    unsigned long long sq[4];
+    int rc = smallqr_stats(st, sq, 0);
+    if (rc) return rc;
+    unsigned long long da, db;
+    {
+        std::lock_guard<std::mutex> lk(cq_slot_mu);
+        da = a - cq_timeouts_seen[slot][0];
+        db = sq[3] - cq_timeouts_seen[slot][1];
+        cq_timeouts_seen[slot][0] = a;
+        cq_timeouts_seen[slot][1] = sq[3];
+        if (da + db > 0) cq_stream_off[st] = true;
+    }
+    if (da + db == 0) return 0;
+    *count_out = (int)(da + db > 2147483647ull ? 2147483647ull : da + db);
+    // leave a clean slate: the stream's panel state (sticky flag, barrier counter) and the small-QR barrier state
+    {
+        std::lock_guard<std::mutex> lk(cq_slot_mu);
+        cq_dirty_mark(slot);
+    }
+    if ((rc = smallqr_reset_state(st))) return rc;
+    return 0;
 }
 
 // The panel state of a factorisation lives in a block of its own per stream (a stream's calls do not overlap), NOT in the shared
@@ -1262,6 +1366,7 @@ static void cq_big_launched(hipStream_t st, int slot) {
 // state block at the head of the workspace and a memset per call.
 __device__ char cq_state_pool[CQ_STAT_SLOTS * CQ_STATE_BYTES];
 static bool cq_dirty[CQ_STAT_SLOTS];
+static void cq_dirty_mark(int slot) { cq_dirty[slot] = true; }      // the next cholqr_begin on this stream clears the block with a memset
 int cholqr_begin(hipStream_t st, void* ws, void** state_out) {
     const int slot = cq_stat_slot(st);
     if (slot >= CQ_STAT_SLOTS) {
@@ -1269,17 +1374,21 @@ int cholqr_begin(hipStream_t st, void* ws, void** state_out) {
         const hipError_t e = hipMemsetAsync(ws, 0, CQ_STATE_BYTES, st);
         return e == hipSuccess ? 0 : hip_fail(e, "memset panel state");
     }
-    static char* base = nullptr;
+    static char* bases[16] = {};                                   // a __device__ symbol has one address per device
     static std::mutex mu;
     bool dirty;
+    char* base = nullptr;
     {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { set_error("cholqr_begin: no current device"); return 1; }
         std::lock_guard<std::mutex> lk(mu);
-        if (!base) {
+        if (!bases[dev]) {
             void* p = nullptr;
             const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(cq_state_pool));
             if (e != hipSuccess) return hip_fail(e, "panel state pool");
-            base = (char*)p;
+            bases[dev] = (char*)p;
         }
+        base = bases[dev];
         dirty = cq_dirty[slot];
         cq_dirty[slot] = true;
     }
@@ -1358,12 +1467,14 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
     // TN_PANEL_MAXPASS (1 .. CQ_MAXPASS): fewer substitution passes, to drive the Householder fallback in tests
     static const int maxpass = [] { const char* e = getenv("TN_PANEL_MAXPASS"); const int v = e ? atoi(e) : CQ_MAXPASS; return v >= 1 && v <= CQ_MAXPASS ? v : CQ_MAXPASS; }();
     const int slot = cq_stat_slot(st);
-    const bool tall = nblk > CQ_FUSED_MAXBLK;
+    const int maxblk = fused_budget().maxblk;                      // ordinary single-launch panels: at most this many workgroups
+    const bool tall = nblk > maxblk;
+    const bool usable = fits && fused_base && nblk <= 2 * maxblk && fused_forms_allowed(st, 1);
     std::unique_lock<std::mutex> big_lock(cq_big_mu, std::defer_lock);
-    bool admitted = true;
-    if (fits && tall) {
+    bool admitted = usable;
+    if (usable && tall) {
         admitted = false;
-        if (fused_base && cq_fused_enabled() && cq_big_enabled()) {
+        if (cq_big_enabled()) {
             int nslots;
             { std::lock_guard<std::mutex> lk(cq_slot_mu); nslots = (int)cq_slot_of.size(); }
             big_lock.lock();
@@ -1371,12 +1482,14 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
             if (!admitted) big_lock.unlock();
         }
     }
-    if (fits && fused_base && cq_fused_enabled() && admitted) {
+    if (admitted) {
+        static const unsigned spin_limit = [] { const char* e = getenv("TN_PANEL_SPIN_LIMIT"); return e ? (unsigned)strtoul(e, nullptr, 10) : CQ_SPIN_LIMIT; }();
+        fused_note_launch();
         // one launch for the whole chain.  Algorithmic bytes: the panel in, the reflectors (and W, Wq) out -- the tile never
         // leaves LDS in between; flops: Gram + post at launch time, the passes are booked from the device counter (cq_stats[3])
         prof_begin(st, PROF_TSQR);
         hipLaunchKernelGGL(cq_fused_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, part, bexp, topblk, stt,
-                           *fused_base, seed, lu, Tp, W, wrs, wcs, Wq, maxpass, slot);
+                           *fused_base, seed, lu, Tp, W, wrs, wcs, Wq, maxpass, slot, spin_limit);
         TN_CHECK_LAUNCH("cq_fused_kernel");
         if (tall) { cq_big_launched(st, slot); big_lock.unlock(); }
         *fused_base += (maxpass + 1) * nblk;

@@ -177,6 +177,23 @@ int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t 
 int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws,
                  int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq, int* fused_base,
                  void* state = nullptr);
+// launches with in-kernel barriers (cq_fused_kernel, sq_kernel): co-residency budget and time-outs, see cholqr.hip
+bool fused_forms_allowed(hipStream_t st, int nwg);
+void fused_forms_disable(hipStream_t st);
+void fused_note_launch();
+bool fused_check_needed();
+bool fused_check_deferred();
+void fused_defer_push();
+void fused_defer_pop();
+struct FusedDeferCheck { FusedDeferCheck() { fused_defer_push(); } ~FusedDeferCheck() { fused_defer_pop(); } };
+int fused_timeouts(hipStream_t st, int* count_out);       // synchronises st; *count_out > 0: redo the work since the last check
+// one-launch factorisation of m x n, n <= 64 (smallqr.hip): 0 done, 1 shape / stream not taken, else error
+bool smallqr_fits(int64_t m, int64_t n);
+int64_t smallqr_ws_bytes(int64_t m, int64_t n);
+int smallqr_factor(hipStream_t st, const double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs, int64_t qcs, double* R,
+                   int64_t rrs, int64_t rcs, double* nf_out2, void* ws, int64_t ws_bytes);
+int cholqr_stream_slot(hipStream_t st);     // statistics / state slot of a stream (CHOLQR_SLOTS = no slot of its own)
+constexpr int CHOLQR_SLOTS = 64;
 int cholqr_debug_state(hipStream_t st, const void* ws, int* ints9, double* dev_hist);
 int cholqr_stats(unsigned long long* out16, int reset, hipStream_t st_or_null, int all_streams);
 

@@ -1088,19 +1088,52 @@ QrTrace g_qr_trace;
 
 static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
                           int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
-                          int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host);
+                          int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host, double* nf_out2,
+                          int* nf_done, bool* input_intact);
+static int qr_factor_traced(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
+              int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
+              int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host, double* nf_out2, int* nf_done,
+              bool* input_intact);
 
+// nf_out2 != NULL (device, 2 doubles): a path that can divide R by its power-of-two norm factor in the launch that produces it does
+// so and sets *nf_done (the one-launch factorisation of smallqr.hip); otherwise *nf_done = 0 and the caller normalises.
+// Launches with in-kernel barriers (single-launch panel steps, smallqr.hip) may give up when the co-residency they rely on does not
+// hold; unless the caller has deferred the check (FusedDeferCheck: tn_compress_mps asks once per row) the call ends by asking
+// fused_timeouts: a factorisation whose input is still intact is redone through the blocked path at once, otherwise the call fails
+// with -7 (the input was overwritten: the caller must rerun from a copy; the stream no longer takes the single-launch forms).
 int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
               int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
-              int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host) {
+              int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host, double* nf_out2, int* nf_done) {
+    bool intact = false;
+    int rc = qr_factor_traced(st, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host, aux, dropped2_host, frob_exit,
+                              pivot_perm_host, nf_out2, nf_done, &intact);
+    if (fused_check_deferred() || !fused_check_needed()) return rc;
+    int gave_up = 0;
+    const int rc2 = fused_timeouts(st, &gave_up);
+    if (rc2) return rc2;
+    if (gave_up == 0) return rc;
+    if (!intact) {
+        set_error("tn_qr: %d launch(es) with in-kernel barriers gave up (co-residency budget exceeded: another tenant on the device?); the "
+                  "results are invalid and the input was overwritten -- rerun from a copy (this stream now takes the six-launch panel chain)", gave_up);
+        return -7;
+    }
+    return qr_factor_traced(st, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host, aux, dropped2_host, frob_exit,
+                            pivot_perm_host, nf_out2, nf_done, &intact);
+}
+
+static int qr_factor_traced(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
+              int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
+              int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host, double* nf_out2, int* nf_done,
+              bool* input_intact) {
+    if (nf_done) *nf_done = 0;
     if (!g_qr_trace.on)
         return qr_factor_impl(st, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host, aux, dropped2_host, frob_exit,
-                              pivot_perm_host);
+                              pivot_perm_host, nf_out2, nf_done, input_intact);
     thread_local hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!e0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
     (void)hipEventRecord(e0, st);
     const int rc = qr_factor_impl(st, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nb, ws, ws_bytes, rank_tol, keff_host, aux, dropped2_host,
-                                  frob_exit, pivot_perm_host);
+                                  frob_exit, pivot_perm_host, nf_out2, nf_done, input_intact);
     (void)hipEventRecord(e1, st);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
@@ -1119,7 +1152,8 @@ int qr_factor(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int6
 
 static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, double* Q, int64_t qrs,
                           int64_t qcs, double* R, int64_t rrs, int64_t rcs, int nb, void* ws, int64_t ws_bytes, double rank_tol,
-                          int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host) {
+                          int64_t* keff_host, hipStream_t aux, double* dropped2_host, int frob_exit, int64_t* pivot_perm_host, double* nf_out2,
+                          int* nf_done, bool* input_intact) {
     TN_CHECK_ARG(m >= 1 && n >= 1, "empty matrix");
     if (dropped2_host) *dropped2_host = 0.0;
     TN_CHECK_ARG(nb == 32 || nb == 64, "nb must be 32 or 64");
@@ -1133,11 +1167,24 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
                                R, rrs, rcs));
             TN_CHECK_LAUNCH("tiny_qr_kernel");
             if (keff_host) *keff_host = k;
+            if (input_intact) *input_intact = true;
             return 0;
         }
     }
     QrWs w;
     qr_layout(m, n, nb, (char*)ws, &w);
+    // up to 64 columns (no pivoting; the rank-revealing exit only exists from three panels on): the whole factorisation in ONE launch,
+    // explicit-Q iterated Cholesky-QR (smallqr.hip); it leaves the input untouched
+    if (nb == 32 && pivot_perm_host == nullptr && Q != nullptr && smallqr_fits(m, n)) {
+        const int rcs_ = smallqr_factor(st, A, rs, cs, m, n, Q, qrs, qcs, R, rrs, rcs, nf_out2, w.gemm_ws, w.gemm_ws_bytes);
+        if (rcs_ == 0) {
+            if (keff_host) *keff_host = k;
+            if (nf_done) *nf_done = nf_out2 ? 1 : 0;
+            if (input_intact) *input_intact = true;
+            return 0;
+        }
+        if (rcs_ != 1) return rcs_;
+    }
     int P = (int)cdiv(k, nb);
     const int64_t kfull = k;
     double scale2 = -1.0;                                            // largest squared column norm of the input (lazily read back)

@@ -14,7 +14,8 @@ namespace tn {
 
 int qr_factor(hipStream_t, double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, int64_t, double*, int64_t, int64_t, int,
               void*, int64_t, double, int64_t*, hipStream_t, double* dropped2_host = nullptr, int frob_exit = 0,
-              int64_t* pivot_perm_host = nullptr);
+              int64_t* pivot_perm_host = nullptr, double* nf_out2 = nullptr,
+              int* nf_done = nullptr);
 int64_t qr_ws_bytes(int64_t, int64_t, int);
 int normalize_pow2(hipStream_t, double*, int64_t, double*, void*, int64_t);
 
@@ -66,19 +67,22 @@ int site_qr(hipStream_t st, int side, double* A, int64_t Dl, int64_t p, int64_t 
     void* qw = w;
     w += qws;
     int64_t keff = d.k;
+    int nf_done = 0;
     {
         ProfPhase ph(PH_QR);
         const double dm = (double)d.m, dn = (double)d.k;
         prof_note(PROF_QR_NOMINAL, 1, 4.0 * dm * dn * dn - 4.0 / 3.0 * dn * dn * dn, 8.0 * (2.0 * dm * dn + dn * dn));
         if (side == 0)      // M (m x n) row-major; Q (m x k) row-major; R (k x n) row-major
-            rc = qr_factor(st, M, d.n, 1, d.m, d.n, Q, d.k, 1, R, d.n, 1, 32, qw, qws, rank_tol, &keff, nullptr, dropped2_host, frob_exit, pivot_perm_host);
+            rc = qr_factor(st, M, d.n, 1, d.m, d.n, Q, d.k, 1, R, d.n, 1, 32, qw, qws, rank_tol, &keff, nullptr, dropped2_host, frob_exit, pivot_perm_host,
+                           nf_out2, &nf_done);
         else                // the (p r) x Dl view of the row-major (Dl, p r) array; Q = Qt^T, R = Ct^T
-            rc = qr_factor(st, M, 1, d.m, d.m, d.n, Q, 1, d.m, R, 1, d.k, 32, qw, qws, rank_tol, &keff, nullptr, dropped2_host, frob_exit, pivot_perm_host);
+            rc = qr_factor(st, M, 1, d.m, d.m, d.n, Q, 1, d.m, R, 1, d.k, 32, qw, qws, rank_tol, &keff, nullptr, dropped2_host, frob_exit, pivot_perm_host,
+                           nf_out2, &nf_done);
     }
     if (rc) return rc;
     if (keff_host) *keff_host = keff;
-    int normalised = 0;
-    if (nf_out2 && keff == d.k) {      // the triangular factor is complete and contiguous: C = R / nfactor(R) (mps.py:781-782, 796-797)
+    int normalised = nf_done;            // (the one-launch factorisation divides R by its norm factor itself)
+    if (!normalised && nf_out2 && keff == d.k) {      // the triangular factor is complete and contiguous: C = R / nfactor(R) (mps.py:781-782, 796-797)
         if ((rc = normalize_pow2(st, R, d.k * d.n, nf_out2, w, 8192))) return rc;
         normalised = 1;
     }

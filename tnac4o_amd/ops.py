@@ -206,17 +206,24 @@ def qr_into(T, Q, R, overwrite=False, nb=None, rank_tol=0.0):
     (use Q[:, :keff], R[:keff])."""
     _need_gpu(T)
     m, n = T.shape
-    if not overwrite:
-        T = T.clone(memory_format=torch.preserve_format)
     nb = nb or QR_NB
     L = lib()
     wsb = L.tn_qr_ws_bytes(m, n, nb)
     ws = workspace(wsb, 0)
     keff = C.c_int64(min(m, n))
     aux = aux_stream() if (nb == 32 and m >= 2048 and min(m, n) >= 128) else None
-    check(L.tn_qr(T.data_ptr(), T.stride(0), T.stride(1), m, n, Q.data_ptr(), Q.stride(0), Q.stride(1), R.data_ptr(),
-                  R.stride(0), R.stride(1), nb, float(rank_tol), C.byref(keff), ws.data_ptr(), wsb, _stream(),
-                  C.c_void_p(aux.cuda_stream) if aux is not None else None))
+    src = T
+    for attempt in range(2):
+        if not overwrite:
+            T = src.clone(memory_format=torch.preserve_format)
+        rc = L.tn_qr(T.data_ptr(), T.stride(0), T.stride(1), m, n, Q.data_ptr(), Q.stride(0), Q.stride(1), R.data_ptr(),
+                     R.stride(0), R.stride(1), nb, float(rank_tol), C.byref(keff), ws.data_ptr(), wsb, _stream(),
+                     C.c_void_p(aux.cuda_stream) if aux is not None else None)
+        # -7: a single-launch panel step gave up at a barrier (results invalid, input overwritten); the stream has been taken off
+        # those launch forms, so a second run from the untouched source takes the six-launch chain
+        if rc != -7 or overwrite or attempt == 1:
+            check(rc)
+            break
     return Q, R, int(keff.value)
 
 
@@ -252,6 +259,20 @@ def panel_stats(reset=False, stream=False):
     else:
         check(lib().tn_panel_stats(st, 1 if reset else 0))
     return {k: int(st[i]) for i, k in enumerate(PANEL_STAT_KEYS)}
+
+
+def smallqr_stats(reset=False):
+    """Diagnostic counters of the one-launch factorisations (csrc/smallqr.hip) on the current stream: dict."""
+    st = (C.c_uint64 * 4)()
+    check(lib().tn_smallqr_stats(st, 1 if reset else 0, _stream()))
+    return dict(calls=int(st[0]), passes=int(st[1]), householder_fallbacks=int(st[2]), timeouts=int(st[3]))
+
+
+def fused_timeouts():
+    """Launches with in-kernel barriers of the current stream that gave up since the last check (synchronises)."""
+    n = C.c_int(0)
+    check(lib().tn_fused_timeouts(C.byref(n), _stream()))
+    return int(n.value)
 
 
 def qr(T, overwrite=False, nb=None):
@@ -529,7 +550,7 @@ def compress_mps_native(sites, mpo_sites, hconj, Dmax, tolS, tolV, max_sweeps, g
     pitch = max(cap, 1)
     sch = (C.c_double * ((L + 1) * pitch))()
     slen = (C.c_int64 * (L + 1))()
-    nfs_cap = 64 * L + 64
+    nfs_cap = max(64, 2 * int(max_sweeps) + 16) * L + 64         # ~2L pairs per variational sweep + ~5L for the canonisation passes; the library fails (-3) rather than reuse a slot
     nfs = torch.empty((nfs_cap, 2), dtype=torch.float64, device=dev)
     ncount = C.c_int64(0)
     info = (C.c_double * 8)()
