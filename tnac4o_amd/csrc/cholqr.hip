@@ -941,10 +941,12 @@ __device__ __forceinline__ bool cq_grid_barrier(int* counter, int target, int* s
 // 32 x 32 row-major + the 32 reciprocals of its diagonal) instead of global memory.  s_out (LDS, 4 ints): [0] decision
 // (0 factor again, 1 converged, 2 out of passes), [1] final_next, [2] dead-column mask, [3] emax (pass 0).  Only `writer`
 // (workgroup 0) keeps the panel's state block and the statistics.  Ends with a barrier.
+// emax_known > -100000: `part` is ONE pre-summed matrix (sliced reduction, see cq_slice_reduce) of a pass-0 Gram whose weights were
+// applied with that exponent.
 __device__ __forceinline__ void cq_tail_fused(const double* part, const int* bexp, int nblk, int b, int pass, CqState* stt, bool writer, double* Gs,
-                                              double* Rf, int* s_out, int maxpass, int tid, long long elems, int slot) {
+                                              double* Rf, int* s_out, int maxpass, int tid, long long elems, int slot, int emax_known = -100001) {
     const int lane = tid & 63;
-    int emax = 0;
+    int emax = emax_known > -100000 ? emax_known : 0;
     if (bexp) {
         int e = -100000;
         for (int i = lane; i < nblk; i += 64) { const int x = cq_ldi(bexp + i); e = x > e ? x : e; }
@@ -1006,7 +1008,7 @@ __device__ __forceinline__ void cq_tail_fused(const double* part, const int* bex
             if (dec != 0) { s_out[1] = 0; s_out[2] = 0; }
             if (writer) {
                 stt->dev_hist[pass <= CQ_MAXPASS ? pass : CQ_MAXPASS] = dev;
-                if (bexp) stt->emax = emax;
+                if (bexp || emax_known > -100000) stt->emax = emax;
                 if (dec != 0) {
                     stt->done = 1;
                     stt->final_next = 0;
@@ -1071,13 +1073,49 @@ __device__ __forceinline__ void cq_tail_fused(const double* part, const int* bex
     __syncthreads();
 }
 
+// Sliced reduction of the published partial Gram matrices (launches of more than CQ_SLICE_FROM workgroups): workgroup w adds slice w of
+// all nblk partials -- block order, the same fused multiply-adds with the same power-of-two weights as the full reduction, hence the
+// same bits -- and publishes its slice of the sum; after one more barrier everybody fetches the 768 sums.  nblk^2 x 6 KB of agent-scope
+// loads per round become 2 x nblk x 6 KB.  Returns the exponent the weights refer to (pass 0).
+constexpr int CQ_SLICE_FROM = 16;
+__device__ __forceinline__ int cq_slice_reduce(const double* part, const int* bexp, int nblk, int blk, double* gsum, int tid) {
+    const int lane = tid & 63;
+    int emax = 0;
+    if (bexp) {
+        int e = -100000;
+        for (int i = lane; i < nblk; i += 64) { const int x = cq_ldi(bexp + i); e = x > e ? x : e; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(e, o, 64); e = y > e ? y : e; }
+        emax = e;
+    }
+    const int sl = (CQ_PART + nblk - 1) / nblk;            // <= 48 entries per workgroup from 16 workgroups on
+    const int e0 = blk * sl + tid;
+    if (tid < sl && e0 < CQ_PART) {
+        double acc = 0.0;
+        for (int b0 = 0; b0 < nblk; b0 += 16) {
+            double v[16];
+            int ex[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool in = b0 + u < nblk;
+                v[u] = in ? cq_ld(part + (int64_t)(b0 + u) * CQ_PART + e0) : 0.0;
+                ex[u] = (bexp && in) ? cq_ldi(bexp + b0 + u) : emax;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = fma(bexp ? ldexp(1.0, 2 * (ex[u] - emax)) : 1.0, v[u], acc);
+        }
+        cq_st(gsum + e0, acc);
+    }
+    return emax;
+}
+
 // part: 2 x nblk x CQ_PART (pass parity), topblk: 2 x 1024 (pass parity), lu_all: nblk x CQ_LU_DOUBLES (private to each workgroup)
 // or NULL (orthonormalisation only).  base: arrivals booked on stt->fcounter by the earlier launches of the call; every launch books
-// exactly (maxpass + 1) * nblk.
+// exactly (maxpass + 1) * nblk (twice that from CQ_SLICE_FROM workgroups on: one more barrier per pass).
 __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t xrs, int64_t xcs, double* Y, int64_t rs, int64_t cs, int64_t nrows,
                                                        int b, int nblk, double* part, int* bexp, double* topblk, CqState* stt, int base,
                                                        uint64_t seed, double* lu_all, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq,
-                                                       int maxpass, int slot, unsigned spin_limit) {
+                                                       int maxpass, int slot, unsigned spin_limit, double* gsum) {
     __shared__ double T[CQ_RB * CQ_P];
     __shared__ __attribute__((aligned(16))) double GR[3 * 1024];      // Gram 32 x 33 | factor 1024 + 32; later the three S matrices of the post step
     __shared__ __attribute__((aligned(16))) double scr[4 * 32 * 33 + 64];
@@ -1104,8 +1142,15 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
         if (tid == 0) cq_sti(bexp + blk, ex);
         alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid, spin_limit);
         int dec = 0, tlast = 0;
+        const bool sliced = nblk > CQ_SLICE_FROM;
+        int emax0 = 0;
+        if (alive && sliced) {
+            emax0 = cq_slice_reduce(part, bexp, nblk, blk, gsum, tid);
+            alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid, spin_limit);
+        }
         if (alive) {
-            cq_tail_fused(part, bexp, nblk, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot);
+            if (sliced) cq_tail_fused(gsum, nullptr, 1, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot, emax0);
+            else cq_tail_fused(part, bexp, nblk, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot);
             dec = s_out[0];
             const int emax = s_out[3];
             const double scl0 = (ex > -2000 && emax > -2000) ? ldexp(1.0, ex - emax) : 0.0;     // tile is 2^-ex X; the passes work on 2^-emax X
@@ -1134,7 +1179,13 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
                     }
                     break;
                 }
-                cq_tail_fused(pt, nullptr, nblk, b, t, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot);
+                if (sliced) {
+                    double* gs = gsum + (t & 1) * CQ_PART;
+                    (void)cq_slice_reduce(pt, nullptr, nblk, blk, gs, tid);
+                    alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid, spin_limit);
+                    if (!alive) break;
+                    cq_tail_fused(gs, nullptr, 1, b, t, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot);
+                } else cq_tail_fused(pt, nullptr, nblk, b, t, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot);
                 dec = s_out[0];
             }
         }
@@ -1188,8 +1239,9 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
             if (W) W[(r0 + i) * wrs + j * wcs] = bad;
         }
     }
-    // every launch books (maxpass + 1) * nblk arrivals, however many barriers it took
-    if (tid == 0 && nbar < maxpass + 1) atomicAdd(&stt->fcounter, maxpass + 1 - nbar);
+    // every launch books (maxpass + 1) * nblk arrivals (twice that with the sliced reduction), however many barriers it took
+    const int nbar_booked = (maxpass + 1) * (nblk > CQ_SLICE_FROM ? 2 : 1);
+    if (tid == 0 && nbar < nbar_booked) atomicAdd(&stt->fcounter, nbar_booked - nbar);
 }
 
 // ---- host driver ---------------------------------------------------------------------------------------------------
@@ -1203,7 +1255,7 @@ int64_t cholqr_ws_bytes(int64_t nrows, int b) {
     const int64_t nblk = cdiv(nrows, CQ_RB);
     const int64_t nlu = cq_fused_fits(nblk) ? nblk : 1, npart = cq_fused_fits(nblk) ? 2 * nblk : nblk;
     return CQ_STATE_BYTES + align_up((1024 + 32) * 8, 256) + align_up(npart * CQ_PART * 8, 256) + align_up(nblk * 4, 256) +
-           align_up(nlu * CQ_LU_DOUBLES * 8, 256) + align_up(2 * 1024 * 8, 256) + 256;
+           align_up(nlu * CQ_LU_DOUBLES * 8, 256) + align_up(2 * 1024 * 8, 256) + align_up(2 * CQ_PART * 8, 256) + 256;
 }
 
 // TN_PANEL_FUSED=0 keeps the six-launch chain for every panel (A/B measurements, cross-checks); read per call: the tests switch it
@@ -1350,6 +1402,9 @@ int fused_timeouts(hipStream_t st, int* count_out) {
     }
     if (da + db == 0) return 0;
     *count_out = (int)(da + db > 2147483647ull ? 2147483647ull : da + db);
+    fprintf(stderr, "[libtnpeps] %llu launch(es) with in-kernel barriers gave up on stream %p (workgroups not co-resident: is the device shared? "
+            "see TN_PANEL_CU_BUDGET); the work is redone through the multi-launch forms, which this stream uses from now on\n",
+            (unsigned long long)(da + db), (void*)st);
     // leave a clean slate: the stream's panel state (sticky flag, barrier counter) and the small-QR barrier state
     {
         std::lock_guard<std::mutex> lk(cq_slot_mu);
@@ -1463,7 +1518,8 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
     double* part = (double*)p; p += align_up((int64_t)(fits ? 2 * nblk : nblk) * CQ_PART * 8, 256);
     int* bexp = (int*)p; p += align_up((int64_t)nblk * 4, 256);
     double* lu = reconstruct ? (double*)p : nullptr; p += align_up((int64_t)(fits ? nblk : 1) * CQ_LU_DOUBLES * 8, 256);
-    double* topblk = (double*)p;
+    double* topblk = (double*)p; p += align_up(2 * 1024 * 8, 256);
+    double* gsum = (double*)p;                                      // 2 x CQ_PART: the summed Gram matrix of the sliced reduction (pass parity)
     // TN_PANEL_MAXPASS (1 .. CQ_MAXPASS): fewer substitution passes, to drive the Householder fallback in tests
     static const int maxpass = [] { const char* e = getenv("TN_PANEL_MAXPASS"); const int v = e ? atoi(e) : CQ_MAXPASS; return v >= 1 && v <= CQ_MAXPASS ? v : CQ_MAXPASS; }();
     const int slot = cq_stat_slot(st);
@@ -1489,10 +1545,10 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
         // leaves LDS in between; flops: Gram + post at launch time, the passes are booked from the device counter (cq_stats[3])
         prof_begin(st, PROF_TSQR);
         hipLaunchKernelGGL(cq_fused_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, part, bexp, topblk, stt,
-                           *fused_base, seed, lu, Tp, W, wrs, wcs, Wq, maxpass, slot, spin_limit);
+                           *fused_base, seed, lu, Tp, W, wrs, wcs, Wq, maxpass, slot, spin_limit, gsum);
         TN_CHECK_LAUNCH("cq_fused_kernel");
         if (tall) { cq_big_launched(st, slot); big_lock.unlock(); }
-        *fused_base += (maxpass + 1) * nblk;
+        *fused_base += (maxpass + 1) * nblk * (nblk > CQ_SLICE_FROM ? 2 : 1);
         const double e = (double)nrows * b;
         prof_end(st, PROF_TSQR, (2.0 + (reconstruct ? (Wq ? 6.0 : 4.0) : 0.0)) * e * b, (reconstruct ? (Wq ? 32.0 : 24.0) : 16.0) * e);
         cq_capture(st, X, irs, ics, nrows, b, stt);

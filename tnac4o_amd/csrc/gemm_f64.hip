@@ -331,6 +331,22 @@ struct GemmTrace {
         double tot = 0.0;
         for (auto& kv : tab) { v.push_back({kv.second.ms, kv.first}); tot += kv.second.ms; }
         std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first > b.first; });
+        {   // classes: split-K or not x depth K x tiles of the launch plan
+            std::map<std::tuple<int, int, int>, ShapeStat> cls;
+            for (auto& kv : tab) {
+                const int64_t M = std::get<0>(kv.first), N = std::get<1>(kv.first), K = std::get<2>(kv.first), b = std::get<3>(kv.first);
+                const int sk = std::get<6>(kv.first);
+                const int kb = K <= 32 ? 32 : K <= 64 ? 64 : K <= 128 ? 128 : K <= 256 ? 256 : K <= 512 ? 512 : K <= 1024 ? 1024 : K <= 4096 ? 4096 : 65536;
+                const int64_t t = cdiv(M, 64) * cdiv(N, 64) * b;
+                const int tb = t <= 1 ? 1 : t <= 4 ? 4 : t <= 16 ? 16 : t <= 64 ? 64 : t <= 256 ? 256 : 100000;
+                ShapeStat& c = cls[std::make_tuple(sk > 1 ? 1 : (sk < 0 ? -1 : 0), kb, tb)];
+                c.ms += kv.second.ms; c.calls += kv.second.calls;
+            }
+            fprintf(stderr, "[tn_gemm classes] split(1)/plain(0)/jacobi(-1)  K<=  64x64-tiles<= : calls  ms  us/call\n");
+            for (auto& kv : cls)
+                fprintf(stderr, "  %2d %6d %7d : %7ld %9.2f %8.2f\n", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), kv.second.calls, kv.second.ms,
+                        1e3 * kv.second.ms / kv.second.calls);
+        }
         fprintf(stderr, "[tn_gemm trace] %zu shapes, %.1f ms in total; M N K batch transA transB splitk : calls, ms, us/call, TFLOP/s\n", v.size(), tot);
         for (size_t i = 0; i < v.size() && i < 40; ++i) {
             auto& k = v[i].second;
