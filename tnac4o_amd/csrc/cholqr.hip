@@ -43,7 +43,9 @@ extern "C" int tn_debug_clocks2(long long* host, int n) {
 #define CQ_CLK_DECL long long clk_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define CQ_CLK(k) do { if (threadIdx.x == 0) clk_[k] = wall_clock64(); } while (0)
 #define CQ_CLK_DUMP(base) do { if (threadIdx.x == 0) for (int q_ = 0; q_ < 12; ++q_) cq_clk[(base) + q_] = clk_[q_]; } while (0)
+#define FQ_CLK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) cq_clk[k] = wall_clock64(); } while (0)
 #else
+#define FQ_CLK(k) do {} while (0)
 #define CQ_CLK_DECL do {} while (0)
 #define CQ_CLK(k) do {} while (0)
 #define CQ_CLK_DUMP(base) do {} while (0)
@@ -837,6 +839,28 @@ __device__ __forceinline__ void cq_post_tile(int blk, int nblk, int64_t nrows, i
         }
         __syncthreads();
         const bool drow = (dcs == 1);
+        // 16-byte stores along the unit-stride direction where the layout allows (full panels): the epilogue of three 64 KB outputs is
+        // bound by store issue (~7 B / cycle / CU with 8-byte stores)
+        const bool wide = b == 32 && (((uintptr_t)dst & 15) == 0) &&
+                          (drow ? (drs & 1) == 0 : (drs == 1 && (dcs & 1) == 0 && (r0 & 1) == 0 && (nr & 1) == 0));
+        if (wide) {
+#pragma unroll
+            for (int u0 = 0; u0 < 16; u0 += 8) {
+                double2 ov[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = tid + 256 * (u0 + u);
+                    const int i = drow ? e >> 4 : 2 * (e & 127), j = drow ? 2 * (e & 15) : e >> 7;
+                    ov[u] = make_double2(tile[i * CQ_P + j], tile[(drow ? i : i + 1) * CQ_P + (drow ? j + 1 : j)]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = tid + 256 * (u0 + u);
+                    const int i = drow ? e >> 4 : 2 * (e & 127), j = drow ? 2 * (e & 15) : e >> 7;
+                    if (i < nr && r0 + i >= b) *reinterpret_cast<double2*>(dst + (r0 + i) * drs + j * dcs) = ov[u];
+                }
+            }
+        } else {
 #pragma unroll
         for (int u0 = 0; u0 < 32; u0 += 8) {
             double ov[8];
@@ -852,6 +876,7 @@ __device__ __forceinline__ void cq_post_tile(int blk, int nblk, int64_t nrows, i
                 const int i = drow ? e >> 5 : e & 255, j = drow ? e & 31 : e >> 8;
                 if (i < nr && j < b && r0 + i >= b) dst[(r0 + i) * drs + j * dcs] = ov[u];
             }
+        }
         }
         if (r0 < b) {                                     // (the first tile only) the top block comes from the reconstruction
             for (int e = tid; e < 1024; e += 256) {
@@ -1136,11 +1161,15 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
     alive = s_flag != 0;
     __syncthreads();
     if (alive) {
+        FQ_CLK(0);
         if (writer && tid == 0) { stt->done = 0; stt->pass = 0; stt->ndefer_total = 0; stt->nrefill_total = 0; stt->fallback = 0; }
         const int ex = cq_load_scaled_tile(X, xrs, xcs, r0, nr, b, T, red, tid);
+        FQ_CLK(1);
         cq_block_gram(T, scr, part + (int64_t)blk * CQ_PART, tid);
         if (tid == 0) cq_sti(bexp + blk, ex);
+        FQ_CLK(2);
         alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid, spin_limit);
+        FQ_CLK(3);
         int dec = 0, tlast = 0;
         const bool sliced = nblk > CQ_SLICE_FROM;
         int emax0 = 0;
@@ -1151,6 +1180,7 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
         if (alive) {
             if (sliced) cq_tail_fused(gsum, nullptr, 1, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot, emax0);
             else cq_tail_fused(part, bexp, nblk, b, 0, stt, writer, Gs, Rf, s_out, maxpass, tid, (long long)nrows * b, slot);
+            FQ_CLK(4);
             dec = s_out[0];
             const int emax = s_out[3];
             const double scl0 = (ex > -2000 && emax > -2000) ? ldexp(1.0, ex - emax) : 0.0;     // tile is 2^-ex X; the passes work on 2^-emax X
@@ -1160,6 +1190,7 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
                 __syncthreads();                             // s_out is rewritten by the next tail
                 cq_substitute(T, Rf, tid, deadmask, seed + 0x9E3779B97F4A7C15ULL * (uint64_t)t, r0, nr, t == 1 ? scl0 : 1.0);
                 __syncthreads();
+                if (t == 1) FQ_CLK(5);
                 double* pt = part + (int64_t)(t & 1) * nblk * CQ_PART;
                 if (!fin) cq_block_gram(T, scr, pt + (int64_t)blk * CQ_PART, tid);
                 if (writer && lu_all) {
@@ -1168,8 +1199,10 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
                     for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; cq_st(tb + e, T[(e >> 5) * CQ_P + (e & 31)]); }
                 }
                 if (writer && tid == 0) stt->pass = t;
+                if (t == 1) FQ_CLK(6);
                 alive = cq_grid_barrier(&stt->fcounter, base + (++nbar) * nblk, &s_flag, tid, spin_limit);
                 if (!alive) break;
+                if (t == 1) FQ_CLK(7);
                 tlast = t;
                 if (fin) {
                     dec = 1;
@@ -1189,6 +1222,7 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
                 dec = s_out[0];
             }
         }
+        FQ_CLK(8);
         if (alive && dec == 1) {
             if (lu_all == nullptr) {
                 cq_store_tile(T, Y, rs, cs, r0, nr, b, tid);
@@ -1196,7 +1230,9 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
                 double* lu = lu_all + (int64_t)blk * CQ_LU_DOUBLES;
                 cq_lu(topblk + (tlast & 1) * 1024, true, b, lu, writer ? Tp : nullptr, scr, tid);
                 __syncthreads();                             // (waits for this workgroup's stores to lu as well)
+                FQ_CLK(9);
                 cq_post_tile(blk, nblk, nrows, b, Y, rs, cs, W, wrs, wcs, Wq, lu, T, GR, tid, true);
+                FQ_CLK(10);
             }
         } else if (alive && dec == 2 && writer) {
             // out of passes (never seen on the contraction path): workgroup 0 redoes the panel with Householder reflections from

@@ -1262,10 +1262,12 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
         // --- panel orthonormalisation
         const bool fused_panel = (nb == 32 && !use_tsqr);     // orthonormalisation + reconstruction + tall products in one chain (cholqr.hip)
         if (fused_panel) {
+            // W_p = Y_p T_p^T of EVERY panel is kept (in the m x k array that holds Y T on the other paths): besides the trailing update it
+            // serves the Q accumulation, H_p Q = Q - Y_p (W_p^T Q), so Y T is never formed (a third of the panel step's output)
             double* Tpf = w.T + (int64_t)p * nb * nb;
-            Mat Wqf = sub(Wqm, j0, j0), Wpf = mat((lookahead && (p & 1)) ? w.W2 : w.W, wrs, wcs);
-            if ((rc = cholqr_panel(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, (uint64_t)p + 1, 1, Tpf, Wpf.p, wrs, wcs,
-                                   Wqf.p, &fbase, w.cq_state)))
+            Mat Wpf = sub(Wqm, j0, j0);
+            if ((rc = cholqr_panel(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, (uint64_t)p + 1, 1, Tpf, Wpf.p, yrs, ycs,
+                                   nullptr, &fbase, w.cq_state)))
                 return rc;
         } else if (nb == 32) {
             if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1, &fbase, w.cq_state))) return rc;
@@ -1292,7 +1294,7 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
         }
         // --- Householder reconstruction
         double* Tp = w.T + (int64_t)p * nb * nb;
-        Mat Wqp = sub(Wqm, j0, j0), Wp = mat((lookahead && (p & 1)) ? w.W2 : w.W, wrs, wcs);
+        Mat Wqp = sub(Wqm, j0, j0), Wp = fused_panel ? sub(Wqm, j0, j0) : mat((lookahead && (p & 1)) ? w.W2 : w.W, wrs, wcs);
         if (fused_panel) {
         } else if (nb == 32)
             TN_PROF_LAUNCH(st, PROF_LU, hipLaunchKernelGGL((lu_reconstruct_kernel<32>), dim3(1), dim3(256), 0, st, Yp.p, yrs, ycs, b, w.Uinv, Tp, w.UT, w.UTq,
@@ -1387,10 +1389,13 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
     // (every workgroup of the Q part recomputes the b x b product: worth it while there are few of them, i.e. for the small
     //  factorisations whose time is launches; the large ones keep the two GEMMs)
     const int fold_b = (nb == 32 && P >= 1 && m * k <= 256 * 512) ? (int)(k - jf) : 0;
+    // fused panel step: the m x k array holds W = Y T^T of every panel and  H_p Q = Q - Y_p (W_p^T Q);  otherwise it holds Y T and
+    // H_p Q = Q - (Y_p T_p) (Y_p^T Q).  The kernel below forms  second (first_top^T Z)  either way.
+    const bool wform = (nb == 32 && !use_tsqr);
     {
         const unsigned nR = (unsigned)cdiv(k * n, 256), nQ = (unsigned)cdiv(m * k, 256);
         TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(assemble_R_init_Q_kernel, dim3(nR + nQ), dim3(256), 0, st, A, rs, cs, nb, k, n, w.Z, w.Tri, R, rrs,
-                           rcs, nR, Q, qrs, qcs, m, qcolfast, (const double*)w.Y, (const double*)w.Wq, yrs, ycs, jf, fold_b));
+                           rcs, nR, Q, qrs, qcs, m, qcolfast, (const double*)(wform ? w.Wq : w.Y), (const double*)(wform ? w.Y : w.Wq), yrs, ycs, jf, fold_b));
         TN_CHECK_LAUNCH("assemble_R_init_Q_kernel");
     }
     Mat Qm = mat(Q, qrs, qcs);
@@ -1401,8 +1406,8 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
         Mat Qp = sub(Qm, j0, j0), Yp = sub(Ym, j0, j0), Wqp = sub(Wqm, j0, j0);
         Mat Xm = mat(w.X, nq, 1);
         // Y^T Q (the last panel meets [Z; 0]: only its top b rows are non-zero, the product over the rest adds zeros)
-        if ((rc = gemm(st, b, nq, p == P - 1 ? (int64_t)b : mp, 1.0, tr(Yp), Qp, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
-        if ((rc = gemm(st, mp, nq, b, -1.0, Wqp, Xm, 1.0, Qp))) return rc;                                  // Q -= (Y T) (Y^T Q)
+        if ((rc = gemm(st, b, nq, p == P - 1 ? (int64_t)b : mp, 1.0, tr(wform ? Wqp : Yp), Qp, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+        if ((rc = gemm(st, mp, nq, b, -1.0, wform ? Yp : Wqp, Xm, 1.0, Qp))) return rc;                     // Q -= (Y T) (Y^T Q) = Y (W^T Q)
     }
     return 0;
 }
