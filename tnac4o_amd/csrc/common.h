@@ -144,8 +144,10 @@ int gram_nchunk(int64_t L);
 // mode 2: SVD pair step  -> out = J (orthogonal), unscaled Gram; nrot[g] = rotations applied, maxoff[g] = largest
 //         relative off-diagonal seen before rotating.
 // relevant2 (mode 2): vectors with squared norm <= relevant2 are left out of the convergence measure maxoff.
+// allow_fast (mode 2, 64 vectors): pairs in the quadratic regime may take the near-diagonal steps on the matrix cores instead of the
+// cyclic sweeps (TN_EIG_FAST; see eig_small3_kernel).
 int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngroups, int mode, int max_sweeps,
-              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2 = 0.0);
+              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2 = 0.0, int allow_fast = 1);
 
 // In place:  X(r, 0:b) <- X(r, 0:b) * S   for r < nrows  (S is b x b row-major in global memory).
 int rows_times_small(hipStream_t st, double* X, int64_t rs, int64_t cs, int64_t nrows, int b, const double* S);

@@ -819,6 +819,26 @@ __global__ __launch_bounds__(256) void eig_small2_kernel(const double* __restric
     }
 }
 
+// Jacobi rotation of a pair (p < q) from g_pp, g_qq, g_pq: the smaller-angle rotation, (c, sn) with G' = R^T G R, R = [[c, sn], [-sn, c]];
+// false (c = 1, sn = 0) when |g_pq| <= tol sqrt(|g_pp g_qq|)  (the rule of eig_small3_kernel's `decide`)
+__device__ __forceinline__ bool eig_decide(double gpp, double gqq, double gpq, double tol, double& c, double& sn) {
+    c = 1.0; sn = 0.0;
+    const double g2 = gpq * gpq;
+    if (g2 > tol * tol * fabs(gpp * gqq)) {
+        const double d = gqq - gpp;
+        const double rh = rsqrt2n(d * d + 4.0 * g2);
+        const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+        const double rcv = rsqrt2n(c2);
+        const double sabs = fabs(gpq) * rh * rcv;
+        if (sabs <= 1.0 && c2 <= 1.0000000000000002) {
+            c = c2 * rcv;
+            sn = ((d >= 0.0) == (gpq >= 0.0)) ? sabs : -sabs;
+            return true;
+        }
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------ eig_small, third form
 // The pipelined kernel above is bound by the instruction streams of its single waves (a wave issues one fp64 instruction per 4
 // cycles: 128 for the update of a quarter of G, 128 for J, ~70 dependent ones for the rotation parameters), not by its barrier.
@@ -830,7 +850,7 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
                                                          int max_sweeps, double dead_thresh,
                                                          double* __restrict__ out, int* __restrict__ dead,
                                                          int* __restrict__ nrot_out, double* __restrict__ maxoff_out,
-                                                         double relevant2, int dbg) {
+                                                         double relevant2, int dbg, double fast_thr) {
     constexpr int P = NB + 1;
     __shared__ double Gb[2][NB * P];
     __shared__ double J[NB * P];
@@ -890,10 +910,11 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
         }
         __syncthreads();
     }
-    {
-        __shared__ double rdg[NB];
+    __shared__ double rdg[NB];
+    // largest relative off-diagonal |g_ij| / sqrt(g_ii g_jj) among the relevant vectors -> red[0] (ends with a barrier)
+    auto measure = [&](const double* Gm) {
         if (tid < NB) {
-            const double gii = fabs(G[tid * P + tid]);
+            const double gii = fabs(Gm[tid * P + tid]);
             rdg[tid] = (gii > relevant2 && tid < nvec) ? fast_rcp(gii) : 0.0;
         }
         __syncthreads();
@@ -901,7 +922,7 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
 #pragma unroll
         for (int t = 0; t < NB * NB / NT_; ++t) {
             const int e = tid + NT_ * t, i = e / NB, j = e % NB;
-            const double g = G[i * P + j];
+            const double g = Gm[i * P + j];
             const double r2 = (i < j) ? g * g * rdg[i] * rdg[j] : 0.0;
             m = r2 > m ? r2 : m;
         }
@@ -912,11 +933,139 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
         if (tid == 0) {
             const double mm = fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
             red[0] = sqrt(mm);
-            if (maxoff_out) maxoff_out[grp] = red[0];
         }
         __syncthreads();
-    }
-    const bool need = (mode != 1) && (nvec >= 2) && (red[0] > 8.881784197001252e-16);
+    };
+    measure(G);
+    if (tid == 0 && maxoff_out) maxoff_out[grp] = red[0];
+    // ---- near-diagonal fast path (SVD pair step, 64 x 64): in the quadratic regime -- every relative off-diagonal below fast_thr, which
+    // is what a pair meets from the second outer sweep on -- the 2 x 63 dependent steps of the cyclic sweeps are replaced by Newton-like
+    // steps on the whole matrix: K = the antisymmetric matrix of ALL Jacobi angles of the current G (K_pq = sin theta_pq), R = I + K made
+    // orthogonal by one Newton-Schulz step (= exp(K) to second order), G <- R^T G R and J <- J R on the matrix cores: five 64^3 products
+    // per step instead of 63 barriers.  Off-diagonals fall quadratically (1e-4 -> 1e-8 -> 1e-16).  The step is only taken while
+    // ||K||_F stays small (nearly equal diagonal entries can ask for large angles: those belong to the cyclic sweep) and while it pays
+    // (the largest off-diagonal must shrink fourfold); otherwise the cyclic sweeps below take over from the current G and J.  G only
+    // steers: J stays orthogonal to rounding (Newton-Schulz here and at the end), and the caller measures convergence on the vectors.
+    int fast_rot = 0;
+    bool fast_done = false;
+    // (Gc: the current matrix, red[0]: its measure; Wk: scratch of the same size.  Leaves red[0] = the measure of what it leaves in Gc.)
+    auto fast_try = [&](double* Gc, double* Wk) {
+        if constexpr (NB == 64) {
+            __shared__ double Rb[NB * P];
+            typedef double d4f __attribute__((ext_vector_type(4)));
+            const int w8 = tid >> 6, ln = tid & 63, li = ln & 15, lk = ln >> 4;
+            const int ti = w8 >> 1, tj0 = (w8 & 1) * 2;
+            int rot_here = 0;
+            // acc[t] = op(A) B for this wave's two 16 x 16 tiles (row block ti, column blocks tj0, tj0 + 1)
+            auto mm64 = [&](const double* Am, bool at, const double* Bm, d4f (&acc)[2]) {
+                acc[0] = d4f{0.0, 0.0, 0.0, 0.0};
+                acc[1] = acc[0];
+#pragma unroll
+                for (int ks = 0; ks < NB / 4; ++ks) {
+                    const int k = ks * 4 + lk;
+                    const double fa = at ? Am[k * P + ti * 16 + li] : Am[(ti * 16 + li) * P + k];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, Bm[k * P + (tj0 + t) * 16 + li], acc[t], 0, 0, 0);
+                }
+            };
+            auto put = [&](double* Dm, const d4f (&acc)[2]) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Dm[(ti * 16 + lk + 4 * r) * P + (tj0 + t) * 16 + li] = acc[t][r];
+            };
+            const double tolf = 8.881784197001252e-16;
+            double m_prev = 0.0;
+            for (int it = 0; it < 5 && !fast_done; ++it) {
+                // relevance from the CURRENT diagonal: a pair takes part when at least one of its vectors is relevant.  Two vectors
+                // below the threshold are both discarded by the caller whatever they look like, and their mutual angles are noise
+                // (large: they alone would push ||K|| over the limit); but a vector that has just dropped below the threshold must still be
+                // cleaned of its components along the kept ones, or it is not small at all.  Done = no such pair asks for a rotation,
+                // the criterion of the cyclic sweeps.
+                if (tid < NB) {
+                    const double gii = fabs(Gc[tid * P + tid]);
+                    rdg[tid] = (gii > relevant2 && tid < nvec) ? 1.0 : 0.0;
+                }
+                __syncthreads();
+                double k2 = 0.0, mw = 0.0;
+                int nrl = 0;
+                for (int e = tid; e < NB * NB; e += NT_) {
+                    const int i = e / NB, j = e % NB;
+                    double v = (i == j) ? 1.0 : 0.0;
+                    if (i != j) {
+                        const int p = i < j ? i : j, q = i < j ? j : i;
+                        double c, sn;
+                        v = 0.0;
+                        if (rdg[p] + rdg[q] > 0.0) {
+                            const double gpp = Gc[p * P + p], gqq = Gc[q * P + q], gpq = Gc[p * P + q];
+                            if (eig_decide(gpp, gqq, gpq, tolf, c, sn)) {
+                                v = (i < j) ? sn : -sn; k2 += sn * sn; ++nrl;
+                                const double r2 = gpq * gpq / fabs(gpp * gqq);
+                                mw = r2 > mw ? r2 : mw;
+                            }
+                        }
+                    }
+                    Rb[i * P + j] = v;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { k2 += __shfl_xor(k2, o, 64); nrl += __shfl_xor(nrl, o, 64); mw = fmax(mw, __shfl_xor(mw, o, 64)); }
+                __syncthreads();
+                if (ln == 0) { red[8 + w8] = k2; red[16 + w8] = (double)nrl; red[24 + w8] = mw; }
+                __syncthreads();
+                double ksum = 0.0, nsum = 0.0, mwide = 0.0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { ksum += red[8 + w]; nsum += red[16 + w]; mwide = fmax(mwide, red[24 + w]); }
+                mwide = sqrt(mwide);
+                if (tid == 0) red[0] = mwide;                      // what the launch leaves (read after the loop)
+                if (nsum == 0.0) { fast_done = true; break; }      // nothing left to rotate
+                if (!(ksum <= 0.02)) break;                        // ||K||_F^2 > 0.02 (or NaN): the cyclic sweeps take over
+                if (it > 0 && !(mwide <= 0.25 * m_prev)) break;    // the steps do not pay: cyclic sweeps from here
+                m_prev = mwide;
+                d4f acc[2];
+                // R = I + K is orthogonal to ||K||^2; a Newton-Schulz step takes an error d to 3/4 d^2.  J must leave this launch
+                // orthogonal to ~1e-8 (its own closing Newton-Schulz step squares that), so: as many steps as ||K|| asks for.
+                const int nns = ksum <= 3e-8 ? 1 : ksum <= 1e-4 ? 2 : 3;
+                for (int ns = 0; ns < nns; ++ns) {
+                    mm64(Rb, true, Rb, acc);                       // S = R^T R
+                    put(Wk, acc);
+                    __syncthreads();
+                    mm64(Rb, false, Wk, acc);                      // R S
+                    d4f rn[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rn[t][r] = 1.5 * Rb[(ti * 16 + lk + 4 * r) * P + (tj0 + t) * 16 + li] - 0.5 * acc[t][r];
+                    __syncthreads();
+                    put(Rb, rn);                                   // R <- 1.5 R - 0.5 R R^T R
+                    __syncthreads();
+                }
+                mm64(Gc, false, Rb, acc);                          // W = G R
+                put(Wk, acc);
+                __syncthreads();
+                mm64(Rb, true, Wk, acc);                           // R^T W
+                d4f jn[2];
+                mm64(J, false, Rb, jn);                            // J R
+                __syncthreads();
+                put(Gc, acc);
+                put(J, jn);
+                __syncthreads();
+                for (int e = tid; e < NB * NB; e += NT_) {         // exactly symmetric again (the cyclic sweeps rely on it): the mean of both halves
+                    const int i = e / NB, j = e % NB;
+                    if (i < j) { const double v = 0.5 * (Gc[i * P + j] + Gc[j * P + i]); Gc[i * P + j] = v; Gc[j * P + i] = v; }
+                }
+                __syncthreads();
+                rot_here += (int)(0.5 * nsum);
+            }
+            __syncthreads();
+            fast_rot += rot_here;
+            if (tid == 0) total += rot_here;
+            __syncthreads();
+        }
+    };
+    const bool fast_on = (NB == 64) && mode == 2 && nvec >= 2 && fast_thr > 0.0;
+    if (fast_on && red[0] > 8.881784197001252e-16 && red[0] <= fast_thr) fast_try(Gb[0], Gb[1]);
+    const bool need = (mode != 1) && (nvec >= 2) && !fast_done && (red[0] > 8.881784197001252e-16);
     int cur = 0;
     if (need) {
         constexpr int HP = NB / 2;
@@ -998,6 +1147,10 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
         double jr[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) jr[k] = (k == tid - 192) ? 1.0 : 0.0;
+        if (fast_rot > 0 && jwave && tid - 192 < NB) {     // the fast path has turned J already: go on from there
+#pragma unroll
+            for (int k = 0; k < NB; ++k) jr[k] = J[(tid - 192) * P + k];
+        }
         constexpr int FU = (NB == 64) ? 7 : 1;
         static_assert(M % FU == 0, "group length must divide the sweep");
         auto apply_j = [&](int pb, auto uc) {
@@ -1241,7 +1394,7 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
 }
 
 int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngroups, int mode, int max_sweeps,
-              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2) {
+              double dead_thresh, double* out, int* dead, int* nrot, double* maxoff, double relevant2, int allow_fast) {
     TN_CHECK_ARG(nvec >= 1 && nvec <= NBMAX, "nvec out of range");
     if (ngroups <= 0) return 0;
     prof_begin(st, PROF_EIG);
@@ -1249,13 +1402,15 @@ int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngro
     static const int gen = [] { const char* e = getenv("TN_EIG_PIPELINED"); return e ? atoi(e) : 2; }();      // 0, 1 (256 threads), 2 (512 threads)
     const bool pipelined = gen == 1;
     static const int dbg = [] { const char* e = getenv("TN_EIG_DBG"); return e ? atoi(e) : 0; }();      // timing diagnostics of the third form
+    // TN_EIG_FAST: largest relative off-diagonal up to which a pair takes the near-diagonal fast path (0 = never; see eig_small3_kernel)
+    static const double fast_thr = [] { const char* e = getenv("TN_EIG_FAST"); return e ? atof(e) : 1e-2; }();
     if (gen >= 2) {
         if (nvec <= 32)
             hipLaunchKernelGGL((eig_small3_kernel<32>), dim3(ngroups), dim3(512), 0, st, part, nchunk, nvec, mode, max_sweeps,
-                               dead_thresh, out, dead, nrot, maxoff, relevant2, dbg);
+                               dead_thresh, out, dead, nrot, maxoff, relevant2, dbg, 0.0);
         else
             hipLaunchKernelGGL((eig_small3_kernel<64>), dim3(ngroups), dim3(512), 0, st, part, nchunk, nvec, mode, max_sweeps,
-                               dead_thresh, out, dead, nrot, maxoff, relevant2, dbg);
+                               dead_thresh, out, dead, nrot, maxoff, relevant2, dbg, allow_fast ? fast_thr : 0.0);
     } else if (pipelined) {
         if (nvec <= 32)
             hipLaunchKernelGGL((eig_small2_kernel<32>), dim3(ngroups), dim3(256), 0, st, part, nchunk, nvec, mode, max_sweeps,

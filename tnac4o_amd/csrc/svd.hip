@@ -570,7 +570,7 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
                               (int64_t)ng * nchunk * nvec * nvec * 8, &xg)))
                 return rc;
             if ((rc = eig_small(st, w.part, used, nvec, ng, 2, (ng == 1) ? 12 : (outer == 0 ? inner_env : inner_later), 0.0, w.Js, nullptr, w.nrot,
-                                w.maxoff + (int64_t)r * ng, relevant2)))
+                                w.maxoff + (int64_t)r * ng, relevant2, outer < 8 ? 1 : 0)))      // (a call that drags on goes back to the plain sweeps)
                 return rc;
             GemmExtra xa;
             xa.pairs = pr; xa.pw = SVD_W; xa.mapB = 1; xa.mapC = 1; xa.skip = w.nrot;
