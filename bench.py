@@ -133,13 +133,18 @@ def main():
     ap.add_argument('--mode', default='sweep', choices=['sweep', 'replicas'],
                     help='sweep: one instance, rotations (and beam partners) sharded over the ranks, strong scaling; '
                          'replicas: every rank its own instance, no collective, weak scaling')
-    ap.add_argument('--cpu-rows', type=int, default=4, help='bulk sites of the middle row timed on the CPU oracle (0 disables)')
+    ap.add_argument('--cpu-rows', type=int, default=2, help='whole bulk rows (apply_mpo + compress_mps) timed on the CPU oracle (0 disables)')
     ap.add_argument('--concurrent', type=int, default=4,
                     help='N = 1: lattice rotations of the instance interleaved on the GPU, one stream each (4 = the full step)')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--sample', type=int, default=8,
                     help='in the timed region bracket every n-th launch of the dominant kernel family with events')
     ap.add_argument('--no-search', action='store_true', help='skip the (untimed) full ground-state search figure')
+    ap.add_argument('--beam-shards', default='auto',
+                    help="ranks per rotation team when --gpus exceeds the number of rotations: 'auto' (default) = 1, i.e. one working rank per "
+                         "rotation and the other ranks idle -- the library's beam walk of one rank (tn_beam_search, ~0.2 s per rotation) "
+                         "beats the sharded torch driver (DESIGN.md section 6); an integer forces teams of that size, whose owners "
+                         "broadcast the boundary MPS to their beam partners over RCCL inside the timed step")
     ap.add_argument('--nrot', type=int, default=4, help='lattice rotations of the instance (4 = the reference driver; fewer only for rehearsals)')
     ap.add_argument('--rehearse-one-gpu', action='store_true',
                     help='multi-rank rehearsal on a single GPU: every rank uses cuda:0 and the exchange runs over gloo')
@@ -209,10 +214,20 @@ def main():
         nteams = min(world, NROT)
         if world % nteams:
             raise SystemExit('--gpus must be 1, 2, 4 or a multiple of the number of rotations')
-        B = world // nteams
-        team, owner = rank // B, rank % B == 0
-        my_rots = [r for r in range(NROT) if r % nteams == team]
-        beam_group = parallel._beam_groups(world, B)[team] if B > 1 else None
+        B = 1 if args.beam_shards == 'auto' else int(args.beam_shards)
+        if B < 1 or world % B or world // B < nteams:
+            raise SystemExit('--beam-shards must divide --gpus and leave at least one team per rotation')
+        if B == 1:
+            # one working rank per rotation; with more ranks than rotations the others idle (they take part in the barriers and in the
+            # final gather only): sharding the beam inside a rotation loses against the library's beam walk of one rank
+            team, owner = rank, rank < nteams
+            my_rots = [r for r in range(NROT) if r % nteams == rank] if owner else []
+            beam_group = None
+        else:
+            nteams = world // B
+            team, owner = rank // B, rank % B == 0
+            my_rots = [r for r in range(NROT) if r % nteams == team]
+            beam_group = parallel._beam_groups(world, B)[team]
     sweeps_per_step = len(my_rots) * (world if replicas else 1) if (replicas or world == 1) else NROT
     solvers = [make(r) for r in my_rots] if owner else []
     solver = solvers[0] if solvers else None
@@ -312,7 +327,8 @@ def main():
             ('%d ranks, every rank its own instance with 4 interleaved rotations, no collective' % world) if replicas else \
             ('%d ranks = %d rotation teams x %d rank(s): each team owner sweeps %d rotation(s)%s' %
              (world, nteams, B, len(my_rots), ', boundary MPS broadcast to its beam partner(s) over RCCL in the timed step'
-              if B > 1 else ''))
+              if B > 1 else (', %d rank(s) idle (more GPUs than rotations; --beam-shards 2 shards the beam instead)' % (world - nteams)
+                             if world > nteams else '')))
         out = {
             'metric': 'PEPS-contraction ms/sweep, %s chi=%d (boundary-MPS sweep _setup_rhoT)' % (
                 'chimera L=%d' % (n * n * 8) if kind == 'Ising' else 'RMF %dx%d d=8' % (n, n), chi),
@@ -329,6 +345,20 @@ def main():
                        'single_chain_sweep_latency_ms': single_ms,
                        'single_chain_sweep_latency_with_events_on_every_launch_ms': single_prof_ms},
         }
+        if single_ms:
+            # a sweep is one sequential chain; a GPU interleaves c chains at (1 + f (c - 1)) x the latency of one, f
+            # measured here when 4 chains ran (else the round-3 figure 0.11); more GPUs than rotations add nothing to the sweep step
+            t1 = single_ms
+            f = ((ms_per_step / t1 - 1.0) / 3.0) if (world == 1 and len(my_rots) == 4) else 0.11
+            model = {}
+            for N in (1, 2, 4, 8):
+                c = max(1, 4 // min(N, 4))
+                model[str(N)] = {'chains_per_gpu': c, 'expected_step_ms': t1 * (1.0 + f * (c - 1)), 'expected_value_ms_per_sweep': t1 * (1.0 + f * (c - 1)) / 4.0}
+            for N in model:
+                model[N]['expected_speedup_vs_1'] = model['1']['expected_step_ms'] / model[N]['expected_step_ms']
+            out['scaling_model'] = {'single_chain_latency_ms': t1, 'cost_of_an_added_chain_frac': f, 'by_gpus': model,
+                                    'note': 'strong scaling of ONE instance over its 4 lattice rotations (north-star decomposition): bounded by the latency '
+                                            'of one chain; N = 8 keeps 4 working ranks (beam sharding inside a rotation does not pay at M = 1024)'}
         if solver is not None and getattr(solver, 'rhoT', None):
             out['config'].update({'rhoT_discarded_max': float(max(solver.rhoT_discarded)),
                                   'rhoT_overlap_min': float(min(solver.rhoT_overlap)),
@@ -451,94 +481,114 @@ def physical_cores():
 
 
 def cpu_baseline(n, args, solver, kw, single_ms):
-    """CPU oracle ("port" of the reference algorithm, numpy/scipy on OpenBLAS) on a bounded bulk sample of the same sweep: the
-    middle row's absorbed boundary MPS, first canonisation pass of compress_mps (attach GEMM, QR with the reference's gauge,
-    nfactor; reference mps.py:187, 220-236) over the right edge and `cpu_rows` bulk sites -- QR shapes up to (p Dr) x Dl = 16384 x
-    1024, what the reference spends 87 % of a sweep on.  Timed with 1 BLAS thread, one per physical core and one per logical core;
-    `value` is the FASTEST of them (`cores` = its thread count).  The GPU runs the SAME steps of the SAME algorithm on the same
-    tensors (`gpu_same_sample_ms`), the two results are compared (Schmidt spectrum of the centre matrix they end with), and the
-    first pass the product really runs on that row (the weighted rank-revealing form, all 16 sites) is timed next to it."""
+    """CPU oracle ("port" of the reference algorithm: oracle/ = numpy/scipy on OpenBLAS restating tnac4o.py:1688-1693 / mps.py:175-200)
+    on a bounded sample of the SAME sweep: `cpu_rows` WHOLE bulk rows -- MPS.apply_mpo + MPS.compress_mps with the defaults of
+    search_ground_state, each from the boundary MPS the GPU sweep fed into that row -- timed with the fastest of the
+    BLAS thread counts {1, 8, 16, 32, 64, physical cores} as found on a proxy (the 4096 x 1024 QR + attach GEMM of a bulk site: what
+    the reference spends 87 % of a row on).  The product path runs the same rows on the GPU from the same inputs (`gpu_ms_per_row`);
+    the fidelity of the two compressed states is asserted (>= 1 - 1e-12) per row.  `value` = CPU time per row; the full-sweep figure
+    multiplies by the number of rows (edge rows are cheaper: an upper bound, stated).  The first-pass sample of the earlier rounds
+    (plain first canonisation pass over 8 sites of one row) is kept as the sub-field `first_pass_sample`."""
     from oracle import mps_ref as mr
     from tnac4o_amd import mps
     try:
         import threadpoolctl
     except ImportError:
         threadpoolctl = None
-    ny = n // 2
-    psi = solver.rhoT[ny + 1].copy()
-    psi.apply_mpo(solver._row_mpo(ny), Hconj=True)
-    first_bulk = max(0, n - 4)                       # absorbed bonds reach their bulk value 3 sites from the edge
-    nsites = min(n, (n - first_bulk) + args.cpu_rows)
-    sites = list(range(n - 1, n - 1 - nsites, -1))
-    host = {s: psi.A[s].cpu().numpy() for s in sites}
-
-    def cpu_run():
-        o = mr.RefMPS(d=[int(a.shape[1]) for a in psi.A], L=n, Dmax=1, canonise=None)
-        o.A = [host[s].copy() if s in host else None for s in range(n)]
-        o.D = list(psi.D)
-        o.C, o.pC = np.ones((1, 1)), n
-        t0 = time.perf_counter()
-        for s in sites:
-            o.attach_AC()
-            o.orth_right(s)
-        return 1e3 * (time.perf_counter() - t0), o
     phys, logical = physical_cores(), os.cpu_count() or 1
-    counts = [1] if threadpoolctl is None else sorted({1, phys, logical})
-    timings, best, spent = {}, None, 0.0
+
+    def limited(nt, fn):
+        if threadpoolctl is None:
+            return fn()
+        with threadpoolctl.threadpool_limits(limits=nt):
+            return fn()
+
+    # ---- thread count: proxy = one bulk-site step of the reference's first pass (attach GEMM 4096 x 1024 x 1024 + QR of 4096 x 1024)
+    rng = np.random.default_rng(1)
+    Tp = rng.standard_normal((4096, 1024))
+    Cp = rng.standard_normal((1024, 1024))
+
+    def proxy():
+        t0 = time.perf_counter()
+        mr.qr_pos(Tp @ Cp)
+        return 1e3 * (time.perf_counter() - t0)
+    counts = [1] if threadpoolctl is None else sorted({c for c in (1, 8, 16, 32, 64, phys) if c <= logical})
+    proxy_ms = {}
     for nt in counts:
-        if spent > 45e3:                             # keep the CPU leg bounded
-            break
-        if threadpoolctl is not None:
-            with threadpoolctl.threadpool_limits(limits=nt):
-                ms, o = cpu_run()
-        else:
-            ms, o = cpu_run()
-        timings[str(nt)] = ms
-        spent += ms
-        if best is None or ms < best[0]:
-            best = (ms, nt, o)
-    cpu_ms, threads, o = best
-    shapes = ['%dx%d' % (o.A[s].shape[1] * o.A[s].shape[2], host[s].shape[0]) for s in sites]
-    # the same steps on the GPU (plain pass, the reference's algorithm), from the same tensors
-    g = psi.copy()
-    g._nfs = []                                      # (the factors of this sample only, like the oracle's normC)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    g.C = torch.ones((1, 1), dtype=torch.float64, device='cuda')
-    g.pC = n
-    for s in sites:
-        g.attach_AC()
-        g.orth_right(s)
-    torch.cuda.synchronize()
-    gpu_ms = 1e3 * (time.perf_counter() - t0)
-    # parity of the two legs: the spectrum of the centre matrix (times the accumulated power-of-two factors) they end with
-    Sc = np.linalg.svd(o.C, compute_uv=False) * o.normC
-    Sg = np.linalg.svd(g.C.cpu().numpy(), compute_uv=False) * g.normC
-    k = min(len(Sc), len(Sg))
-    dev = float(np.max(np.abs(Sc[:k] - Sg[:k])) / Sc[0])
-    assert dev < 1e-12, 'cpu_baseline: GPU and CPU oracle disagree on the sample (max |dS| / S0 = %.2e)' % dev
-    # what the product runs on that row: the weighted rank-revealing first pass over all sites
-    w = psi                                          # (last use of psi: the pass works on the absorbed MPS itself, factors attached)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ok = w.canonise_right_weighted()
-    torch.cuda.synchronize()
-    prod_ms = 1e3 * (time.perf_counter() - t0)
-    ratio = cpu_ms / gpu_ms if gpu_ms > 0 else None
-    return {'value': cpu_ms, 'unit': 'ms for the sample', 'cores': int(threads), 'kind': 'port', 'cpu_model': cpu_model(),
-            'physical_cores': phys, 'logical_cores': logical, 'ms_by_blas_threads': timings,
-            'sample': 'row %d of %d (bulk), first canonisation pass of compress_mps (reference algorithm: attach GEMM + QR + nfactor) over '
-                      'sites %d..%d, QR shapes %s; oracle/ numpy+scipy, fastest of the BLAS thread counts tried (%d threads)'
-                      % (ny, n, sites[0], sites[-1], ', '.join(shapes), threads),
-            'gpu_same_sample_ms': gpu_ms, 'speedup_on_sample': ratio,
-            'parity_on_sample_max_dS_over_S0': dev,
-            'gpu_product_first_pass_whole_row_ms': prod_ms, 'gpu_product_first_pass_accepted': bool(ok),
-            'gpu_product_first_pass_note': 'the weighted rank-revealing first pass the product runs instead of the plain one, over all %d '
-                                           'sites of the same row (Gram recursion + pivoted early-exit QR)' % n,
-            'full_sweep_cpu_ms_linear_extrapolation': (ratio * single_ms) if (ratio and single_ms) else None,
-            'extrapolation': 'order of magnitude only: single-chain GPU sweep latency x (CPU / GPU time on the sample, same algorithm on '
-                             'both sides); the reference spends 87 % of a chi=64 sweep in these QR calls (SURVEY.md 3.1), the GPU sweep '
-                             'runs a cheaper first pass'}
+        limited(nt, proxy)                                 # (first touch: thread pool start-up)
+        proxy_ms[str(nt)] = min(limited(nt, proxy) for _ in range(2))
+    threads = int(min(proxy_ms, key=proxy_ms.get))
+
+    # ---- whole bulk rows
+    kwc = dict(Dmax=kw['Dmax'], tolS=1e-16, tolV=1e-10, max_sweeps=20, graduate_truncation=True)
+    rows = [n // 2 - i for i in range(max(1, args.cpu_rows))]
+    per_row = []
+    for ny in rows:
+        psi = solver.rhoT[ny + 1]
+        mpo = solver._row_mpo(ny)
+        inp = [a.cpu().numpy() for a in psi.A]
+        Ws = [w.cpu().numpy() for w in mpo.W]
+
+        def cpu_row():
+            o = mr.RefMPS(d=[a.shape[1] for a in inp], L=n, Dmax=1, canonise=None)
+            o.A = [np.array(a) for a in inp]
+            o.D = [inp[0].shape[0]] + [a.shape[2] for a in inp]
+            M = mr.RefMPO(n)
+            for i, W in enumerate(Ws):
+                M.set_direct(np.array(W), i)
+            t0 = time.perf_counter()
+            o.apply_mpo(M, Hconj=True)
+            ov = o.compress_mps(**kwc)
+            return 1e3 * (time.perf_counter() - t0), o, ov
+        cpu_ms, o, ov_ref = limited(threads, cpu_row)
+        out = psi.copy()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ov = out.apply_mpo_compress(mpo, Hconj=True, **kwc)
+        torch.cuda.synchronize()
+        gpu_ms = 1e3 * (time.perf_counter() - t0)
+        got = mr.RefMPS(d=[a.shape[1] for a in out.A], L=n, Dmax=1, canonise=None)
+        got.A = [a.cpu().numpy() for a in out.A]
+        fid = abs(mr.mps_dot(got, o)) / np.sqrt(mr.mps_dot(got, got) * mr.mps_dot(o, o))
+        assert 1.0 - fid < 1e-12, 'cpu_baseline: GPU and CPU oracle disagree on row %d (1 - fidelity = %.2e)' % (ny, 1.0 - fid)
+        per_row.append({'row': ny, 'cpu_ms': cpu_ms, 'gpu_ms': gpu_ms, 'one_minus_fidelity': float(1.0 - fid), 'overlap_cpu': float(ov_ref),
+                        'overlap_gpu': float(ov), 'discarded_max_cpu': float(max(o.discarded)), 'discarded_max_gpu': float(max(out.discarded)),
+                        'absorbed_bond_max': int(max(a.shape[0] for a in inp) * max(w.shape[0] for w in Ws))})
+    cpu_row_ms = float(np.mean([r['cpu_ms'] for r in per_row]))
+    gpu_row_ms = float(np.mean([r['gpu_ms'] for r in per_row]))
+
+    # ---- the earlier rounds' sample, kept for continuity: plain first canonisation pass over the right edge + 4 bulk sites of the middle row
+    first_pass = None
+    try:
+        ny = n // 2
+        psi = solver.rhoT[ny + 1].copy()
+        psi.apply_mpo(solver._row_mpo(ny), Hconj=True)
+        sites = list(range(n - 1, n - 9, -1))
+        host = {s_: psi.A[s_].cpu().numpy() for s_ in sites}
+
+        def fp_run():
+            o = mr.RefMPS(d=[int(a.shape[1]) for a in psi.A], L=n, Dmax=1, canonise=None)
+            o.A = [host[s_].copy() if s_ in host else None for s_ in range(n)]
+            o.D = list(psi.D)
+            o.C, o.pC = np.ones((1, 1)), n
+            t0 = time.perf_counter()
+            for s_ in sites:
+                o.attach_AC()
+                o.orth_right(s_)
+            return 1e3 * (time.perf_counter() - t0)
+        first_pass = {'what': 'plain first canonisation pass (attach GEMM + QR + nfactor) over sites %d..%d of row %d' % (sites[0], sites[-1], ny),
+                      'cpu_ms': limited(threads, fp_run), 'threads': threads}
+    except Exception as e:                                 # noqa: BLE001 -- a sub-field must not take the bench line down
+        first_pass = {'error': repr(e)}
+    return {'value': cpu_row_ms, 'unit': 'ms per bulk row (apply_mpo + compress_mps)', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
+            'physical_cores': phys, 'logical_cores': logical, 'proxy_ms_by_blas_threads': proxy_ms,
+            'sample': 'whole bulk rows %s of the %d-row sweep (chi = %d): MPS.apply_mpo + MPS.compress_mps of the reference algorithm (oracle/, '
+                      'numpy + scipy LAPACK) from the boundary MPS the GPU sweep fed into each row; %d BLAS threads = the fastest of %s on a '
+                      '4096 x 1024 attach + QR proxy' % (rows, n, kw['Dmax'], threads, sorted(int(k) for k in proxy_ms)),
+            'rows': per_row, 'gpu_ms_per_row': gpu_row_ms, 'speedup_per_row': cpu_row_ms / gpu_row_ms if gpu_row_ms > 0 else None,
+            'full_sweep_cpu_ms_extrapolation': cpu_row_ms * n,
+            'extrapolation': 'CPU time per bulk row x %d rows (the two edge rows are cheaper: an upper bound by < 2 rows); no GPU figure enters it' % n,
+            'first_pass_sample': first_pass}
 
 
 if __name__ == '__main__':

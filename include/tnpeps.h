@@ -291,10 +291,16 @@ int tn_profile_get_phase(int phase, int family, uint64_t* calls_host, double* ms
  *   nfs_dev         DEVICE table of nfs_cap pairs [nf, 1/nf]: the power-of-two factors taken out of the centre matrices (normC is
  *                   their product), *nfs_count_host of them written
  *   info_host[8]    {a-posteriori bound of the weighted pass, plain-pass fallbacks, weighted pass used, peak arena bytes, sum of the
- *                   bond dimensions before / after the first canonisation pass, 0, 0}
+ *                   bond dimensions before / after the first canonisation pass, attempts redone after a barrier time-out (see
+ *                   tn_fused_timeouts: the call checks once, at its end, and redoes the row through the multi-launch forms), 0}
+ * tn_compress_mps_arena_bytes: Dmax >= 0 -> what a call needs when the weighted first pass is accepted (~1.6x the measured peak at
+ * L = 2048); Dmax < 0 -> the conservative bound that also covers the plain first pass on the kept input.  A call that runs out of arena
+ * fails with -3 and has returned nothing: retry with the conservative size (tnac4o_amd.ops does).  nfs_cap too small: -3 as well (size
+ * it (2 max_sweeps + 16) L + 64).
  * Synchronises `stream` wherever the algorithm needs a number on the host (kept ranks, convergence, overlaps).  On return the results
  * have been copied out of the arena by `stream`; the arena may be reused by the next call on the same stream.
- * Errors: -3 arena too small, -4 Jacobi sweeps did not converge even after QR preconditioning, -5 zero centre matrix. */
+ * Errors: -3 arena (or factor table) too small, -4 Jacobi sweeps did not converge even after QR preconditioning, -5 zero centre matrix,
+ * -7 launches with in-kernel barriers gave up twice in a row. */
 int64_t tn_compress_mps_arena_bytes(int64_t L, const int64_t* site_dims_host, const int64_t* mpo_dims_host, int64_t Dmax);
 int tn_compress_mps(int64_t L, const double* const* sites_host, const int64_t* site_dims_host, const double* const* mpo_host,
                     const int64_t* mpo_dims_host, int hconj, int64_t Dmax, double tolS, double tolV, int max_sweeps, int graduate, int flags,

@@ -123,8 +123,8 @@ def test_rmf_d8_chi128_config5_shapes():
 
 
 # --------------------------------------------------------------------------- the headline size against the oracle
-def _oracle_row(inp_sites, mpo_sites, chi, perturb=None):
-    """One row step of the reference algorithm on the CPU oracle: apply_mpo(Hconj=True) + compress_mps from the given input MPS / MPO
+def _oracle_row(inp_sites, mpo_sites, chi, perturb=None, hconj=True):
+    """One row step of the reference algorithm on the CPU oracle: apply_mpo(Hconj=hconj) + compress_mps from the given input MPS / MPO
     (host arrays).  perturb: relative size of a random perturbation of every QR input (the eps probe of the oracle's own conditioning)."""
     from oracle import mps_ref as mr
     o = mr.RefMPS(d=[a.shape[1] for a in inp_sites], L=len(inp_sites), Dmax=1, canonise=None)
@@ -138,7 +138,7 @@ def _oracle_row(inp_sites, mpo_sites, chi, perturb=None):
         rng = np.random.default_rng(0)
         mr.qr_pos = lambda T: orig(T * (1 + perturb * rng.standard_normal(T.shape)))
     try:
-        o.apply_mpo(M, Hconj=True)
+        o.apply_mpo(M, Hconj=hconj)
         ov = o.compress_mps(Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20, graduate_truncation=True)
     finally:
         mr.qr_pos = orig
@@ -146,12 +146,15 @@ def _oracle_row(inp_sites, mpo_sites, chi, perturb=None):
 
 
 def test_headline_rows_hip_vs_oracle():
-    """BASELINE's headline size against the CPU oracle (reference tnac4o.py:1674-1695 at L = 2048, chi = 64, seed 20260004): rows 14
-    (absorbed bond 256, the first truncating row) and 13 (absorbed bond 1024: the bulk shape, 16384 x 1024 QRs and 1024 x 1024
-    centre matrices) of the bench's sweep, HIP (the production path: tn_compress_mps with the weighted rank-revealing first pass,
-    early-exit QR, block-Jacobi SVD) against oracle/ restating the reference's pass structure with LAPACK, both from the SAME input
-    MPS and MPO.  Fidelity of the compressed states >= 1 - 1e-12, overlaps to 1e-12, discarded weights to 1e-6 relative -- or, should
-    a row exceed that, to 3x the oracle's own movement under a 1e-16 perturbation of its QR inputs (printed)."""
+    """BASELINE's headline size against the CPU oracle (reference tnac4o.py:1674-1718 at L = 2048, chi = 64, seed 20260004): rows 14
+    (absorbed bond 256, the first truncating row), 13 (absorbed bond 1024: the bulk shape, 16384 x 1024 QRs and 1024 x 1024 centre
+    matrices), 8 (mid-lattice, chi saturated for several rows: where rounding has been amplified most) and 1 (the last bulk row) of
+    the bench's top-down sweep (_setup_rhoT, Hconj=True), and row 8 of the bottom-up sweep (_setup_rhoB, Hconj=False: the other
+    absorption orientation) -- HIP (the production path: tn_compress_mps with the weighted rank-revealing first pass, early-exit QR,
+    block-Jacobi SVD) against oracle/ restating the reference's pass structure with LAPACK, each from the SAME input MPS and MPO (the
+    GPU sweep's own boundary MPS going into that row).  Fidelity of the compressed states >= 1 - 1e-12, overlaps to 1e-12, discarded
+    weights to 1e-6 relative -- or, should a row exceed that, to 3x the oracle's own movement under a 1e-16 perturbation of its QR
+    inputs (printed with the margins)."""
     import time
     import tnac4o_amd
     from tnac4o_amd import mps
@@ -165,32 +168,43 @@ def test_headline_rows_hip_vs_oracle():
     n, chi = 16, 64
     s = tnac4o_amd.tnac4o(mode='Ising', Nx=n, Ny=n, Nc=8, J=synthetic_chimera(n, n, 20260004), beta=3.0)
     kw = dict(Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20, graduate_truncation=True)
-    psi = mps.MPS(d=1, L=n, Dmax=1, initial='X')
+
+    def check(tag, psi, mpo, out, ov, hconj):
+        inp = [a.cpu().numpy() for a in psi.A]
+        Ws = [w.cpu().numpy() for w in mpo.W]
+        t0 = time.perf_counter()
+        o, ov_ref = _oracle_row(inp, Ws, chi, hconj=hconj)
+        t_cpu = time.perf_counter() - t0
+        got = mr.RefMPS(d=[a.shape[1] for a in out.A], L=n, Dmax=1, canonise=None)
+        got.A = [a.cpu().numpy() for a in out.A]
+        fid = abs(mr.mps_dot(got, o)) / np.sqrt(mr.mps_dot(got, got) * mr.mps_dot(o, o))
+        dg, dr = max(out.discarded), max(o.discarded)
+        rel = abs(dg - dr) / max(dr, 1e-300)
+        print('%s: input bonds up to %d, oracle %.1f s; 1 - fidelity %.2e (allowed 1e-12), |d overlap| %.2e (allowed 1e-12), discarded %.6e vs %.6e '
+              '(rel %.2e), D %s vs %s' % (tag, max(a.shape[0] for a in inp), t_cpu, 1.0 - fid, abs(ov - ov_ref), dg, dr, rel, out.D, o.D))
+        assert 1.0 - fid < 1e-12, tag
+        assert abs(ov - ov_ref) < 1e-12, tag
+        if not (rel < 1e-6 or abs(dg - dr) < 1e-14):
+            o2, _ = _oracle_row(inp, Ws, chi, perturb=1e-16, hconj=hconj)
+            spread = abs(max(o2.discarded) - dr)
+            print('%s: oracle eps-probe moves its discarded weight by %.3e (rel %.2e); HIP differs by %.3e' % (tag, spread, spread / dr, abs(dg - dr)))
+            assert abs(dg - dr) <= 3.0 * spread, tag
     try:
-        for ny in (15, 14, 13):
+        psi = mps.MPS(d=1, L=n, Dmax=1, initial='X')
+        for ny in range(n - 1, 0, -1):                       # _setup_rhoT: rows 15 .. 1
             mpo = s._row_mpo(ny)
             out = psi.copy()
             ov = out.apply_mpo_compress(mpo, Hconj=True, **kw)
-            if ny in (14, 13):
-                inp = [a.cpu().numpy() for a in psi.A]
-                Ws = [w.cpu().numpy() for w in mpo.W]
-                t0 = time.perf_counter()
-                o, ov_ref = _oracle_row(inp, Ws, chi)
-                t_cpu = time.perf_counter() - t0
-                got = mr.RefMPS(d=[a.shape[1] for a in out.A], L=n, Dmax=1, canonise=None)
-                got.A = [a.cpu().numpy() for a in out.A]
-                fid = abs(mr.mps_dot(got, o)) / np.sqrt(mr.mps_dot(got, got) * mr.mps_dot(o, o))
-                dg, dr = max(out.discarded), max(o.discarded)
-                rel = abs(dg - dr) / max(dr, 1e-300)
-                print('row %d: absorbed bonds up to %d, oracle %.1f s; 1 - fidelity %.2e, |d overlap| %.2e, discarded %.6e vs %.6e (rel %.2e), D %s vs %s'
-                      % (ny, max(a.shape[0] for a in inp) * 16, t_cpu, 1.0 - fid, abs(ov - ov_ref), dg, dr, rel, out.D, o.D))
-                assert 1.0 - fid < 1e-12
-                assert abs(ov - ov_ref) < 1e-12
-                if not (rel < 1e-6 or abs(dg - dr) < 1e-14):
-                    o2, _ = _oracle_row(inp, Ws, chi, perturb=1e-16)
-                    spread = abs(max(o2.discarded) - dr)
-                    print('row %d: oracle eps-probe moves its discarded weight by %.3e (rel %.2e)' % (ny, spread, spread / dr))
-                    assert abs(dg - dr) <= 3.0 * spread
+            if ny in (14, 13, 8, 1):
+                check('rhoT row %d' % ny, psi, mpo, out, ov, True)
+            psi = out
+        psi = mps.MPS(d=1, L=n, Dmax=1, initial='X')
+        for ny in range(0, 9):                               # _setup_rhoB: rows 0 .. 8, the other orientation
+            mpo = s._row_mpo(ny)
+            out = psi.copy()
+            ov = out.apply_mpo_compress(mpo, Hconj=False, **kw)
+            if ny == 8:
+                check('rhoB row %d (Hconj=False)' % ny, psi, mpo, out, ov, False)
             psi = out
     finally:
         if limit is not None:

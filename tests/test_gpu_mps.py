@@ -516,7 +516,7 @@ def test_bench_sharded_step_rehearsal_four_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [_sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
            '--master-port', '29641', os.path.join(root, 'bench.py'), '--gpus', '4', '--rehearse-one-gpu', '--nrot', '2', '--L', '128',
-           '--chi', '16', '--steps', '1', '--warmup', '1', '--cpu-rows', '0']
+           '--chi', '16', '--steps', '1', '--warmup', '1', '--cpu-rows', '0', '--beam-shards', '2']
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]

@@ -127,6 +127,25 @@ def test_beam_sharded_inside_a_rotation(nproc, rots, inst):
         assert r1 == r2
 
 
+def test_more_ranks_than_rotations_idle_partners():
+    """The layout `bench.py --gpus 8` runs by default (--beam-shards auto): one working rank per lattice rotation, the other four
+    ranks idle -- they only take part in the final gather; every rank ends with the serial result."""
+    rots = (0, 1, 2, 3)
+    outs = run_beam_world(8, rots, 1, 1, 29590)
+    for o in outs[1:]:
+        for k in ('energy', 'degeneracy', 'rotation', 'probability', 'state', 'records'):
+            assert o[k] == outs[0][k]
+    assert [r['rotation'] for r in outs[0]['records']] == list(rots)
+    from oracle import solver_ref as sr
+    from tnac4o_amd.parallel import solve_rotations
+    J = gi.droplet_J(128, 1)
+    ser = solve_rotations(lambda: sr.RefSolver(mode='Ising', Nx=4, Ny=4, Nc=8, J=J, beta=3.0), rotations=rots, M=64,
+                          relative_P_cutoff=1e-6, Dmax=8)
+    a = outs[0]
+    assert ser['energy'] == a['energy'] and ser['degeneracy'] == a['degeneracy'] and ser['rotation'] == a['rotation']
+    assert [int(x) for x in ser['state']] == a['state'] and ser['probability'] == a['probability']
+
+
 EXCHANGE_WORKER = r'''
 import json, os, sys
 sys.path.insert(0, %(root)r)

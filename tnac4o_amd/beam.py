@@ -29,6 +29,10 @@ import torch
 from . import ops
 
 
+class NoCandidate(RuntimeError):
+    """No candidate of a site-step passes the cut-off (every log2 p is -inf or NaN): the caller redoes the search on the host path."""
+
+
 class SiteTables:
     """Per-cell look-up tables on the device: bond index of a cell state towards the row below / the cell to the right, and the three
     energy tables of tnac4o._cell_energies (reference tnac4o.py:1469-1489, 1506-1558)."""
@@ -171,6 +175,8 @@ def search_device(solver, M, relative_P_cutoff, min_dEng, beam_group=None):
             if world > 1:                                                 # only the surviving (index, log2 p) pairs travel
                 idx, vals, rest_max = parallel.allgather_candidates(idx, vals, rest_max, beam_group)
             keep = idx.numel()
+            if keep == 0:
+                raise NoCandidate('no candidate passes the cut-off at site (%d, %d)' % (ny, nx))
             if keep < total:
                 pd_max = torch.maximum(pd_max, rest_max)
             parent = torch.div(idx, q, rounding_mode='floor')
@@ -283,9 +289,13 @@ def search_native(solver, M, relative_P_cutoff, min_dEng):
     deg = torch.empty(M, dtype=torch.int64, device=dev)
     nb, pdm, gmin = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
     has_cut = relative_P_cutoff > 0
-    ops.check(L.tn_beam_search(Nx, Ny, C.cast(cells, C.c_void_p), M, 1 if has_cut else 0, float(np.log2(relative_P_cutoff)) if has_cut else 0.0,
-                               float(min_dEng), maxidx + 1, states.data_ptr(), Eng.data_ptr(), prob.data_ptr(), deg.data_ptr(), C.byref(nb),
-                               C.byref(pdm), C.byref(gmin), ws.data_ptr(), wsb, ops._stream()))
+    rc = L.tn_beam_search(Nx, Ny, C.cast(cells, C.c_void_p), M, 1 if has_cut else 0, float(np.log2(relative_P_cutoff)) if has_cut else 0.0,
+                          float(min_dEng), maxidx + 1, states.data_ptr(), Eng.data_ptr(), prob.data_ptr(), deg.data_ptr(), C.byref(nb),
+                          C.byref(pdm), C.byref(gmin), ws.data_ptr(), wsb, ops._stream())
+    if rc == -6:                                            # no candidate passed the cut-off at some site (include/tnpeps.h)
+        del keep
+        raise NoCandidate('tn_beam_search: no candidate survives the cut-off')
+    ops.check(rc)
     n = int(nb.value)
     solver.energy = Eng[:n].cpu().numpy()
     solver.degeneracy = int(deg[0].item())

@@ -8,9 +8,14 @@
 //     order-preserving ranks (prefix rank, down index, right index, suffix rank); members in candidate order; representative =
 //     first member of minimal energy (tn_merge_groups);
 //   * the M survivors = the M largest group log2 p (ties to the smaller group index), kept in group order.
-// Sorting is hipCUB's radix sort (stable); "unique" = sort, head flags, prefix sum.  Index rows live column-major (a column of
+// Sorting is rocPRIM's radix sort (stable; called directly, no CUDA-compat layer); "unique" = sort, head flags, prefix sum.  Index rows live column-major (a column of
 // boundary indices is contiguous: it is what tn_calc_pn and the keys read).
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+
+#include <cstring>
+#include <limits>
+
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -248,12 +253,12 @@ struct Search {
         TAKE(head, int32_t, scratch, n, "head flags");
         TAKE(gid, int32_t, scratch, n, "group ids");
         size_t tb = cub_bytes;
-        BSH(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tb, key, skey, iota, sidx, (int)n, 0, 64, st), "beam search: sort keys");
+        BSH(rocprim::radix_sort_pairs(cub_tmp, tb, key, skey, iota, sidx, (int)n, 0, 64, st), "beam search: sort keys");
         const unsigned nblk = (unsigned)cdiv(n, 256);
         hipLaunchKernelGGL(heads_kernel, dim3(nblk), dim3(256), 0, st, skey, n, head);
         TN_CHECK_LAUNCH("heads_kernel");
         tb = cub_bytes;
-        BSH(hipcub::DeviceScan::InclusiveSum(cub_tmp, tb, head, gid, (int)n, st), "beam search: scan");
+        BSH(rocprim::inclusive_scan(cub_tmp, tb, head, gid, (size_t)n, rocprim::plus<int32_t>(), st), "beam search: scan");
         hipLaunchKernelGGL(unique_scatter_kernel, dim3(nblk), dim3(256), 0, st, sidx, head, gid, n, inv, first, starts);
         TN_CHECK_LAUNCH("unique_scatter_kernel");
         int32_t g = 0;
@@ -279,7 +284,7 @@ int64_t tn_beam_search_ws_bytes(int64_t Nx, int64_t Ny, int64_t M, int64_t qmax,
         add((Nx + 1) * cap * 4); add(Nx * cap * 4); add(cap * 4); add(cap * nsites * 2); add(cap * 8); add(cap * 8); add(cap * 8);
     }
     add(cand * 4); add(64); add(64);                 // iota, scalars, counter
-    add((int64_t)64 << 20);                          // hipCUB temporary storage (checked against its queries at run time)
+    add((int64_t)64 << 20);                          // rocPRIM temporary storage (checked against its queries at run time)
     // a row: right environments and MPO site of every level, the levels' index scratch, two generations of left environments
     add(256);
     for (int64_t l = 0; l < Nx; ++l) { add(cap * max_env * 8); add(max_w * 8); add(cap * 64 + 4096); }
@@ -340,19 +345,19 @@ int tn_beam_search(int64_t Nx, int64_t Ny, const tn_beam_cell* cells, int64_t M,
     S.cub_bytes = (size_t)64 << 20;
     S.cub_tmp = bump.take<char>((int64_t)S.cub_bytes);
     TN_CHECK_ARG(S.cub_tmp != nullptr, "workspace too small");
-    {   // the temporary storage hipCUB asks for at the largest sizes must fit the slot
+    {   // the temporary storage rocPRIM asks for at the largest sizes must fit the slot
         size_t need = 0, t = 0;
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, (const int64_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int)cand, 0, 64, st);
+        (void)rocprim::radix_sort_pairs(nullptr, t, (const int64_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int)cand, 0, 64, st);
         need = std::max(need, t);
-        (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int)cand, 0, 64, st);
+        (void)rocprim::radix_sort_pairs_desc(nullptr, t, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int)cand, 0, 64, st);
         need = std::max(need, t);
-        (void)hipcub::DeviceScan::InclusiveSum(nullptr, t, (const int32_t*)nullptr, (int32_t*)nullptr, (int)cand, st);
+        (void)rocprim::inclusive_scan(nullptr, t, (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)cand, rocprim::plus<int32_t>(), st);
         need = std::max(need, t);
-        (void)hipcub::DeviceSelect::Flagged(nullptr, t, (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int)cand, st);
+        (void)rocprim::select(nullptr, t, (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int)cand, st);
         need = std::max(need, t);
-        (void)hipcub::DeviceReduce::Max(nullptr, t, (const double*)nullptr, (double*)nullptr, (int)cand, st);
+        (void)rocprim::reduce(nullptr, t, (const double*)nullptr, (double*)nullptr, std::numeric_limits<double>::lowest(), (size_t)cand, rocprim::maximum<double>(), st);
         need = std::max(need, t);
-        TN_CHECK_ARG(need <= S.cub_bytes, "hipCUB temporary storage exceeds its slot");
+        TN_CHECK_ARG(need <= S.cub_bytes, "rocPRIM temporary storage exceeds its slot");
     }
     hipLaunchKernelGGL(iota_kernel, dim3((unsigned)cdiv(cand, 256)), dim3(256), 0, st, S.iota, cand);
     TN_CHECK_LAUNCH("iota_kernel");
@@ -443,7 +448,7 @@ int tn_beam_search(int64_t Nx, int64_t Ny, const tn_beam_cell* cells, int64_t M,
             BS(calc_pn(st, T1, RRs[(size_t)lvl], c.F, c.dmap, c.rmap, b0.pref, b0.sufmat + lvl * cap, b0.vind + nx * cap, b0.vind + (nx + 1) * cap, nb, q,
                        c.nl, c.nu, c.p, c.Dr, c.br, Pn, mP, b0.prob, LP));
             size_t tb = S.cub_bytes;
-            BSH(hipcub::DeviceReduce::Min(S.cub_tmp, tb, mP, S.scal + 4, (int)nb, st), "beam search: minimum");
+            BSH(rocprim::reduce(S.cub_tmp, tb, mP, S.scal + 4, std::numeric_limits<double>::max(), (size_t)nb, rocprim::minimum<double>(), st), "beam search: minimum");
             hipLaunchKernelGGL(scalar_min_kernel, dim3(1), dim3(1), 0, st, S.scal, 1, S.scal + 4);
             TN_CHECK_LAUNCH("scalar_min_kernel");
             // ---- cut-off against the largest candidate (tnac4o.py:455-465)
@@ -451,16 +456,16 @@ int tn_beam_search(int64_t Nx, int64_t Ny, const tn_beam_cell* cells, int64_t M,
             const int32_t* idx = S.iota;
             if (has_cut) {
                 tb = S.cub_bytes;
-                BSH(hipcub::DeviceReduce::Max(S.cub_tmp, tb, LP, S.scal + 2, (int)total, st), "beam search: maximum");
+                BSH(rocprim::reduce(S.cub_tmp, tb, LP, S.scal + 2, std::numeric_limits<double>::lowest(), (size_t)total, rocprim::maximum<double>(), st), "beam search: maximum");
                 TAKE(flag, int32_t, bump, total, "flags");
                 TAKE(rest, double, bump, total, "cut candidates");
                 TAKE(kept, int32_t, bump, total, "kept candidates");
                 hipLaunchKernelGGL(cut_flags_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, LP, total, S.scal + 2, log2_cutoff, flag, rest);
                 TN_CHECK_LAUNCH("cut_flags_kernel");
                 tb = S.cub_bytes;
-                BSH(hipcub::DeviceSelect::Flagged(S.cub_tmp, tb, S.iota, flag, kept, S.counter, (int)total, st), "beam search: compaction");
+                BSH(rocprim::select(S.cub_tmp, tb, S.iota, flag, kept, S.counter, (int)total, st), "beam search: compaction");
                 tb = S.cub_bytes;
-                BSH(hipcub::DeviceReduce::Max(S.cub_tmp, tb, rest, S.scal + 3, (int)total, st), "beam search: maximum of the cut");
+                BSH(rocprim::reduce(S.cub_tmp, tb, rest, S.scal + 3, std::numeric_limits<double>::lowest(), (size_t)total, rocprim::maximum<double>(), st), "beam search: maximum of the cut");
                 int32_t k32 = 0;
                 BS(S.read_i32(S.counter, k32));
                 keep = k32;
@@ -509,11 +514,11 @@ int tn_beam_search(int64_t Nx, int64_t Ny, const tn_beam_cell* cells, int64_t M,
                 TAKE(six, int32_t, bump, ng, "groups by probability");
                 TAKE(selb, int32_t, bump, M, "selection");
                 tb = S.cub_bytes;
-                BSH(hipcub::DeviceRadixSort::SortPairsDescending(S.cub_tmp, tb, lpn, sv, S.iota, six, (int)ng, 0, 64, st), "beam search: sort groups");
+                BSH(rocprim::radix_sort_pairs_desc(S.cub_tmp, tb, lpn, sv, S.iota, six, (int)ng, 0, 64, st), "beam search: sort groups");
                 hipLaunchKernelGGL(scalar_max_kernel, dim3(1), dim3(1), 0, st, S.scal, 0, sv + M);
                 TN_CHECK_LAUNCH("scalar_max_kernel");
                 tb = S.cub_bytes;
-                BSH(hipcub::DeviceRadixSort::SortKeys(S.cub_tmp, tb, six, selb, (int)M, 0, 32, st), "beam search: selection order");
+                BSH(rocprim::radix_sort_keys(S.cub_tmp, tb, six, selb, (int)M, 0, 32, st), "beam search: selection order");
                 sel = selb;
                 nbn = M;
             }

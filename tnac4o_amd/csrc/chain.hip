@@ -949,9 +949,13 @@ using namespace tn;
 
 extern "C" {
 
-// conservative size of the arena for tn_compress_mps: the absorbed sites, the pass-1 output and its copy, the largest site's scratch
+// Size of the arena for tn_compress_mps.  Dmax >= 0: what a call needs when the weighted first pass is accepted (always, so far): the
+// absorbed sites (consumed site by site as the first pass walks over them, their factors are much smaller) plus the attach result, Q, the
+// reflector panels and trailing scratch of the largest site's factorisation, the Gram-recursion temporaries and a fixed reserve for
+// the small tensors -- about 1.6x the measured peak at L = 2048 (2.15 GB).  Dmax < 0: the conservative bound that also covers the plain
+// first pass on the kept input (full-size factors of every site next to the absorbed ones).  A call that runs out of arena fails with
+// -3 before anything is returned; tnac4o_amd.ops then retries once with the conservative size.
 int64_t tn_compress_mps_arena_bytes(int64_t L, const int64_t* site_dims_host, const int64_t* mpo_dims_host, int64_t Dmax) {
-    (void)Dmax;
     if (L < 1 || !site_dims_host) { set_error("tn_compress_mps_arena_bytes: bad arguments"); return -1; }
     int64_t total = 0, biggest = 0, bmax = 1;
     for (int64_t n = 0; n < L; ++n) {
@@ -967,6 +971,7 @@ int64_t tn_compress_mps_arena_bytes(int64_t L, const int64_t* site_dims_host, co
     }
     // absorbed input + pass-1 output (shared with its copy) + second-pass output, attach result + Q + Y + Wq + trailing scratch of the
     // largest QR, the Gram-recursion temporaries (up to b x a site), SVD workspaces; plus a fixed reserve for the small tensors
+    if (Dmax >= 0) return total + 8 * biggest + (int64_t)256 * 1024 * 1024;
     return 3 * total + (10 + 2 * bmax) * biggest + (int64_t)512 * 1024 * 1024;
 }
 

@@ -557,9 +557,20 @@ def compress_mps_native(sites, mpo_sites, hconj, Dmax, tolS, tolV, max_sweeps, g
     flags = (1 if weighted else 0) | (2 if structured else 0) | (4 if lazy else 0)
     ab = arena.data_ptr()
     off = (-ab) % 256
-    check(Lb.tn_compress_mps(L, sp, sd, mp, md, 1 if hconj else 0, int(Dmax), float(tolS), float(tolV), int(max_sweeps), 1 if graduate else 0,
-                             flags, out.data_ptr(), slot, od, C.byref(overlap), disc, sch, pitch, slen, nfs.data_ptr(), nfs_cap, C.byref(ncount),
-                             info, C.c_void_p(ab + off), arena.numel() - off, _stream()))
+    for attempt in range(2):
+        rc = Lb.tn_compress_mps(L, sp, sd, mp, md, 1 if hconj else 0, int(Dmax), float(tolS), float(tolV), int(max_sweeps), 1 if graduate else 0,
+                                flags, out.data_ptr(), slot, od, C.byref(overlap), disc, sch, pitch, slen, nfs.data_ptr(), nfs_cap, C.byref(ncount),
+                                info, C.c_void_p(ab + off), arena.numel() - off, _stream())
+        if rc == -3 and attempt == 0 and arena.numel() < int(Lb.tn_compress_mps_arena_bytes(L, sd, md, -1)):
+            # the typical arena did not do (e.g. the weighted first pass fell back to the plain one): once more with the conservative bound
+            torch.cuda.current_stream().synchronize()
+            arena = None
+            arena = chain_arena(int(Lb.tn_compress_mps_arena_bytes(L, sd, md, -1)))
+            ab = arena.data_ptr()
+            off = (-ab) % 256
+            continue
+        check(rc)
+        break
     A = []
     for n in range(L):
         a, b, c = int(od[3 * n]), int(od[3 * n + 1]), int(od[3 * n + 2])

@@ -669,12 +669,19 @@ class tnac4o:
         if beam_mode == 'device' and recorder is None and trace is None:
             from . import beam
             # one rank on the rotation: the whole loop in the library (tn_beam_search); a beam group shares the site-steps through
-            # torch.distributed and keeps the torch driver
-            if beam_group is None and beam.NATIVE_BEAM:
-                E = beam.search_native(self, M, relative_P_cutoff, min_dEng)
-                if E is not None:
-                    return E
-            return beam.search_device(self, M, relative_P_cutoff, min_dEng, beam_group=beam_group)
+            # torch.distributed and keeps the torch driver.  A site-step at which NO candidate passes the cut-off (every log2 p is -inf or
+            # NaN: a degenerate contraction) is not handled on the device: the search is redone on the host path, which keeps the single
+            # best candidate there like the reference's keep = max(count, 1) (tnac4o.py:460-462).
+            try:
+                if beam_group is None and beam.NATIVE_BEAM:
+                    E = beam.search_native(self, M, relative_P_cutoff, min_dEng)
+                    if E is not None:
+                        return E
+                return beam.search_device(self, M, relative_P_cutoff, min_dEng, beam_group=beam_group)
+            except beam.NoCandidate:
+                if beam_group is not None:
+                    raise
+                self.logger.warning('beam search: no candidate passed the cut-off at some site; redoing the search on the host path')
         canonical = beam_mode != 'numpy'
         Nx, Ny = self.Nx, self.Ny
         vind = np.zeros((1, Nx + 1), dtype=self.indtype)
@@ -732,6 +739,8 @@ class tnac4o:
                     if keep < prob.size:
                         if canonical:                                        # ascending flat index; the largest value cut
                             kept = prob > cutoff
+                            if not kept.any():                               # all -inf / NaN: the single best, as keep = 1 does in the reference
+                                kept[int(np.argmax(prob))] = True
                             order = np.flatnonzero(kept)
                             pd_max = max(pd_max, float(np.max(prob[~kept])))
                         else:
