@@ -112,7 +112,7 @@ def cpu_model():
 
 
 def load_pmc():
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', name)))
             d['file'] = 'profiles/' + name

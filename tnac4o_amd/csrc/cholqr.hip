@@ -255,7 +255,12 @@ enum { CQ_LU_YTOP = 0, CQ_LU_Y1 = 1024, CQ_LU_UINV = 2048, CQ_LU_UT = 3072, CQ_L
 // so that rows below the top block follow as  Y = Q1 Uinv,  W = Y T^T = Q1 UT,  Wq = Y T = Q1 UTq.
 // The elimination runs in wave 0 without barriers: lane r holds row r, the pivot row reaches the other lanes through
 // cross-lane reads (SGPR operands of the updates).  scr: LDS, >= 4 * 32 * 33 + 32 doubles.  Tp: b x b, pitch b.
-__device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, int b, double* lu, double* Tp, double* scr, int tid) {
+// Ss != nullptr (single-launch form): Uinv, UT (and UTq) go to that LDS array (3 x 1024, what cq_post_tile multiplies by) instead of the
+// global buffer, and only a workgroup with write_top (the one that owns the top rows of the panel) stores the top blocks Y1 / Wtop
+// (/ Wqtop) to `lu`: the reconstruction is redundant in every workgroup, its 57 KB need not travel to memory and back 64 times.
+// want_q == false: Y T is not wanted (UTq, Wqtop are skipped).
+__device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, int b, double* lu, double* Tp, double* scr, int tid,
+                                      double* Ss = nullptr, bool write_top = true, bool want_q = true) {
     constexpr int P = 33;
     double* Um = scr;                  // U (zeros below the diagonal), then U S, then T
     double* Lm = scr + 32 * P;         // L (unit lower, zeros above)
@@ -370,21 +375,27 @@ __device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, i
     }
     __syncthreads();
     // wave 0: UT = Uinv T^T, wave 1: UTq = Uinv T, wave 2: Wtop = L T^T, wave 3: Wqtop = L T
-    mm((wave < 2) ? Ui : Lm, Um, (wave & 1) == 0, acc);
-    double* dst = lu + (wave == 0 ? CQ_LU_UT : wave == 1 ? CQ_LU_UTQ : wave == 2 ? CQ_LU_WTOP : CQ_LU_WQTOP);
+    const bool q_wave = (wave & 1) == 1, top_wave = wave >= 2;
+    const bool skip = (q_wave && !want_q) || (top_wave && !write_top);       // (wave-uniform)
+    if (!skip) {
+        mm((wave < 2) ? Ui : Lm, Um, (wave & 1) == 0, acc);
+        double* dst = (Ss && wave < 2) ? Ss + (wave == 0 ? 1024 : 2048)
+                                       : lu + (wave == 0 ? CQ_LU_UT : wave == 1 ? CQ_LU_UTQ : wave == 2 ? CQ_LU_WTOP : CQ_LU_WQTOP);
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+            for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = ti * 16 + lk + 4 * q, j = tj * 16 + li_;
-                dst[i * 32 + j] = (i < b && j < b) ? acc[ti][tj][q] : 0.0;
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const int i = ti * 16 + lk + 4 * q, j = tj * 16 + li_;
+                    dst[i * 32 + j] = (i < b && j < b) ? acc[ti][tj][q] : 0.0;
+                }
+    }
     for (int e = tid; e < 1024; e += 256) {
         const int i = e >> 5, j = e & 31;
-        lu[CQ_LU_UINV + e] = (i < b && j < b) ? Ui[i * P + j] : 0.0;
-        lu[CQ_LU_Y1 + e] = Lm[i * P + j];
+        const double ui = (i < b && j < b) ? Ui[i * P + j] : 0.0;
+        if (Ss) Ss[e] = ui; else lu[CQ_LU_UINV + e] = ui;
+        if (write_top) lu[CQ_LU_Y1 + e] = Lm[i * P + j];
     }
     __syncthreads();
 }
@@ -772,7 +783,8 @@ __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_
 // One tile of <= 256 rows on the matrix cores (wave w owns rows 64w .. 64w+63); tile: LDS 256 x CQ_P, Ss: LDS 3 x 1024.
 // tile_ready: the orthonormal tile is in `tile` already (single-launch form), otherwise it is fetched from Y.
 __device__ __forceinline__ void cq_post_tile(int blk, int nblk, int64_t nrows, int b, double* Y, int64_t rs, int64_t cs, double* W, int64_t wrs,
-                                             int64_t wcs, double* Wq, const double* lu, double* tile, double* Ss, int tid, bool tile_ready = false) {
+                                             int64_t wcs, double* Wq, const double* lu, double* tile, double* Ss, int tid, bool tile_ready = false,
+                                             bool ss_ready = false) {
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     int64_t r0;
     int nr;
@@ -780,12 +792,14 @@ __device__ __forceinline__ void cq_post_tile(int blk, int nblk, int64_t nrows, i
     const bool xrow = (cs == 1);
     {
         double sv[3][4], xv[32];
+        if (!ss_ready) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int e = tid + 256 * t;
-            sv[0][t] = lu[CQ_LU_UINV + e];
-            sv[1][t] = lu[CQ_LU_UT + e];
-            sv[2][t] = lu[CQ_LU_UTQ + e];
+            for (int t = 0; t < 4; ++t) {
+                const int e = tid + 256 * t;
+                sv[0][t] = lu[CQ_LU_UINV + e];
+                sv[1][t] = lu[CQ_LU_UT + e];
+                sv[2][t] = lu[CQ_LU_UTQ + e];
+            }
         }
         if (!tile_ready) {
 #pragma unroll
@@ -795,10 +809,12 @@ __device__ __forceinline__ void cq_post_tile(int blk, int nblk, int64_t nrows, i
                 xv[u] = (i < nr && j < b) ? Y[(r0 + i) * rs + j * cs] : 0.0;
             }
         }
+        if (!ss_ready) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int e = tid + 256 * t;
-            Ss[e] = sv[0][t]; Ss[1024 + e] = sv[1][t]; Ss[2048 + e] = sv[2][t];
+            for (int t = 0; t < 4; ++t) {
+                const int e = tid + 256 * t;
+                Ss[e] = sv[0][t]; Ss[1024 + e] = sv[1][t]; Ss[2048 + e] = sv[2][t];
+            }
         }
         if (!tile_ready) {
 #pragma unroll
@@ -1228,10 +1244,12 @@ __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t 
                 cq_store_tile(T, Y, rs, cs, r0, nr, b, tid);
             } else {
                 double* lu = lu_all + (int64_t)blk * CQ_LU_DOUBLES;
-                cq_lu(topblk + (tlast & 1) * 1024, true, b, lu, writer ? Tp : nullptr, scr, tid);
+                // (the Gram matrix / factor in GR are done with: the three S matrices of the post step go there directly; the top blocks,
+                //  which only the workgroup with the first rows stores, travel through its own slice of lu_all)
+                cq_lu(topblk + (tlast & 1) * 1024, true, b, lu, writer ? Tp : nullptr, scr, tid, GR, r0 < b, Wq != nullptr);
                 __syncthreads();                             // (waits for this workgroup's stores to lu as well)
                 FQ_CLK(9);
-                cq_post_tile(blk, nblk, nrows, b, Y, rs, cs, W, wrs, wcs, Wq, lu, T, GR, tid, true);
+                cq_post_tile(blk, nblk, nrows, b, Y, rs, cs, W, wrs, wcs, Wq, lu, T, GR, tid, true, true);
                 FQ_CLK(10);
             }
         } else if (alive && dec == 2 && writer) {

@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get('ROUND', 'r03')
+ROUND = os.environ.get('ROUND', 'r04')
 BASE = os.path.join(ROOT, 'gpurun_out', 'prof_' + ROUND)
 
 
@@ -76,7 +76,7 @@ for p in range(16):
 fam['panel step (cq_fused / cq_gram / cq_pass / cq_post)'] = {'probe_shape': 'tn_qr 16384 x 1024 (32 panels, %s) + tn_qr 4096 x 512 (16 panels, single-launch form)' % ('six-launch chain' if six_launch else 'single-launch form: 64 workgroups'), 'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
                                    'traffic_bytes_per_launch': (fb + wb) / n, 'algorithmic_bytes_per_launch': alg / n,
                                    'traffic_over_algorithmic': (fb + wb) / alg}
-for name, pat in (('eig_small_kernel', 'eig_small'), ('absorb_kernel', 'absorb_mfma_kernel')):
+for name, pat in (('eig_small_kernel', 'eig_small'), ('absorb_kernel', 'absorb_mfma_kernel'), ('sq_kernel (one-launch factorisation)', 'sq_kernel')):
     ks = [k for k in kern if pat in k]
     if ks:
         k = ks[0]
@@ -98,6 +98,11 @@ if times.get('svd_trunc_320x1024_ms'):
     svd['GBps'] = svd_bytes / (times['svd_trunc_320x1024_ms'] * 1e-3) / 1e9
     svd['frac_of_hbm_peak'] = svd['GBps'] / 8000.0
 whole['tn_svd_trunc_320x1024'] = svd
+# sixteen one-launch factorisations 1024 x 64 (segment 6 of the probe): in 8 B, Q out 8 B per element + R
+sq_bytes = segment_bytes(6) / 16.0
+sq_alg = 8.0 * (2 * 1024 * 64 + 64 * 64)
+whole['tn_qr_1024x64_one_launch'] = {'hbm_bytes': sq_bytes, 'compulsory_bytes': sq_alg, 'traffic_over_compulsory': sq_bytes / sq_alg if sq_alg else None,
+                                     'us_unprofiled': times.get('qr_1024x64_one_launch_us')}
 
 mfma = {}
 for k in kern:

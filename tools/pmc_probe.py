@@ -4,7 +4,7 @@ of a centre matrix as the sweep produces them (the leading 320 rows of the trian
 i.e. what the rank-revealing QR of a truncating pass hands over: eig_small + pair GEMMs).  Inputs are prepared with torch
 (rocSOLVER / rocBLAS kernels, not counted).  Run under rocprofv3 --pmc in separate passes (tools/collect_profiles.sh);
 tools/pmc_summary.py aggregates the counter CSV per kernel and per SEGMENT: a torch bitwise_xor launch (used nowhere else) marks
-the boundaries -- segment 1 = the 16384 x 1024 QR, 2 = the 4096 x 512 QR, 4 = the truncated SVD -- so that whole-call traffic is the
+the boundaries -- segment 1 = the 16384 x 1024 QR, 2 = the 4096 x 512 QR, 4 = the truncated SVD, 6 = sixteen one-launch 1024 x 64 QRs -- so that whole-call traffic is the
 sum over everything launched inside the call.  Prints the un-profiled timings of the QR and the SVD."""
 import json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
@@ -49,6 +49,18 @@ out = ops.svd_trunc(C, 256, 1e-17)
 torch.cuda.synchronize()
 t_svd = time.perf_counter() - t0
 marker()
+# sixteen one-launch factorisations of the 1024 x 64 class (csrc/smallqr.hip; segment 5)
+X3 = torch.randn(1024, 64, dtype=torch.float64, device='cuda')
+Q3 = torch.empty((1024, 64), dtype=torch.float64, device='cuda'); R3 = torch.empty((64, 64), dtype=torch.float64, device='cuda')
+ops.qr_into(X3, Q3, R3, overwrite=True)
+torch.cuda.synchronize()
+marker()
+t0 = time.perf_counter()
+for _ in range(16):
+    ops.qr_into(X3, Q3, R3, overwrite=True)
+torch.cuda.synchronize()
+t_sq = (time.perf_counter() - t0) / 16
+marker()
 print('done', float(T.sum()), float(Z.sum()), float(Rr.abs().sum()), out[1][:2])
 print('PROBE_TIMES ' + json.dumps({'svd_trunc_320x1024_ms': 1e3 * t_svd, 'svd_sweeps': out[5]['sweeps'], 'svd_keep': out[3],
-                                   'svd_preconditioned': bool(out[5].get('preconditioned')), 'qr_16384x1024_ms': 1e3 * t_qr}))
+                                   'svd_preconditioned': bool(out[5].get('preconditioned')), 'qr_16384x1024_ms': 1e3 * t_qr, 'qr_1024x64_one_launch_us': 1e6 * t_sq}))
