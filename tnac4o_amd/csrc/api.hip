@@ -121,6 +121,7 @@ int tn_stream_create_masked(const uint32_t* mask_host, int nwords, void** stream
     return 0;
 }
 int tn_stream_destroy(void* stream) {
+    fused_stream_released((hipStream_t)stream);
     const hipError_t e = hipStreamDestroy((hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "hipStreamDestroy");
 }

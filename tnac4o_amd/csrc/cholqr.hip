@@ -1321,11 +1321,15 @@ static bool cq_fused_enabled() {
 // statistics slot of a stream (first come, first served; the streams beyond CQ_STAT_SLOTS share the last slot)
 static std::mutex cq_slot_mu;
 static std::map<hipStream_t, int> cq_slot_of;
+static std::vector<int> cq_slot_free;                               // slots of destroyed streams (tn_stream_destroy), handed out again first
+static int cq_slot_next = 0;
 static int cq_stat_slot(hipStream_t st) {
     std::lock_guard<std::mutex> lk(cq_slot_mu);
     auto it = cq_slot_of.find(st);
     if (it != cq_slot_of.end()) return it->second;
-    const int s = (int)cq_slot_of.size() < CQ_STAT_SLOTS ? (int)cq_slot_of.size() : CQ_STAT_SLOTS;
+    int s = CQ_STAT_SLOTS;
+    if (!cq_slot_free.empty()) { s = cq_slot_free.back(); cq_slot_free.pop_back(); }
+    else if (cq_slot_next < CQ_STAT_SLOTS) s = cq_slot_next++;
     cq_slot_of.emplace(st, s);
     return s;
 }
@@ -1370,6 +1374,18 @@ static std::map<hipStream_t, bool> cq_stream_off;                  // (guarded b
 void fused_forms_disable(hipStream_t st) {
     std::lock_guard<std::mutex> lk(cq_slot_mu);
     cq_stream_off[st] = true;
+}
+static void cq_dirty_mark(int slot);
+// tn_stream_destroy: the stream's slot (statistics, panel state, admission bookkeeping) goes back to the pool, so that the count of
+// live streams the admission of tall panels works with stays a count of LIVE streams
+void fused_stream_released(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(cq_slot_mu);
+    cq_stream_off.erase(st);
+    auto it = cq_slot_of.find(st);
+    if (it == cq_slot_of.end()) return;
+    const int slot = it->second;
+    cq_slot_of.erase(it);
+    if (slot < CQ_STAT_SLOTS) { cq_slot_free.push_back(slot); cq_dirty_mark(slot); }
 }
 static bool cq_stream_is_off(hipStream_t st) {
     std::lock_guard<std::mutex> lk(cq_slot_mu);
@@ -1421,7 +1437,6 @@ static void cq_big_launched(hipStream_t st, int slot) {
 // defer the check to the end of their call (FusedDeferCheck).
 int smallqr_stats(hipStream_t st, unsigned long long* out4, int reset);
 int smallqr_reset_state(hipStream_t st);
-static void cq_dirty_mark(int slot);
 static thread_local long cq_fused_launches = 0;                    // launches with in-kernel barriers enqueued by this thread since its last check
 static thread_local int cq_defer_depth = 0;
 void fused_note_launch() { ++cq_fused_launches; }

@@ -182,6 +182,7 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
 // launches with in-kernel barriers (cq_fused_kernel, sq_kernel): co-residency budget and time-outs, see cholqr.hip
 bool fused_forms_allowed(hipStream_t st, int nwg);
 void fused_forms_disable(hipStream_t st);
+void fused_stream_released(hipStream_t st);
 void fused_note_launch();
 bool fused_check_needed();
 bool fused_check_deferred();

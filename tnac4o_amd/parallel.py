@@ -71,6 +71,12 @@ def run_concurrent(fns):
     # 8 or 16 queues 2.90 s per step; the round-2 form with fresh pool streams on every call happened to dodge the collision until
     # the pool wrapped, every 8th call).  tnac4o_amd/__init__.py therefore asks for 8 queues before the runtime starts.
     from . import ops
+    import tnac4o_amd as _pkg
+    if _pkg.HIP_STARTED_BEFORE_IMPORT and n > 3 and not getattr(run_concurrent, '_warned', False):
+        run_concurrent._warned = True
+        import warnings
+        warnings.warn('tnac4o_amd was imported after the HIP runtime had started with its default of 4 hardware queues: %d interleaved chains '
+                      'will share queues and run ~1.5x slower; export GPU_MAX_HW_QUEUES=8 (or import tnac4o_amd first)' % n)
     key = (torch.cuda.current_device(), n)
     streams = _CHAIN_STREAMS.get(key)
     if streams is None:
