@@ -99,7 +99,10 @@ def test_absorb_golden(ops):
 
 
 @pytest.mark.parametrize('dims', [(1, 1, 1, 1, 1, 1, 1), (1, 16, 1, 1, 16, 16, 16), (5, 8, 3, 2, 8, 4, 6), (16, 16, 16, 16, 16, 16, 16),
-                                  (64, 16, 64, 16, 16, 16, 16), (7, 4, 130, 1, 4, 16, 2)])
+                                  (64, 16, 64, 16, 16, 16, 16), (7, 4, 130, 1, 4, 16, 2),
+                                  # edge sites of a sweep: any MPS bond (padded to 16-wide tiles in LDS by the matrix-core kernel)
+                                  (13, 16, 23, 16, 16, 16, 16), (45, 16, 58, 16, 16, 16, 16), (60, 16, 1, 16, 16, 16, 16), (1, 16, 13, 1, 16, 16, 16),
+                                  (23, 16, 112, 16, 16, 16, 16)])
 @pytest.mark.parametrize('hconj', [True, False])
 def test_absorb_vs_oracle(ops, dims, hconj):
     Dl, p, Dr, ba, po, bb, pi = dims

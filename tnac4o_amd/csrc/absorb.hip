@@ -84,12 +84,17 @@ __global__ __launch_bounds__(256) void absorb_mfma_kernel(const double* __restri
     const double* __restrict__ W = W_ + (int64_t)blockIdx.y * bsW;
     double* __restrict__ out = out_ + (int64_t)blockIdx.y * bsO;
     const int pc = pold, pnew = HCONJ ? pi : po;
-    double* sA = lds;                      // [pc][Dr]
-    double* sW = lds + (int64_t)pc * Dr;   // [pc][pnew][bb]
+    // the right bond of the MPS site is padded to whole 16-wide tiles in LDS (zeros): edge sites have any Dr (13, 23, 45, 58 ...)
+    constexpr int DrP = (HCONJ ? TS : TF) * 16;
+    double* sA = lds;                      // [pc][DrP]
+    double* sW = lds + (int64_t)pc * DrP;  // [pc][pnew][bb]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dl = HCONJ ? blockIdx.x / ba : blockIdx.x % Dl;
     const int a = HCONJ ? blockIdx.x % ba : blockIdx.x / Dl;
-    for (int e = tid; e < pc * Dr; e += 256) sA[e] = A[(int64_t)dl * pold * Dr + e];
+    for (int e = tid; e < pc * DrP; e += 256) {
+        const int c = e / DrP, dr = e % DrP;
+        sA[e] = dr < Dr ? A[((int64_t)dl * pold + c) * Dr + dr] : 0.0;
+    }
     for (int e = tid; e < pc * pnew * bb; e += 256) {
         const int b = e % bb, q = (e / bb) % pnew, c = e / (bb * pnew);
         const int o = HCONJ ? c : q, i = HCONJ ? q : c;
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(256) void absorb_mfma_kernel(const double* __restri
 #pragma unroll
     for (int t = 0; t < TA; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) fa[t][ks] = sA[(ks * 4 + lk) * Dr + t * 16 + li];
+        for (int ks = 0; ks < KS; ++ks) fa[t][ks] = sA[(ks * 4 + lk) * DrP + t * 16 + li];
     for (int q = wave; q < pnew; q += 4) {
         constexpr int TWn = HCONJ ? TF : TS;
         double fw[TWn][KS];
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void absorb_mfma_kernel(const double* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int slow = ts * 16 + lk + 4 * r, fast = tf * 16 + li;
-                    oblk[(int64_t)q * ncol + (int64_t)slow * fastdim + fast] = acc[r];
+                    if ((HCONJ ? slow : fast) < Dr) oblk[(int64_t)q * ncol + (int64_t)slow * fastdim + fast] = acc[r];
                 }
             }
     }
@@ -138,8 +143,9 @@ template <bool HCONJ>
 static bool launch_absorb_mfma(hipStream_t st, dim3 grid, size_t lds, const double* A, const double* W, double* out, int Dl, int pold,
                                int Dr, int ba, int po, int bb, int pi, int64_t bsA, int64_t bsW, int64_t bsO) {
     const int slow = HCONJ ? Dr : bb, fast = HCONJ ? bb : Dr;
-    if (pold % 4 || slow % 16 || fast % 16) return false;
-    const int ts = slow / 16, tf = fast / 16, ks = pold / 4;
+    if (pold % 4 || (HCONJ ? bb : bb) % 16) return false;              // the MPO bond must be whole tiles; the MPS bond Dr is padded in LDS
+    const int ts = (slow + 15) / 16, tf = (fast + 15) / 16, ks = pold / 4;
+    lds = ((size_t)pold * (HCONJ ? ts : tf) * 16 + (size_t)pold * (HCONJ ? pi : po) * bb) * 8;
 #define TN_ABS(TS_, TF_, KS_)                                                                                             \
     if (ts == TS_ && tf == TF_ && ks == KS_) {                                                                            \
         if (lds > 64 * 1024)                                                                                              \
@@ -151,7 +157,7 @@ static bool launch_absorb_mfma(hipStream_t st, dim3 grid, size_t lds, const doub
     }
     // (slow tiles, fast tiles, k steps) of the configurations on the benchmark path: chi in {16,32,64,128}, b = p in {8,16}
     TN_ABS(4, 1, 4) TN_ABS(1, 4, 4) TN_ABS(2, 1, 4) TN_ABS(1, 2, 4) TN_ABS(1, 1, 4) TN_ABS(8, 1, 4) TN_ABS(1, 8, 4)
-    TN_ABS(3, 1, 4) TN_ABS(1, 3, 4)
+    TN_ABS(3, 1, 4) TN_ABS(1, 3, 4) TN_ABS(5, 1, 4) TN_ABS(1, 5, 4) TN_ABS(6, 1, 4) TN_ABS(1, 6, 4) TN_ABS(7, 1, 4) TN_ABS(1, 7, 4)
 #undef TN_ABS
     return false;
 }

@@ -1114,11 +1114,11 @@ __device__ __forceinline__ void cq_tail_fused(const double* part, const int* bex
     __syncthreads();
 }
 
-// Sliced reduction of the published partial Gram matrices (launches of more than CQ_SLICE_FROM workgroups): workgroup w adds slice w of
+// Sliced reduction of the published partial Gram matrices (launches of more than CQ_SLICE_FROM workgroups; an in-kernel barrier costs 1-2 us): workgroup w adds slice w of
 // all nblk partials -- block order, the same fused multiply-adds with the same power-of-two weights as the full reduction, hence the
 // same bits -- and publishes its slice of the sum; after one more barrier everybody fetches the 768 sums.  nblk^2 x 6 KB of agent-scope
 // loads per round become 2 x nblk x 6 KB.  Returns the exponent the weights refer to (pass 0).
-constexpr int CQ_SLICE_FROM = 16;
+constexpr int CQ_SLICE_FROM = 4;
 __device__ __forceinline__ int cq_slice_reduce(const double* part, const int* bexp, int nblk, int blk, double* gsum, int tid) {
     const int lane = tid & 63;
     int emax = 0;
@@ -1129,7 +1129,7 @@ __device__ __forceinline__ int cq_slice_reduce(const double* part, const int* be
         for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(e, o, 64); e = y > e ? y : e; }
         emax = e;
     }
-    const int sl = (CQ_PART + nblk - 1) / nblk;            // <= 48 entries per workgroup from 16 workgroups on
+    const int sl = (CQ_PART + nblk - 1) / nblk;            // <= 154 entries per workgroup
     const int e0 = blk * sl + tid;
     if (tid < sl && e0 < CQ_PART) {
         double acc = 0.0;
