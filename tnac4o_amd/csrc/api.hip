@@ -192,6 +192,15 @@ int tn_panel_orth(const double* X, int64_t rs, int64_t cs, int64_t nrows, int b,
     if (rc) return rc;
     int fbase = 0;
     if ((rc = cholqr_orthonormalize(ST, X, rs, cs, Y, yrs, ycs, nrows, b, ws, ws_bytes, 0x5DEECE66DULL, &fbase))) return rc;
+    if (fused_check_needed() && !fused_check_deferred()) {      // the single-launch form may have given up at a barrier: never hand NaN back
+        int gave_up = 0;
+        if ((rc = fused_timeouts(ST, &gave_up))) return rc;
+        if (gave_up > 0) {                                      // X is untouched: once more, through the six-launch chain the stream now takes
+            if ((rc = cholqr_reset(ST, ws))) return rc;
+            fbase = 0;
+            if ((rc = cholqr_orthonormalize(ST, X, rs, cs, Y, yrs, ycs, nrows, b, ws, ws_bytes, 0x5DEECE66DULL, &fbase))) return rc;
+        }
+    }
     if (state9_host && dev_host) return cholqr_debug_state(ST, ws, state9_host, dev_host);
     return 0;
 }

@@ -58,14 +58,33 @@ int qr_batched(hipStream_t st, double* A, int64_t rs, int64_t cs, int64_t m, int
             if ((e = hipStreamWaitEvent((hipStream_t)side[s], fj.fork, 0)) != hipSuccess) return hip_fail(e, "wait fork");
     }
     int rc = 0;
-    for (int64_t i = 0; i < batch && rc == 0; ++i) {
-        hipStream_t si = used > 0 ? (hipStream_t)side[i % used] : st;
-        rc = qr_factor(si, A + i * bsA, rs, cs, m, n, Q + i * bsQ, qrs, qcs, R + i * bsR, rrs, rcs, nb, (char*)ws + i * wsi, wsi, rank_tol,
-                       keff_host ? keff_host + i : nullptr, nullptr);
+    {
+        // the items' own checks for launches that gave up at an in-kernel barrier would each synchronise its stream and so undo the
+        // concurrency this entry point exists for: they are deferred, and every stream that was used is asked once after the join
+        FusedDeferCheck defer;
+        for (int64_t i = 0; i < batch && rc == 0; ++i) {
+            hipStream_t si = used > 0 ? (hipStream_t)side[i % used] : st;
+            rc = qr_factor(si, A + i * bsA, rs, cs, m, n, Q + i * bsQ, qrs, qcs, R + i * bsR, rrs, rcs, nb, (char*)ws + i * wsi, wsi, rank_tol,
+                           keff_host ? keff_host + i : nullptr, nullptr);
+        }
     }
     for (int s = 0; s < used; ++s) {      // join even after an error so that the caller's stream stays ordered
         if ((e = hipEventRecord(fj.done[s], (hipStream_t)side[s])) != hipSuccess) return hip_fail(e, "record join");
         if ((e = hipStreamWaitEvent(st, fj.done[s], 0)) != hipSuccess) return hip_fail(e, "wait join");
+    }
+    if (fused_check_needed()) {
+        int total = 0;
+        for (int s = 0; s < (used > 0 ? used : 1); ++s) {
+            int gave_up = 0;
+            const int rc2 = fused_timeouts(used > 0 ? (hipStream_t)side[s] : st, &gave_up);
+            if (rc2) return rc2;
+            total += gave_up;
+        }
+        if (total > 0) {
+            set_error("tn_qr_batched: %d launch(es) with in-kernel barriers gave up; the results are invalid and the inputs may have been "
+                      "overwritten -- rerun from copies (these streams now take the multi-launch forms)", total);
+            return -7;
+        }
     }
     return rc;
 }
