@@ -46,6 +46,8 @@ expect_neg(L.tn_panel_orth(P, 4, 1, 64, 4, P, 4, 1, 0, None, None, P, 16, None),
 expect_neg(L.tn_panel_orth(P, 40, 1, 64, 40, C.cast(C.byref(host, 8), C.c_void_p), 40, 1, 1, None, None, P, 1 << 22, None), 'tn_panel_orth width')
 expect_neg(L.tn_panel_stats(None, 0), 'tn_panel_stats null')
 expect_neg(L.tn_panel_stats_stream(None, 0, None), 'tn_panel_stats_stream null')
+expect_neg(L.tn_smallqr_stats(None, 0, None), 'tn_smallqr_stats null')
+expect_neg(L.tn_fused_timeouts(None, None), 'tn_fused_timeouts null')
 desc = (C.c_int64 * 10)(C.cast(host, C.c_void_p).value, 64, 1, 8, 65, C.cast(host, C.c_void_p).value, 64, 1, 9, 8)
 expect_neg(L.tn_svdvals_small_batched(P, -1, desc, P, None), 'svdvals_small_batched batch')
 expect_neg(L.tn_svdvals_small_batched(P, 1, desc, P, None), 'svdvals_small_batched length')
