@@ -258,6 +258,68 @@ def test_svd_shapes(ops, shape):
     check_svd(ops, T, max(1, min(shape) // 2), 1e-16)
 
 
+def _svd_case(k, n, seed, decay=0.25):
+    g = np.random.default_rng(seed)
+    r = min(k, n)
+    U, _ = np.linalg.qr(g.standard_normal((k, r)))
+    V, _ = np.linalg.qr(g.standard_normal((n, r)))
+    A = (U * np.exp(-decay * np.arange(r))) @ V.T
+    return np.triu(A) if seed % 2 else A
+
+
+@pytest.mark.parametrize('shape', [(128, 200), (192, 600), (192, 900), (100, 100), (65, 65), (64, 700), (130, 70), (256, 500), (70, 3000)])
+def test_svd_rounds_in_one_launch_bit_identical_to_separate_launches(ops, shape, monkeypatch):
+    """All Jacobi rounds of a truncated SVD in ONE launch (svdl_kernel: the vectors resident in LDS, grid barriers between the
+    phases) against three launches per round and a read-back per sweep (TN_SVD_FUSED=0): same arithmetic in the same order -- U, S,
+    V^T, the kept rank, the discarded weight and the number of sweeps agree bit for bit.  (Shapes with more than 192 live vectors or
+    more chunks than the co-residency budget holds stay on the separate launches in both runs.)"""
+    for seed in (1, 2):
+        T = dev(_svd_case(shape[0], shape[1], seed))
+        outs = []
+        for mode in ('0', '1'):
+            monkeypatch.setenv('TN_SVD_FUSED', mode)
+            outs.append(ops.svd_trunc(T, 64, 1e-8))
+        (U0, S0, V0, k0, d0, i0), (U1, S1, V1, k1, d1, i1) = outs
+        assert k0 == k1 and d0 == d1 and i0['sweeps'] == i1['sweeps']
+        assert torch.equal(U0, U1) and torch.equal(S0, S1) and torch.equal(V0, V1)
+        Sr = np.linalg.svd(T.cpu().numpy(), compute_uv=False)
+        np.testing.assert_allclose(S1.cpu().numpy(), Sr[:k1], rtol=0, atol=1e-14 * Sr[0])
+
+
+SVD_TIMEOUT_CHILD = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np, torch
+from tnac4o_amd import ops
+from test_gpu_kernels import _svd_case
+ok = True
+for (k, n) in ((128, 300), (192, 600)):
+    T = torch.as_tensor(_svd_case(k, n, 1)).cuda()
+    os.environ['TN_SVD_FUSED'] = '0'
+    U0, S0, V0, k0, d0, i0 = ops.svd_trunc(T, 64, 1e-8)
+    os.environ['TN_SVD_FUSED'] = '1'
+    st = torch.cuda.Stream()              # a fresh stream per case: a stream that has given up stays off the single-launch forms
+    with torch.cuda.stream(st):
+        U1, S1, V1, k1, d1, i1 = ops.svd_trunc(T, 64, 1e-8)
+    st.synchronize()
+    ok &= bool(k0 == k1 and d0 == d1 and torch.equal(U0, U1) and torch.equal(S0, S1) and torch.equal(V0, V1))
+    ok &= bool(torch.isfinite(U1).all() and torch.isfinite(S1).all() and torch.isfinite(V1).all())
+print('CHILD_OK' if ok else 'CHILD_FAIL')
+'''
+
+
+def test_svd_one_launch_rounds_that_give_up_are_redone_as_separate_launches():
+    """TN_PANEL_SPIN_LIMIT=0: every barrier of svdl_kernel gives up at once.  The launch reports it in its status word, tn_svd_trunc
+    sets the vectors up again and runs the rounds as separate launches: the result is the one of TN_SVD_FUSED=0 bit for bit, the
+    library says so on stderr, nothing non-finite comes back."""
+    out = _run_child(SVD_TIMEOUT_CHILD, {'TN_PANEL_SPIN_LIMIT': '0'})
+    assert 'CHILD_OK' in out, out
+    assert out.count('[libtnpeps] the one-launch Jacobi rounds') == 2, out
+    out = _run_child(SVD_TIMEOUT_CHILD, {})
+    assert 'CHILD_OK' in out and '[libtnpeps]' not in out, out
+
+
 def test_svd_triangular_lowrank(ops):
     # the shape the sweep produces: an upper-triangular factor of a numerically low-rank matrix
     rng = np.random.default_rng(21)

@@ -301,6 +301,7 @@ __device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, i
         }
     }
     __syncthreads();
+    FQ_CLK(11);
     // U^-1 and L^-1 by substitution, one column per lane with the column in registers (wave 0: U^-1, wave 1: L^-1)
     if (wave == 0 && lane < 32) {
         const int j = lane;
@@ -332,6 +333,7 @@ __device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, i
         for (int i = 0; i < 32; ++i) Li[i * P + j] = x[i];
     }
     __syncthreads();
+    FQ_CLK(12);
     for (int e = tid; e < 1024; e += 256) Um[(e >> 5) * P + (e & 31)] *= sg[e & 31];      // U S, in place
     __syncthreads();
     const int li_ = lane & 15, lk = lane >> 4;
@@ -374,6 +376,7 @@ __device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, i
                 }
     }
     __syncthreads();
+    FQ_CLK(13);
     // wave 0: UT = Uinv T^T, wave 1: UTq = Uinv T, wave 2: Wtop = L T^T, wave 3: Wqtop = L T
     const bool q_wave = (wave & 1) == 1, top_wave = wave >= 2;
     const bool skip = (q_wave && !want_q) || (top_wave && !write_top);       // (wave-uniform)

@@ -117,6 +117,8 @@ struct GemmExtra {
     bool raw_partials = false;
     int* splitk_used = nullptr;
 };
+// how gemm_ex cuts K for force_splitk = s: returns the number of splits actually used, *kchunk = elements per split
+int gemm_forced_split(int64_t K, int s, int64_t* kchunk);
 int gemm_ex(hipStream_t st, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t rsa, int64_t csa,
             const double* B, int64_t rsb, int64_t csb, double beta, double* C, int64_t rsc, int64_t csc, int64_t batch,
             int64_t bsa, int64_t bsb, int64_t bsc, double* ws, int64_t ws_bytes, const GemmExtra* x);
@@ -154,6 +156,15 @@ int rows_times_small(hipStream_t st, double* X, int64_t rs, int64_t cs, int64_t 
 
 // Out(v, c) = sum_u S[u][v] * In(u, c)  for the nvec vectors of each group (same addressing as gram_partial),
 // c < L; in place when Out == In.  If nrot != nullptr groups with nrot[g]==0 are skipped.
+// All Jacobi rounds of a block-pair SVD (jacobi_core, svd.hip) in one launch (small.hip).  norms: nvp + 4 doubles.
+struct SvdRoundsJob {
+    double* X; int64_t pitch, L; int nvp, w;
+    const int* pairs; int ng, nr, nchunk;
+    double* part; int64_t part_bytes; double* Js; int* nrot; double* maxoff;
+    double relevant2, last_tol; int inner_first, inner_later;
+    double* norms;
+};
+int svd_rounds_fused(hipStream_t st, const SvdRoundsJob& j);       // 0 launched, 1 not taken
 int small_t_times_vecs(hipStream_t st, const double* S, double* X, int64_t vs, int64_t es, int64_t L, int nvec, int w,
                        const int* pairs, int ngroups, const int* nrot);
 

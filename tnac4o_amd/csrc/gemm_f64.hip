@@ -305,6 +305,11 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int64_t batch) {
     return p;
 }
 
+int gemm_forced_split(int64_t K, int s, int64_t* kchunk) {
+    *kchunk = s > 1 ? align_up(cdiv(K, s), 2 * BK) : (K > 0 ? align_up(K, 2 * BK) : 2 * BK);      // whole steps of either K depth
+    return s > 1 ? (int)cdiv(K, *kchunk) : s;
+}
+
 int64_t gemm_ws_bytes(int64_t M, int64_t N, int64_t K, int64_t batch) {
     const GemmPlan p = plan_gemm(M, N, K, batch);
     return p.s > 1 ? (int64_t)p.s * batch * M * N * 8 : 0;
@@ -414,9 +419,7 @@ static int gemm_ex_impl(hipStream_t st, int64_t M, int64_t N, int64_t K, double 
     }
     const bool raw = x && x->raw_partials;
     TN_CHECK_ARG(!raw || ws != nullptr, "raw partials need a workspace");
-    g.splitk = s;
-    g.kchunk = s > 1 ? align_up(cdiv(K, s), 2 * BK) : (K > 0 ? align_up(K, 2 * BK) : 2 * BK);      // whole steps of either K depth
-    if (s > 1) g.splitk = s = (int)cdiv(K, g.kchunk);
+    g.splitk = s = gemm_forced_split(K, s, &g.kchunk);
     if (raw && s == 1) g.splitk = -1;          // single "partial": still written to ws (handled below)
     if (x && x->splitk_used) *x->splitk_used = s;
     if (batch * s > 65535) {      // grid.z limit: run the batch in slices (same stream, so the split-K scratch can be reused)

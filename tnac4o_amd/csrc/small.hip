@@ -5,6 +5,8 @@
 //   small_t_times_vecs  vecs <- S^T . vecs            (small matrix times a bundle of long vectors, in place)
 // All are HBM/LDS-streaming VALU kernels; the flops that matter live in gemm_f64.hip.
 #include <stdlib.h>
+#include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -58,8 +60,10 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const double* __restr
             if (j0 + j < nvec) out[i * nvec + j0 + j] = acc[j];
 }
 
+// chunks of 64 elements (what a workgroup of the LDS-resident SVD kernel holds of every vector: the partial sums of all forms
+// then add up in the same order), fewer and longer ones beyond 4096
 int gram_nchunk(int64_t L) {
-    int64_t n = L / 128;
+    int64_t n = (L + 63) / 64;
     if (n < 1) n = 1;
     if (n > 64) n = 64;
     return (int)n;
@@ -845,21 +849,31 @@ __device__ __forceinline__ bool eig_decide(double gpp, double gqq, double gpq, d
 // Here the workgroup has 8 waves: wave 0 decides the next step's rotations, wave 3 turns its register rows of J, and FIVE waves
 // (1, 2, 4, 5, 6) update G over the 2 x 2 blocks of the upper triangle only (528 instead of 1024 for a 64 x 64 matrix), writing
 // every block and its mirror image, so that G stays exactly symmetric and a thread has two blocks per step instead of eight.
-template <int NB>
-__global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restrict__ part, int nchunk, int nvec, int mode,
-                                                         int max_sweeps, double dead_thresh,
-                                                         double* __restrict__ out, int* __restrict__ dead,
-                                                         int* __restrict__ nrot_out, double* __restrict__ maxoff_out,
-                                                         double relevant2, int dbg, double fast_thr) {
+// (The body is a device function: the standalone kernel below runs it once per launch, the persistent SVD kernels once per Jacobi
+// round.  pool: LDS, 4 x NB x (NB + 1) doubles (the two copies of G, J, and the fast path's R), supplied by the caller, who may use
+// it for something else between calls.  COH: the partial sums / the
+// results are exchanged with other workgroups of the SAME launch -- agent-scope accesses.)
+template <int NB, bool COH = false>
+__device__ __forceinline__ void eig_small3_body(double* pool, const int grp, const double* part, int nchunk, int nvec, int mode,
+                                                int max_sweeps, double dead_thresh, double* out, int* dead, int* nrot_out, double* maxoff_out,
+                                                double relevant2, int dbg, double fast_thr) {
     constexpr int P = NB + 1;
-    __shared__ double Gb[2][NB * P];
-    __shared__ double J[NB * P];
+    auto ldc = [](const double* q) -> double {
+        if constexpr (COH) return __hip_atomic_load((const __attribute__((address_space(1))) double*)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *q;
+    };
+    auto stc = [](double* q, double v) {
+        if constexpr (COH) __hip_atomic_store((__attribute__((address_space(1))) double*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *q = v;
+    };
+    double (*Gb)[NB * P] = reinterpret_cast<double (*)[NB * P]>(pool);
+    double* J = pool + 2 * NB * P;
     __shared__ double dsc[NB];
     __shared__ int cnt, total;
     __shared__ int stepflag[2];
     __shared__ double red[512];
     constexpr int NT_ = 512;
-    const int tid = threadIdx.x, grp = blockIdx.x;
+    const int tid = threadIdx.x;
     const double* pg = part + (int64_t)grp * nchunk * nvec * nvec;
     double* G = Gb[0];
     {
@@ -867,19 +881,23 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
         double acc[EPT];
 #pragma unroll
         for (int t = 0; t < EPT; ++t) acc[t] = 0.0;
-        for (int c = 0; c < nchunk; c += 2) {
-            double v0[EPT], v1[EPT];
-            const bool two = (c + 1 < nchunk);
+        // four partial sums per memory round trip, added in chunk order (an absent one adds +0.0, which changes nothing: acc is never -0.0)
+        for (int c = 0; c < nchunk; c += 4) {
+            double v0[EPT], v1[EPT], v2[EPT], v3[EPT];
+            const bool two = (c + 1 < nchunk), three = (c + 2 < nchunk), four = (c + 3 < nchunk);
+            const int64_t nn = (int64_t)nvec * nvec;
 #pragma unroll
             for (int t = 0; t < EPT; ++t) {
                 const int e = tid + NT_ * t, i = e / NB, j = e % NB;
                 const bool in = (i < nvec && j < nvec);
-                const int64_t o = (int64_t)c * nvec * nvec + i * nvec + j;
-                v0[t] = in ? pg[o] : 0.0;
-                v1[t] = (in && two) ? pg[o + (int64_t)nvec * nvec] : 0.0;
+                const int64_t o = (int64_t)c * nn + i * nvec + j;
+                v0[t] = in ? ldc(pg + o) : 0.0;
+                v1[t] = (in && two) ? ldc(pg + o + nn) : 0.0;
+                v2[t] = (in && three) ? ldc(pg + o + 2 * nn) : 0.0;
+                v3[t] = (in && four) ? ldc(pg + o + 3 * nn) : 0.0;
             }
 #pragma unroll
-            for (int t = 0; t < EPT; ++t) acc[t] = (acc[t] + v0[t]) + v1[t];
+            for (int t = 0; t < EPT; ++t) acc[t] = (((acc[t] + v0[t]) + v1[t]) + v2[t]) + v3[t];
         }
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
@@ -937,7 +955,7 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
         __syncthreads();
     };
     measure(G);
-    if (tid == 0 && maxoff_out) maxoff_out[grp] = red[0];
+    if (tid == 0 && maxoff_out) stc(maxoff_out + grp, red[0]);
     // ---- near-diagonal fast path (SVD pair step, 64 x 64): in the quadratic regime -- every relative off-diagonal below fast_thr, which
     // is what a pair meets from the second outer sweep on -- the 2 x 63 dependent steps of the cyclic sweeps are replaced by Newton-like
     // steps on the whole matrix: K = the antisymmetric matrix of ALL Jacobi angles of the current G (K_pq = sin theta_pq), R = I + K made
@@ -951,7 +969,7 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
     // (Gc: the current matrix, red[0]: its measure; Wk: scratch of the same size.  Leaves red[0] = the measure of what it leaves in Gc.)
     auto fast_try = [&](double* Gc, double* Wk) {
         if constexpr (NB == 64) {
-            __shared__ double Rb[NB * P];
+            double* Rb = pool + 3 * NB * P;
             typedef double d4f __attribute__((ext_vector_type(4)));
             const int w8 = tid >> 6, ln = tid & 63, li = ln & 15, lk = ln >> 4;
             const int ti = w8 >> 1, tj0 = (w8 & 1) * 2;
@@ -1329,7 +1347,10 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
     }
     double* Gf = Gb[cur];                                  // the rotated Gram matrix
     double* Gs = Gb[cur ^ 1];                              // scratch for the Newton-Schulz step
-    if (tid == 0 && nrot_out) nrot_out[grp] = total;
+    if (tid == 0 && nrot_out) {
+        if constexpr (COH) __hip_atomic_store((__attribute__((address_space(1))) int*)(nrot_out + grp), (int)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else nrot_out[grp] = total;
+    }
     if (mode != 1 && total > 0) {
         typedef double d4e __attribute__((ext_vector_type(4)));
         constexpr int NT = NB / 16, TPW = NT * NT / 4;
@@ -1389,8 +1410,18 @@ __global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restric
             v = (di == 0.0) ? 0.0 : v / di;
             if (dsc[j] == 0.0) v = 0.0;
         }
-        o[e] = v;
+        stc(o + e, v);
     }
+}
+
+template <int NB>
+__global__ __launch_bounds__(512) void eig_small3_kernel(const double* __restrict__ part, int nchunk, int nvec, int mode,
+                                                         int max_sweeps, double dead_thresh,
+                                                         double* __restrict__ out, int* __restrict__ dead,
+                                                         int* __restrict__ nrot_out, double* __restrict__ maxoff_out,
+                                                         double relevant2, int dbg, double fast_thr) {
+    __shared__ double pool[4 * NB * (NB + 1)];
+    eig_small3_body<NB>(pool, (int)blockIdx.x, part, nchunk, nvec, mode, max_sweeps, dead_thresh, out, dead, nrot_out, maxoff_out, relevant2, dbg, fast_thr);
 }
 
 int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngroups, int mode, int max_sweeps,
@@ -1426,6 +1457,290 @@ int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngro
                            dead_thresh, out, dead, nrot, maxoff, relevant2);
     TN_CHECK_LAUNCH("eig_small_kernel");
     prof_end(st, PROF_EIG, 0.0, 8.0 * ngroups * ((double)nchunk + 1.0) * nvec * nvec);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ all Jacobi rounds of an SVD in ONE launch
+// jacobi_core (svd.hip) spends three launches per round -- pair Gram matrices, eig_small, rotation of the vectors -- and one host
+// synchronisation per sweep: ~60 launches and 5-6 round trips per truncated SVD of the headline workload, 11 k launches per sweep of a
+// chain.  svdl_kernel runs the SAME three steps (every sum in the same order: results identical bit for bit) as phases of one
+// persistent launch, separated by grid barriers; the convergence test of a sweep (largest relative off-diagonal met) is taken by
+// every workgroup from the same numbers; the squared norms of the rotated vectors -- what the host sorts the singular values from --
+// close the launch.  Every vector is cut into chunks of 64 elements and workgroup c keeps chunk c of ALL vectors (X and the accumulator
+// P: nvp x 64 doubles, up to 96 KB) in LDS for the whole launch; ng further workgroups solve the eigenproblems.  Per round: the chunk
+// workgroups form their 64-element share of every pair's Gram matrix straight from LDS (MFMA, the sequence of the GEMM kernel over
+// K = 64) and publish it; barrier; eigenproblems (the body of eig_small3_kernel; its prologue adds the shares up in chunk order,
+// gram_nchunk cuts the separate launches at the same 64); barrier; the chunk workgroups fetch J and rotate their rows in LDS.  What
+// crosses workgroups (agent-scope accesses) is the partial Gram matrices and J -- the vectors travel once in and once out.
+// A form that kept the vectors in memory and ran the GEMM tile body between the barriers was measured first: every K step of those
+// small products is a memory round trip, ~40 us per round around the eigenproblems against ~23 us for the two GEMM launches.
+// The workgroups spin on barriers, so they must be co-resident: the grid is kept within the budget of cholqr.hip (fused_forms_allowed),
+// the spins are bounded, and a launch in which a barrier gave up says so in its status word (the caller redoes the rounds with the
+// three-launch form and takes the stream off the single-launch forms).  The barrier state cleans itself: all workgroups leave sooner
+// or later, the last one resets the counters.
+// Needs nvp <= 192 (LDS) and ceil(pitch / 64) + ng workgroups within the budget; otherwise the rounds stay separate launches.
+struct SvdjState { int counter; int exits; int gaveup; int pad; };
+__device__ SvdjState svdj_state_pool[CHOLQR_SLOTS];
+constexpr unsigned SVDJ_MAGIC = 0x53564a31u;
+
+// naps: the pause between two looks at the counter, in units of ~0.4 us.  The wait for the eigenproblems lasts 15-100 us and up to 30
+// workgroups per chain sit in it.
+__device__ __forceinline__ bool svdj_barrier(int* counter, int target, int* s_flag, int tid, unsigned spin_limit, int naps = 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(counter, 1);
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(15);
+            if (++spins > spin_limit) { ok = 0; break; }
+        }
+        *s_flag = ok;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+struct SvdlArgs {
+    double* X;
+    int64_t pitch, L;
+    int nvp, ncw, ng, nr, nchunk;
+    const int* pairs;
+    double* part;
+    double* Js;
+    int* nrot;
+    double* maxoff;
+    double relevant2, fast_thr, last_tol;
+    int inner_first, inner_later, dbg;
+    double* norms;                     // nvp squared norms, then status: sweeps, converged, workgroups that gave up
+    SvdjState* stt;
+    unsigned spin_limit;
+    unsigned magic;
+    int eig_naps;
+};
+typedef const __attribute__((address_space(4))) SvdlArgs* SvdlArgsK;
+
+__device__ __noinline__ void svdl_eig(SvdlArgsK a_in, double* pool, int grp, int r, int outer) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long v = (unsigned long long)a_in;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    SvdlArgsK a = (SvdlArgsK)(((unsigned long long)hi << 32) | lo);
+    const int inner = (a->ng == 1) ? 12 : (outer == 0 ? a->inner_first : a->inner_later);
+    eig_small3_body<64, true>(pool, grp, a->part, a->nchunk, 64, 2, inner, 0.0, a->Js, nullptr, a->nrot, a->maxoff + (int64_t)r * a->ng,
+                              a->relevant2, a->dbg, outer < 8 ? a->fast_thr : 0.0);
+#endif
+}
+
+__global__ __launch_bounds__(512) void svdl_kernel(SvdlArgs a) {
+    constexpr int NB = 64, P = NB + 1, XP = 65, W = 32;
+    typedef double d4l __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) double* gcd;
+    typedef __attribute__((address_space(1))) double* gd;
+    __shared__ double pool[4 * NB * P];
+    __shared__ double redn[256];
+    __shared__ int s_flag;
+    __shared__ int s_pairs[64];
+    __shared__ int s_rot[32];
+    const int tid = threadIdx.x, blk = blockIdx.x, nwg = gridDim.x;
+    SvdlArgsK ak = (SvdlArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    const bool chunk_wg = blk < a.ncw;
+    const int c0 = blk * 64, grp = blk - a.ncw;
+    double* Xc = pool;                       // chunk workgroups: [nvp][XP]
+    double* Jl = pool + 3 * NB * P;          // ... and the J of the pair being rotated
+    int nbar = 0, sweeps = 0;
+    bool alive = ak != nullptr && ak->magic == SVDJ_MAGIC && ak->nvp == a.nvp && ak->pairs == a.pairs && ak->norms == a.norms && ak->Js == a.Js;
+    bool converged = false;
+    auto bar = [&](int naps = 0) -> bool { ++nbar; return svdj_barrier(&a.stt->counter, nbar * nwg, &s_flag, tid, a.spin_limit, naps); };
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int ti = wave >> 1, tj0 = (wave & 1) * 2;          // this wave's two 16 x 16 tiles of a 64 x 64 result
+    if (chunk_wg && alive) {
+        for (int e = tid; e < a.nvp * 64; e += 512) {
+            const int r = e >> 6, c = e & 63;
+            Xc[r * XP + c] = (c0 + c < a.pitch) ? a.X[(int64_t)r * a.pitch + c0 + c] : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int outer = 0; outer < 40 && !converged && alive; ++outer) {
+        for (int r = 0; r < a.nr; ++r) {
+            if (tid < 2 * a.ng && tid < 64) s_pairs[tid] = a.pairs[(int64_t)r * a.ng * 2 + tid];
+            __syncthreads();
+            if (chunk_wg && blk < a.nchunk) {
+                // this chunk's share of every pair's Gram matrix (the MFMA sequence of gemm_kernel over K = 64, elements past L as zeros)
+                for (int z = 0; z < a.ng; ++z) {
+                    const int b0 = s_pairs[2 * z], b1 = s_pairs[2 * z + 1];
+                    auto prow = [&](int v) -> int { return v < W ? b0 * W + v : b1 * W + (v - W); };
+                    const int ra = prow(ti * 16 + li), rb0 = prow(tj0 * 16 + li), rb1 = prow((tj0 + 1) * 16 + li);
+                    d4l acc0 = d4l{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+                    for (int k4 = 0; k4 < 16; ++k4) {
+                        const int k = k4 * 4 + lk;
+                        const bool in = c0 + k < a.L;
+                        const double fa = in ? Xc[ra * XP + k] : 0.0;
+                        const double f0 = in ? Xc[rb0 * XP + k] : 0.0, f1 = in ? Xc[rb1 * XP + k] : 0.0;
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, f0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, f1, acc1, 0, 0, 0);
+                    }
+                    gd o = (gd)(a.part + ((int64_t)z * a.nchunk + blk) * (NB * NB));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = ti * 16 + lk + 4 * q;
+                        __hip_atomic_store(o + row * NB + tj0 * 16 + li, acc0[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(o + row * NB + (tj0 + 1) * 16 + li, acc1[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (!(alive = bar())) break;
+            if (!chunk_wg) {
+                svdl_eig(ak, pool, grp, r, outer);
+                __syncthreads();
+            }
+            if (!(alive = bar(chunk_wg ? a.eig_naps : 0))) break;
+            if (chunk_wg) {
+                if (tid < a.ng && tid < 32) s_rot[tid] = __hip_atomic_load((const __attribute__((address_space(1))) int*)(a.nrot + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                for (int z = 0; z < a.ng; ++z) {
+                    if (s_rot[z] == 0) continue;                    // (uniform) no rotation in this pair
+                    const int b0 = s_pairs[2 * z], b1 = s_pairs[2 * z + 1];
+                    auto prow = [&](int v) -> int { return v < W ? b0 * W + v : b1 * W + (v - W); };
+                    {
+                        gcd jsrc = (gcd)(a.Js + (int64_t)z * (NB * NB));
+                        double jv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) jv[u] = __hip_atomic_load(jsrc + tid + 512 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const int e = tid + 512 * u; Jl[(e >> 6) * P + (e & 63)] = jv[u]; }
+                    }
+                    __syncthreads();
+                    // rows of the pair <- J^T rows (gemm_kernel's sequence over K = 64 vectors)
+                    d4l acc0 = d4l{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+                    for (int k4 = 0; k4 < 16; ++k4) {
+                        const int k = k4 * 4 + lk;
+                        const double fa = Jl[k * P + ti * 16 + li];
+                        const int rk = prow(k);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, Xc[rk * XP + tj0 * 16 + li], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, Xc[rk * XP + (tj0 + 1) * 16 + li], acc1, 0, 0, 0);
+                    }
+                    __syncthreads();                                // every wave has read the old rows
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ri = prow(ti * 16 + lk + 4 * q);
+                        Xc[ri * XP + tj0 * 16 + li] = acc0[q];
+                        Xc[ri * XP + (tj0 + 1) * 16 + li] = acc1[q];
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (!alive) break;
+        ++sweeps;
+        double m = 0.0;
+        for (int e = tid; e < a.nr * a.ng; e += 512) m = fmax(m, __hip_atomic_load((gcd)(a.maxoff + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+        if ((tid & 63) == 0) redn[tid >> 6] = m;
+        __syncthreads();
+        double worst = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) worst = fmax(worst, redn[w]);
+        __syncthreads();
+        converged = worst < 4.0e-15 || worst <= a.last_tol;
+    }
+    if (alive) {
+        if (chunk_wg) {
+            for (int e = tid; e < a.nvp * 64; e += 512) {
+                const int r = e >> 6, c = e & 63;
+                if (c0 + c < a.pitch) __hip_atomic_store((gd)(a.X + (int64_t)r * a.pitch + c0 + c), Xc[r * XP + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        alive = bar();
+    }
+    if (alive) {
+        // squared norms of the vectors, summed as vec_norm2_kernel sums them
+        for (int row = blk; row < a.nvp; row += nwg) {
+            gcd x = (gcd)(a.X + (int64_t)row * a.pitch);
+            double sacc = 0.0;
+            if (tid < 256)
+                for (int64_t c = tid; c < a.L; c += 256) { const double t = __hip_atomic_load(x + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sacc += t * t; }
+            if (tid < 256) redn[tid] = sacc;
+            __syncthreads();
+            for (int k = 128; k > 0; k >>= 1) {
+                if (tid < k) redn[tid] += redn[tid + k];
+                __syncthreads();
+            }
+            if (tid == 0) a.norms[row] = redn[0];
+            __syncthreads();
+        }
+        if (blk == 0 && tid == 0) { a.norms[a.nvp] = (double)sweeps; a.norms[a.nvp + 1] = converged ? 1.0 : 0.0; }
+    }
+    if (tid == 0) {
+        if (!alive) atomicAdd(&a.stt->gaveup, 1);
+        __threadfence();
+        const int prev = atomicAdd(&a.stt->exits, 1);
+        if (prev == nwg - 1) {
+            const int gu = atomicAdd(&a.stt->gaveup, 0);
+            a.norms[a.nvp + 2] = (double)gu;
+            a.stt->exits = 0; a.stt->counter = 0; a.stt->gaveup = 0;
+            __threadfence();
+        }
+    }
+}
+
+static SvdjState* svdj_state_of(int slot) {
+    static std::mutex mu;
+    static char* base[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!base[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(svdj_state_pool)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        base[dev] = (char*)p;
+    }
+    return (SvdjState*)base[dev] + slot;
+}
+
+// 0: the launch is in the stream (read norms[nvp .. nvp + 2] back: sweeps, converged, workgroups that gave up); 1: not taken (the
+// caller runs the rounds as separate launches); else an error
+int svd_rounds_fused(hipStream_t st, const SvdRoundsJob& j) {
+    {
+        const char* e = getenv("TN_SVD_FUSED");                       // read per call: the tests switch it
+        if (e && e[0] == '0') return 1;
+    }
+    static const int gen = [] { const char* e = getenv("TN_EIG_PIPELINED"); return e ? atoi(e) : 2; }();
+    if (gen < 2) return 1;
+    static const int dbg = [] { const char* e = getenv("TN_EIG_DBG"); return e ? atoi(e) : 0; }();
+    static const double fast_thr = [] { const char* e = getenv("TN_EIG_FAST"); return e ? atof(e) : 1e-2; }();
+    static const int eig_naps = [] { const char* e = getenv("TN_SVDJ_NAPS"); return e ? atoi(e) : 2; }();
+    const int slot = cholqr_stream_slot(st);
+    if (slot >= CHOLQR_SLOTS) return 1;
+    if (2 * j.w != 64 || j.ng < 1 || j.ng > 32 || j.nr < 1 || j.nvp > 192) return 1;
+    // the chunks of the kernel must be the splits the GEMM of the separate launches would use (gram_nchunk cuts at 64 up to L = 4096)
+    int64_t kchunk = 0;
+    const int nchunk = gemm_forced_split(j.L, j.nchunk, &kchunk);
+    const int ncw = (int)cdiv(j.pitch, 64);
+    if (!(kchunk == 64 || nchunk == 1) || nchunk < 1 || nchunk > ncw) return 1;
+    if ((int64_t)j.ng * nchunk * 64 * 64 * 8 > j.part_bytes) return 1;
+    if (!fused_forms_allowed(st, ncw + j.ng)) return 1;
+    SvdlArgs l;
+    l.X = j.X; l.pitch = j.pitch; l.L = j.L; l.nvp = j.nvp; l.ncw = ncw; l.ng = j.ng; l.nr = j.nr; l.nchunk = nchunk;
+    l.pairs = j.pairs; l.part = j.part; l.Js = j.Js; l.nrot = j.nrot; l.maxoff = j.maxoff;
+    l.relevant2 = j.relevant2; l.fast_thr = fast_thr; l.last_tol = j.last_tol;
+    l.inner_first = j.inner_first; l.inner_later = j.inner_later; l.dbg = dbg;
+    l.norms = j.norms;
+    l.stt = svdj_state_of(slot);
+    if (!l.stt) return 1;
+    l.spin_limit = 1u << 22;
+    if (const char* e = getenv("TN_PANEL_SPIN_LIMIT")) l.spin_limit = (unsigned)strtoul(e, nullptr, 10);      // tests: force the barriers to give up
+    l.magic = SVDJ_MAGIC;
+    l.eig_naps = eig_naps;
+    prof_begin(st, PROF_EIG);
+    hipLaunchKernelGGL(svdl_kernel, dim3(ncw + j.ng), dim3(512), 0, st, l);
+    TN_CHECK_LAUNCH("svdl_kernel");
+    prof_end(st, PROF_EIG, 0.0, 0.0);
     return 0;
 }
 

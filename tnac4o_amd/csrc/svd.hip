@@ -555,9 +555,47 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     static const bool restrict_conv = [] { const char* e = getenv("TN_SVD_RELEVANT"); return !(e && e[0] == '0'); }();
     const double rel4 = 0.25 * rel_tol;
     const double relevant2 = restrict_conv ? nmax * rel4 * rel4 : 0.0;
+    static const double last_tol = [] { const char* e = getenv("TN_SVD_LAST"); return e ? atof(e) : 1e-9; }();
+    static const bool trace = [] { const char* e = getenv("TN_SVD_TRACE"); return e && e[0] == '1'; }();
     int sweeps = 0;
     bool converged = false;
-    for (int outer = 0; outer < 40 && !converged; ++outer) {
+    std::vector<double> hs(nvp);
+    // All rounds of all sweeps, the convergence tests and the final norms in ONE launch (svdl_kernel, small.hip) -- the same arithmetic
+    // as the loop below, bit for bit.  If one of its barriers gave up (workgroups not co-resident) the vectors are set up again and the
+    // loop below does the work; the stream stays off the single-launch forms from then on.
+    bool fused_done = false;
+    if (!trace) {
+        SvdRoundsJob j;
+        j.X = w.X; j.pitch = pitch; j.L = L; j.nvp = (int)nvp; j.w = SVD_W;
+        j.pairs = w.pairs; j.ng = ng; j.nr = nr; j.nchunk = nchunk;
+        j.part = w.part; j.part_bytes = (int64_t)ng * nchunk * nvec * nvec * 8; j.Js = w.Js; j.nrot = w.nrot; j.maxoff = w.maxoff;
+        j.relevant2 = relevant2; j.last_tol = last_tol; j.inner_first = inner_env; j.inner_later = inner_later;
+        j.norms = w.norms;                                            // (w.Ssorted follows it: room for the status words)
+        rc = svd_rounds_fused(st, j);
+        if (rc != 0 && rc != 1) return rc;
+        if (rc == 0) {
+            std::vector<double> hb(nvp + 4);
+            double* stage = (double*)pinned_host((size_t)(nvp + 4) * 8, 2);
+            if ((e = hipMemcpyAsync(stage ? stage : hb.data(), w.norms, (nvp + 4) * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy S");
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync S");
+            if (stage) std::memcpy(hb.data(), stage, (size_t)(nvp + 4) * 8);
+            if (hb[nvp + 2] != 0.0) {
+                fprintf(stderr, "[libtnpeps] the one-launch Jacobi rounds of an SVD gave up at a barrier on stream %p (%d workgroup(s); workgroups not "
+                        "co-resident: is the device shared? see TN_PANEL_CU_BUDGET); the rounds are redone as separate launches, which this stream "
+                        "uses from now on\n", (void*)st, (int)hb[nvp + 2]);
+                fused_forms_disable(st);
+                TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(svd_init_kernel, dim3((unsigned)nvp), dim3(256), 0, st, M, vs, es, L, nv, w.live, nvl, w.X,
+                                   vectors ? w.P : nullptr, pitch));
+                TN_CHECK_LAUNCH("svd_init_kernel");
+            } else {
+                sweeps = (int)hb[nvp];
+                converged = hb[nvp + 1] != 0.0;
+                std::copy(hb.begin(), hb.begin() + nvp, hs.begin());
+                fused_done = true;
+            }
+        }
+    }
+    for (int outer = 0; outer < 40 && !converged && !fused_done; ++outer) {
         for (int r = 0; r < nr; ++r) {
             const int* pr = w.pairs + (int64_t)r * ng * 2;
             // Gram matrices of all block pairs on the matrix cores: G = Xp Xp^T, split over L with the partial sums left
@@ -587,7 +625,6 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
         }
         double worst = 0.0;
         for (double v : hoff) worst = std::max(worst, v);
-        static const bool trace = [] { const char* e = getenv("TN_SVD_TRACE"); return e && e[0] == '1'; }();
         if (trace) {
             fprintf(stderr, "[tn_svd] nv=%lld L=%lld live=%d sweep=%d worst=%.3e offs", (long long)nv, (long long)L, nvl, sweeps, worst);
             for (double v : hoff) fprintf(stderr, " %.2e", v);
@@ -597,15 +634,13 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
         // diagonalised to rounding by the two inner sweeps, cross terms are products of two such numbers), so the verification sweep
         // that would follow finds every pair below 4e-15 and rotates nothing -- it is skipped (8-10 % of the rounds of a sweep of the
         // headline workload); the results are the same bit for bit unless that sweep would have found something, which 1e-18 cannot be.
-        static const double last_tol = [] { const char* e = getenv("TN_SVD_LAST"); return e ? atof(e) : 1e-9; }();
         converged = worst < 4.0e-15 || worst <= last_tol;
     }
     if (sweeps_out) *sweeps_out = sweeps;
     if (info) *info = converged ? 0 : 1;
-    TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nvp), dim3(256), 0, st, w.X, pitch, 1, L, w.norms));
-    TN_CHECK_LAUNCH("vec_norm2_kernel");
-    std::vector<double> hs(nvp);
-    {
+    if (!fused_done) {
+        TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nvp), dim3(256), 0, st, w.X, pitch, 1, L, w.norms));
+        TN_CHECK_LAUNCH("vec_norm2_kernel");
         double* stage = (double*)pinned_host((size_t)nvp * 8, 2);
         if ((e = hipMemcpyAsync(stage ? stage : hs.data(), w.norms, nvp * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy S");
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync S");

@@ -18,4 +18,6 @@ for m in (288, 1056, 2080, 4128, 8224, 16416):
     buf = (C.c_longlong * 32)()
     L.tn_debug_clocks2(buf, 32)
     t = [buf[i] for i in range(11)]
-    print('%6d rows ' % (m - 32) + '  '.join('%s %.1f' % (names[i], (t[i + 1] - t[i]) / 100.0) for i in range(10)) + '   total %.1f us' % ((t[10] - t[0]) / 100.0))
+    print('%6d rows ' % (m - 32) + '  '.join('%s %.1f' % (names[i], (t[i + 1] - t[i]) / 100.0) for i in range(10)) + '   total %.1f us' % ((t[10] - t[0]) / 100.0)
+          + '   [lu: eliminate %.1f  inverses %.1f  T %.1f  products+stores %.1f]' % (
+              (buf[11] - t[8]) / 100.0, (buf[12] - buf[11]) / 100.0, (buf[13] - buf[12]) / 100.0, (t[9] - buf[13]) / 100.0))
