@@ -264,79 +264,158 @@ __device__ __forceinline__ void cq_lu(const double* ytop, bool coherent_loads, i
     constexpr int P = 33;
     double* Um = scr;                  // U (zeros below the diagonal), then U S, then T
     double* Lm = scr + 32 * P;         // L (unit lower, zeros above)
-    double* Ui = scr + 2 * 32 * P;     // U^-1
+    double* Ui = scr + 2 * 32 * P;     // U^-1  (before that: the matrix itself, consumed block by block)
     double* Li = scr + 3 * 32 * P;     // L^-1
     double* sg = scr + 4 * 32 * P;
+    double* Bm = Ui;
     const int lane = tid & 63, wave = tid >> 6;
-    if (tid < 64) {
-        const int r = lane & 31;
-        double u[32], l[32];
+    const int li_ = lane & 15, lk = lane >> 4;
+    // The factorisation is blocked 2 x 2 in 16 x 16 blocks, so that only the two diagonal blocks go through the one-wave elimination
+    // with its sequential pivots (2 x 16 steps over at most 15 columns instead of 32 over at most 31) and the 16-step substitutions
+    // for their inverses; everything off the diagonal -- U12 = L11^-1 B12, the Schur complement B22 - L21 U12, and the off-diagonal
+    // blocks of both inverses -- is 16 x 16 x 16 products on the matrix cores.  A product's result tile (D layout) is the B operand
+    // of the next product's K steps as it stands, so two chained products need no trip through LDS.
+    {   // the matrix, padded with an identity block that is never eliminated: one coalesced round trip
+        double v[4];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const double x = coherent_loads ? cq_ld(ytop + r * 32 + c) : ytop[r * 32 + c];
-            u[c] = (r < b && c < b) ? x : ((r == c) ? 1.0 : 0.0);       // padding: identity block, never eliminated
-            l[c] = (r == c) ? 1.0 : 0.0;
-        }
-        double mysg = 1.0;
+        for (int t = 0; t < 4; ++t) { const int e = tid + 256 * t; v[t] = coherent_loads ? cq_ld(ytop + e) : ytop[e]; }
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const double bii = cq_readlane(u[i], i);
-            const bool live = i < b;                      // uniform
-            const double sgn = (bii >= 0.0) ? -1.0 : 1.0, piv = bii - sgn, rp = fast_rcp(live ? piv : 1.0);
-            const double li = (live && r > i) ? u[i] * rp : 0.0;
-#pragma unroll
-            for (int c = i + 1; c < 32; ++c) {
-                const double uic = cq_readlane(u[c], i);
-                cq_fnma_s(u[c], uic, li);
-            }
-            l[i] = (r > i) ? li : l[i];
-            u[i] = (r > i) ? 0.0 : ((r == i && live) ? piv : u[i]);
-            if (r == i) mysg = live ? sgn : 1.0;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (lane < 32) {
-#pragma unroll
-            for (int c = 0; c < 32; ++c) { Um[r * P + c] = u[c]; Lm[r * P + c] = l[c]; Ui[r * P + c] = 0.0; Li[r * P + c] = 0.0; }
-            sg[r] = mysg;
+        for (int t = 0; t < 4; ++t) {
+            const int e = tid + 256 * t, r = e >> 5, c = e & 31;
+            Bm[r * P + c] = (r < b && c < b) ? v[t] : ((r == c) ? 1.0 : 0.0);
         }
     }
     __syncthreads();
-    FQ_CLK(11);
-    // U^-1 and L^-1 by substitution, one column per lane with the column in registers (wave 0: U^-1, wave 1: L^-1)
-    if (wave == 0 && lane < 32) {
-        const int j = lane;
-        double x[32], rd[32];
+    // one-wave elimination of a 16-column block: lane -> row `r`, the block's columns c0 .. c0 + 15 of that row in registers; the pivot
+    // row of step i sits in lane i.  Leaves U (rows above / on the diagonal), the multipliers (rows below) and the signs.
+    auto eliminate16 = [&](const int r, const int c0, const bool rows_on) {
+        double u[16], l[16];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) rd[i] = fast_rcp(Um[i * P + i]);
+        for (int c = 0; c < 16; ++c) { u[c] = Bm[r * P + c0 + c]; l[c] = (r == c0 + c) ? 1.0 : 0.0; }
+        double mysg = 1.0;
 #pragma unroll
-        for (int i = 31; i >= 0; --i) {
+        for (int i = 0; i < 16; ++i) {
+            const int gi = c0 + i;
+            const double bii = cq_readlane(u[i], i);
+            const bool live = gi < b;                      // uniform
+            const double sgn = (bii >= 0.0) ? -1.0 : 1.0, piv = bii - sgn, rp = fast_rcp(live ? piv : 1.0);
+            const double lv = (live && r > gi) ? u[i] * rp : 0.0;
+#pragma unroll
+            for (int c = i + 1; c < 16; ++c) {
+                const double uic = cq_readlane(u[c], i);
+                cq_fnma_s(u[c], uic, lv);
+            }
+            l[i] = (r > gi) ? lv : l[i];
+            u[i] = (r > gi) ? 0.0 : ((r == gi && live) ? piv : u[i]);
+            if (r == gi) mysg = live ? sgn : 1.0;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (rows_on) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { Um[r * P + c0 + c] = u[c]; Lm[r * P + c0 + c] = l[c]; }
+            if (r >= c0 && r < c0 + 16) sg[r] = mysg;
+        }
+    };
+    // inverse of a 16 x 16 triangular diagonal block by substitution, one column per lane (upper: of Um, lower unit: of Lm)
+    auto inv_upper16 = [&](const int o, const int j) {
+        double x[16], rd[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rd[i] = fast_rcp(Um[(o + i) * P + o + i]);
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
             double sa[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = i + 1; k < 32; ++k) sa[k & 3] += Um[i * P + k] * x[k];
+            for (int k = i + 1; k < 16; ++k) sa[k & 3] += Um[(o + i) * P + o + k] * x[k];
             const double t = (sa[0] + sa[1]) + (sa[2] + sa[3]);
             x[i] = (i > j) ? 0.0 : ((i == j) ? rd[i] : -t * rd[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 32; ++i) Ui[i * P + j] = x[i];
-    } else if (wave == 1 && lane < 32) {
-        const int j = lane;
-        double x[32];
+        for (int i = 0; i < 16; ++i) Ui[(o + i) * P + o + j] = x[i];
+    };
+    auto inv_lower16 = [&](const int o, const int j) {
+        double x[16];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < 16; ++i) {
             double sa[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < i; ++k) sa[k & 3] += Lm[i * P + k] * x[k];
+            for (int k = 0; k < i; ++k) sa[k & 3] += Lm[(o + i) * P + o + k] * x[k];
             const double t = (sa[0] + sa[1]) + (sa[2] + sa[3]);
             x[i] = (i < j) ? 0.0 : ((i == j) ? 1.0 : -t);
         }
 #pragma unroll
-        for (int i = 0; i < 32; ++i) Li[i * P + j] = x[i];
+        for (int i = 0; i < 16; ++i) Li[(o + i) * P + o + j] = x[i];
+    };
+    // 16 x 16 x 16 products by one wave: D = sa A B + C, A from LDS (block at Am, pitch P), B from LDS or from the result tile of
+    // the product before (register r = K step r)
+    auto mm16 = [&](const double* Am, const double sa, const double* Bm_, const d4c* Breg, const d4c c0v) -> d4c {
+        d4c acc = c0v;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = ks * 4 + lk;
+            const double fa = sa * Am[li_ * P + k];
+            const double fb = Breg ? (*Breg)[ks] : Bm_[k * P + li_];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    auto put16 = [&](double* Dm, const d4c v) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dm[(lk + 4 * q) * P + li_] = v[q];
+    };
+    const d4c zero4 = d4c{0.0, 0.0, 0.0, 0.0};
+    FQ_CLK(14);
+    // (1) first block column: rows 0 .. 31 in lanes 0 .. 31
+    if (wave == 0) eliminate16(lane & 31, 0, lane < 32);
+    __syncthreads();
+    FQ_CLK(15);
+    // (2) inverses of the first diagonal blocks (two waves side by side)
+    if (wave == 0 && lane < 16) inv_upper16(0, lane);
+    else if (wave == 1 && lane < 16) inv_lower16(0, lane);
+    __syncthreads();
+    FQ_CLK(16);
+    // (3) U12 = L11^-1 B12, then the Schur complement S22 = B22 - L21 U12 straight from the result tile
+    if (wave == 0) {
+        const d4c u12 = mm16(Li, 1.0, Bm + 16, nullptr, zero4);
+        d4c b22;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b22[q] = Bm[(16 + lk + 4 * q) * P + 16 + li_];
+        const d4c s22 = mm16(Lm + 16 * P, -1.0, nullptr, &u12, b22);
+        put16(Um + 16, u12);
+        put16(Bm + 16 * P + 16, s22);
+    } else if (wave == 1) {                                // blocks nobody computes: zeros
+        for (int e = lane; e < 256; e += 64) {
+            const int r = e >> 4, c = e & 15;
+            Um[(16 + r) * P + c] = 0.0;                     // (U's lower-left block; the elimination left zeros there already)
+            Lm[r * P + 16 + c] = 0.0;
+            Li[r * P + 16 + c] = 0.0;
+        }
+    }
+    __syncthreads();
+    FQ_CLK(17);
+    // (4) second diagonal block: rows 16 .. 31 in lanes 0 .. 15 (the other lanes mirror them)
+    if (wave == 0) eliminate16(16 + (lane & 15), 16, lane < 16);
+    __syncthreads();
+    FQ_CLK(18);
+    if (wave == 0 && lane < 16) inv_upper16(16, lane);
+    else if (wave == 1 && lane < 16) inv_lower16(16, lane);
+    __syncthreads();
+    FQ_CLK(19);
+    // (5) off-diagonal blocks of the inverses:  U^-1_12 = -U11^-1 (U12 U22^-1),  L^-1_21 = -L22^-1 (L21 L11^-1)
+    if (wave == 0) {
+        const d4c p = mm16(Um + 16, 1.0, Ui + 16 * P + 16, nullptr, zero4);
+        const d4c x = mm16(Ui, -1.0, nullptr, &p, zero4);
+        put16(Ui + 16, x);
+    } else if (wave == 1) {
+        const d4c p = mm16(Lm + 16 * P, 1.0, Li, nullptr, zero4);
+        const d4c x = mm16(Li + 16 * P + 16, -1.0, nullptr, &p, zero4);
+        put16(Li + 16 * P, x);
+    } else if (wave == 2) {
+        for (int e = lane; e < 256; e += 64) Ui[(16 + (e >> 4)) * P + (e & 15)] = 0.0;
     }
     __syncthreads();
     FQ_CLK(12);
     for (int e = tid; e < 1024; e += 256) Um[(e >> 5) * P + (e & 31)] *= sg[e & 31];      // U S, in place
     __syncthreads();
-    const int li_ = lane & 15, lk = lane >> 4;
     // 32 x 32 products on the matrix cores, one wave each: acc[ti][tj] = op(A) op(B)
     auto mm = [&](const double* Am, const double* Bm, bool bt, d4c (&acc)[2][2]) {
 #pragma unroll

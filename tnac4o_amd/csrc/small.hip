@@ -1479,6 +1479,25 @@ int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngro
 // three-launch form and takes the stream off the single-launch forms).  The barrier state cleans itself: all workgroups leave sooner
 // or later, the last one resets the counters.
 // Needs nvp <= 192 (LDS) and ceil(pitch / 64) + ng workgroups within the budget; otherwise the rounds stay separate launches.
+// -DTN_CLOCKS: thread 0 of workgroup 0 (a chunk workgroup) accumulates the 100 MHz wall clock per phase over all launches:
+// [0] load  [1] Gram shares  [2] barrier  [3] wait for the eigenproblems  [4] rotation  [5] store + norms  [6] rounds  [7] launches
+#ifdef TN_CLOCKS
+__device__ long long svdl_clk[8];
+}  // namespace tn
+extern "C" int tn_debug_svdl_clocks(long long* host, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tn::svdl_clk), sizeof(long long) * 8);
+    if (reset) { long long z[8] = {}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(tn::svdl_clk), z, sizeof(z)); }
+    return rc;
+}
+namespace tn {
+#define SVL_CLK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const long long now_ = wall_clock64(); svdl_clk[k] += now_ - clk_last_; clk_last_ = now_; } } while (0)
+#define SVL_CNT(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) svdl_clk[k] += 1; } while (0)
+#define SVL_CLK_INIT long long clk_last_ = wall_clock64()
+#else
+#define SVL_CLK(k) do {} while (0)
+#define SVL_CNT(k) do {} while (0)
+#define SVL_CLK_INIT do {} while (0)
+#endif
 struct SvdjState { int counter; int exits; int gaveup; int pad; };
 __device__ SvdjState svdj_state_pool[CHOLQR_SLOTS];
 constexpr unsigned SVDJ_MAGIC = 0x53564a31u;
@@ -1556,6 +1575,8 @@ __global__ __launch_bounds__(512) void svdl_kernel(SvdlArgs a) {
     auto bar = [&](int naps = 0) -> bool { ++nbar; return svdj_barrier(&a.stt->counter, nbar * nwg, &s_flag, tid, a.spin_limit, naps); };
     const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int ti = wave >> 1, tj0 = (wave & 1) * 2;          // this wave's two 16 x 16 tiles of a 64 x 64 result
+    SVL_CLK_INIT;
+    SVL_CNT(7);
     if (chunk_wg && alive) {
         for (int e = tid; e < a.nvp * 64; e += 512) {
             const int r = e >> 6, c = e & 63;
@@ -1563,8 +1584,10 @@ __global__ __launch_bounds__(512) void svdl_kernel(SvdlArgs a) {
         }
     }
     __syncthreads();
+    SVL_CLK(0);
     for (int outer = 0; outer < 40 && !converged && alive; ++outer) {
         for (int r = 0; r < a.nr; ++r) {
+            SVL_CNT(6);
             if (tid < 2 * a.ng && tid < 64) s_pairs[tid] = a.pairs[(int64_t)r * a.ng * 2 + tid];
             __syncthreads();
             if (chunk_wg && blk < a.nchunk) {
@@ -1592,12 +1615,15 @@ __global__ __launch_bounds__(512) void svdl_kernel(SvdlArgs a) {
                     }
                 }
             }
+            SVL_CLK(1);
             if (!(alive = bar())) break;
+            SVL_CLK(2);
             if (!chunk_wg) {
                 svdl_eig(ak, pool, grp, r, outer);
                 __syncthreads();
             }
             if (!(alive = bar(chunk_wg ? a.eig_naps : 0))) break;
+            SVL_CLK(3);
             if (chunk_wg) {
                 if (tid < a.ng && tid < 32) s_rot[tid] = __hip_atomic_load((const __attribute__((address_space(1))) int*)(a.nrot + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
@@ -1637,6 +1663,7 @@ __global__ __launch_bounds__(512) void svdl_kernel(SvdlArgs a) {
         }
         if (!alive) break;
         ++sweeps;
+        SVL_CLK(4);
         double m = 0.0;
         for (int e = tid; e < a.nr * a.ng; e += 512) m = fmax(m, __hip_atomic_load((gcd)(a.maxoff + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
@@ -1674,6 +1701,7 @@ __global__ __launch_bounds__(512) void svdl_kernel(SvdlArgs a) {
             if (tid == 0) a.norms[row] = redn[0];
             __syncthreads();
         }
+        SVL_CLK(5);
         if (blk == 0 && tid == 0) { a.norms[a.nvp] = (double)sweeps; a.norms[a.nvp + 1] = converged ? 1.0 : 0.0; }
     }
     if (tid == 0) {

@@ -19,5 +19,6 @@ for m in (288, 1056, 2080, 4128, 8224, 16416):
     L.tn_debug_clocks2(buf, 32)
     t = [buf[i] for i in range(11)]
     print('%6d rows ' % (m - 32) + '  '.join('%s %.1f' % (names[i], (t[i + 1] - t[i]) / 100.0) for i in range(10)) + '   total %.1f us' % ((t[10] - t[0]) / 100.0)
-          + '   [lu: eliminate %.1f  inverses %.1f  T %.1f  products+stores %.1f]' % (
-              (buf[11] - t[8]) / 100.0, (buf[12] - buf[11]) / 100.0, (buf[13] - buf[12]) / 100.0, (t[9] - buf[13]) / 100.0))
+          + '   [lu: load %.1f  eliminate 1 %.1f  inverses 1 %.1f  Schur %.1f  eliminate 2 %.1f  inverses 2 %.1f  off-diagonal %.1f  T %.1f  products+stores %.1f]' % (
+              (buf[14] - t[8]) / 100.0, (buf[15] - buf[14]) / 100.0, (buf[16] - buf[15]) / 100.0, (buf[17] - buf[16]) / 100.0, (buf[18] - buf[17]) / 100.0,
+              (buf[19] - buf[18]) / 100.0, (buf[12] - buf[19]) / 100.0, (buf[13] - buf[12]) / 100.0, (t[9] - buf[13]) / 100.0))
