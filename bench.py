@@ -41,10 +41,11 @@ FAMILIES = ['gemm_kernel<128,128>', 'gemm_kernel<128,32>', 'gemm_kernel<32,128>'
             'rows_times_small_kernel', 'small_t_times_vecs_kernel', 'panel step (cq_fused / cq_gram / cq_pass / cq_post)',
             'lu_reconstruct_kernel', 'qr_aux (diag_qr, assemble_R, init_Q, norms, copies)',
             'svd_aux (norms, init, gather)', 'misc (nfactor, scaling, builders)']
-COUNTERS = {'qr_nominal': 15, 'svd_nominal': 16, 'svd_stream': 17, 'svdvals_nominal': 18}   # counter-only families
+COUNTERS = {'qr_nominal': 15, 'svd_nominal': 16, 'svd_stream': 17, 'svdvals_nominal': 18, 'svd_rounds': 19}   # counter-only families
 PHASES = ['gemm_var (attach / projector / environment GEMMs, scaling)', 'absorb', 'qr', 'svd_trunc', 'svdvals', 'mpo_build']
 MFMA_FAM = {0, 1, 2, 3}
-SERIAL_FAM = {7: ('eig_small_kernel', 'Jacobi step (32 plane rotations of a 64 x 64 Gram matrix in LDS)', 126),
+SERIAL_FAM = {7: ('eig_small_kernel', 'round of the block-Jacobi SVD (pair Gram matrices from LDS, up to 2 x 63 Jacobi steps of 32 plane rotations on the 64 x 64 '
+                   'Gram matrix or its Newton-like fast path, rotation of the vectors in LDS; all rounds of a call in ONE launch, svdl_kernel)', None),
               10: ('panel step (cq_fused / cq_gram / cq_pass / cq_post)',
                    'launch of the panel step (ONE per panel of up to 4096 rows: Gram, 32-step one-wave Cholesky, substitution passes, '
                    'Householder reconstruction and reflector products behind in-kernel barriers; six per taller panel, of which the '
@@ -92,6 +93,7 @@ def phase_report(lib, pmc):
             'hbm_secondary_jacobi_streaming_model_GBps': stream['bytes'] / t_svd / 1e9,
             'hbm_secondary_frac': stream['bytes'] / t_svd / 1e9 / PEAK_HBM_GBS,
             'hbm_tertiary_pmc': tert,
+            'hbm_tertiary_pmc_one_launch_form': (pmc or {}).get('whole_call', {}).get('tn_svd_trunc_192x900_one_launch'),
             'note': 'block Jacobi (32-wide blocks): the pair Gram/apply are MFMA GEMMs on L2/Infinity-Cache-resident data, '
                     'so the streaming model of a column-pair Jacobi overstates the bytes actually moved; the step is '
                     'latency-bound (eig_small: one workgroup per block pair), not HBM-bound'})
@@ -399,10 +401,17 @@ def main():
                          'algorithmic_bytes_per_launch': d['bytes'] / max(1, d['calls'])})
             if dom in SERIAL_FAM:
                 _, what, nser = SERIAL_FAM[dom]
+                if nser is None:             # rounds per launch are data dependent: device-side counter over the same timed region
+                    rounds = _get(lib, -1, COUNTERS['svd_rounds'])
+                    rounds_per_sweep = rounds['calls'] / max(1, args.steps * len(my_rots))
+                    launches_per_sweep = warm_prof[dom]['calls'] if warm_prof is not None else d['calls'] * max(1, args.sample) / max(1, args.steps * len(my_rots))
+                    nser = max(1.0, rounds_per_sweep / max(1, launches_per_sweep))
+                    roof['rounds_per_launch'] = nser
+                    roof['rounds_per_sweep'] = rounds_per_sweep
                 roof['limited_by'] = ('latency: serial steps of a single workgroup / dependent memory round trips (the bytes moved are '
                                       'close to the algorithmic minimum, see traffic); figure of merit = time per serial step')
                 roof['us_per_serial_step'] = 1e3 * avg_ms / nser
-                roof['serial_step'] = '%s, %d per launch' % (what, nser)
+                roof['serial_step'] = '%s, %.1f per launch' % (what, nser)
             fam = (pmc or {}).get('families', {}).get(d['kernel']) if pmc else None
             if fam:
                 roof['traffic'] = fam['traffic_bytes_per_launch']

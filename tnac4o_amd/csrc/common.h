@@ -70,6 +70,7 @@ enum { PROF_GEMM_128x128 = 0, PROF_GEMM_128x32, PROF_GEMM_32x128, PROF_GEMM_64x6
        PROF_SVD_NOMINAL,                 // per tn_svd_trunc call: 14mn^2 + 8n^3 flops, 8(2mn + n^2 + n) bytes
        PROF_SVD_STREAM,                  // per tn_svd_trunc call: calls += executed sweeps, bytes += sweeps*(n-1)*16*n*(m+n)
        PROF_SVDVALS_NOMINAL,             // per tn_svdvals call: 4mn^2 - 4/3 n^3 flops, 8(mn + n) bytes
+       PROF_SVD_ROUNDS,                  // per block-Jacobi SVD: calls += executed rounds (sweeps x rounds per sweep), flops += pair eigenproblems
        PROF_NFAM };
 // phase a launch is attributed to (thread-local; set by the entry points that own a phase)
 enum { PH_OTHER = 0, PH_ABSORB, PH_QR, PH_SVD, PH_SVDVALS, PH_BUILD, PH_N };

@@ -1768,7 +1768,7 @@ int svd_rounds_fused(hipStream_t st, const SvdRoundsJob& j) {
     prof_begin(st, PROF_EIG);
     hipLaunchKernelGGL(svdl_kernel, dim3(ncw + j.ng), dim3(512), 0, st, l);
     TN_CHECK_LAUNCH("svdl_kernel");
-    prof_end(st, PROF_EIG, 0.0, 0.0);
+    prof_end(st, PROF_EIG, 0.0, 16.0 * (double)j.nvp * (double)j.pitch);      // the vectors in and out; what the rounds exchange is not compulsory
     return 0;
 }
 

@@ -638,6 +638,7 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     }
     if (sweeps_out) *sweeps_out = sweeps;
     if (info) *info = converged ? 0 : 1;
+    prof_note(PROF_SVD_ROUNDS, (double)sweeps * nr, (double)sweeps * nr * ng, 0.0);
     if (!fused_done) {
         TN_PROF_LAUNCH(st, PROF_SVD_AUX, hipLaunchKernelGGL(vec_norm2_kernel, dim3((unsigned)nvp), dim3(256), 0, st, w.X, pitch, 1, L, w.norms));
         TN_CHECK_LAUNCH("vec_norm2_kernel");

@@ -76,11 +76,16 @@ for p in range(16):
 fam['panel step (cq_fused / cq_gram / cq_pass / cq_post)'] = {'probe_shape': 'tn_qr 16384 x 1024 (32 panels, %s) + tn_qr 4096 x 512 (16 panels, single-launch form)' % ('six-launch chain' if six_launch else 'single-launch form: 64 workgroups'), 'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
                                    'traffic_bytes_per_launch': (fb + wb) / n, 'algorithmic_bytes_per_launch': alg / n,
                                    'traffic_over_algorithmic': (fb + wb) / alg}
-for name, pat in (('eig_small_kernel', 'eig_small'), ('absorb_kernel', 'absorb_mfma_kernel'), ('sq_kernel (one-launch factorisation)', 'sq_kernel')):
+for name, pat in (('eig_small_kernel', 'svdl_kernel'), ('eig_small3_kernel (rounds as separate launches)', 'eig_small'), ('absorb_kernel', 'absorb_mfma_kernel'),
+                  ('sq_kernel (one-launch factorisation)', 'sq_kernel')):
     ks = [k for k in kern if pat in k]
     if ks:
         k = ks[0]
         fam[name] = dict(kern[k])
+        if pat == 'svdl_kernel':
+            fam[name]['probe_shape'] = 'tn_svd_trunc 192 x 900 (tools/pmc_probe.py): all Jacobi rounds of the call in one launch of svdl_kernel'
+            fam[name]['algorithmic_bytes_per_launch'] = 16.0 * 192 * (900 + 192)
+            fam[name]['traffic_over_algorithmic'] = fam[name]['traffic_bytes_per_launch'] / fam[name]['algorithmic_bytes_per_launch']
 
 # whole-call traffic: everything launched between the probe's markers (segment 1 = tn_qr 16384 x 1024, 4 = tn_svd_trunc)
 qr_bytes = segment_bytes(1)
@@ -103,6 +108,13 @@ sq_bytes = segment_bytes(6) / 16.0
 sq_alg = 8.0 * (2 * 1024 * 64 + 64 * 64)
 whole['tn_qr_1024x64_one_launch'] = {'hbm_bytes': sq_bytes, 'compulsory_bytes': sq_alg, 'traffic_over_compulsory': sq_bytes / sq_alg if sq_alg else None,
                                      'us_unprofiled': times.get('qr_1024x64_one_launch_us')}
+
+# the 192 x 900 truncated SVD whose rounds run in one launch (segment 8): in 8 B per element, U / S / V^T out
+s2_bytes = segment_bytes(8)
+s2_comp = 8.0 * (192 * 900 + 192 * 64 + 64 + 64 * 900)
+whole['tn_svd_trunc_192x900_one_launch'] = {'hbm_bytes': s2_bytes, 'compulsory_bytes': s2_comp, 'traffic_over_compulsory': s2_bytes / s2_comp,
+                                            'ms_unprofiled': times.get('svd_trunc_192x900_ms'), 'sweeps': times.get('svd_192x900_sweeps'),
+                                            'keep': times.get('svd_192x900_keep')}
 
 mfma = {}
 for k in kern:

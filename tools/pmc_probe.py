@@ -4,7 +4,7 @@ of a centre matrix as the sweep produces them (the leading 320 rows of the trian
 i.e. what the rank-revealing QR of a truncating pass hands over: eig_small + pair GEMMs).  Inputs are prepared with torch
 (rocSOLVER / rocBLAS kernels, not counted).  Run under rocprofv3 --pmc in separate passes (tools/collect_profiles.sh);
 tools/pmc_summary.py aggregates the counter CSV per kernel and per SEGMENT: a torch bitwise_xor launch (used nowhere else) marks
-the boundaries -- segment 1 = the 16384 x 1024 QR, 2 = the 4096 x 512 QR, 4 = the truncated SVD, 6 = sixteen one-launch 1024 x 64 QRs -- so that whole-call traffic is the
+the boundaries -- segment 1 = the 16384 x 1024 QR, 2 = the 4096 x 512 QR, 4 = the truncated SVD (320 vectors: rounds as separate launches), 6 = sixteen one-launch 1024 x 64 QRs, 8 = a 192 x 900 truncated SVD (all rounds in one launch) -- so that whole-call traffic is the
 sum over everything launched inside the call.  Prints the un-profiled timings of the QR and the SVD."""
 import json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
@@ -61,6 +61,19 @@ for _ in range(16):
 torch.cuda.synchronize()
 t_sq = (time.perf_counter() - t0) / 16
 marker()
+# a truncated SVD of the class the sweep runs most (192 x 900, chi = 64): all Jacobi rounds in ONE launch with the vectors resident in
+# LDS (svdl_kernel; segment 8)
+_, Rf2 = torch.linalg.qr(G0[:, :200] @ torch.randn(200, 900, dtype=torch.float64, device='cuda'))
+C2 = Rf2[:192].contiguous()
+out2 = ops.svd_trunc(C2, 64, 1e-16)
+torch.cuda.synchronize()
+marker()
+t0 = time.perf_counter()
+out2 = ops.svd_trunc(C2, 64, 1e-16)
+torch.cuda.synchronize()
+t_svd2 = time.perf_counter() - t0
+marker()
 print('done', float(T.sum()), float(Z.sum()), float(Rr.abs().sum()), out[1][:2])
 print('PROBE_TIMES ' + json.dumps({'svd_trunc_320x1024_ms': 1e3 * t_svd, 'svd_sweeps': out[5]['sweeps'], 'svd_keep': out[3],
-                                   'svd_preconditioned': bool(out[5].get('preconditioned')), 'qr_16384x1024_ms': 1e3 * t_qr, 'qr_1024x64_one_launch_us': 1e6 * t_sq}))
+                                   'svd_preconditioned': bool(out[5].get('preconditioned')), 'qr_16384x1024_ms': 1e3 * t_qr, 'qr_1024x64_one_launch_us': 1e6 * t_sq,
+                                   'svd_trunc_192x900_ms': 1e3 * t_svd2, 'svd_192x900_sweeps': out2[5]['sweeps'], 'svd_192x900_keep': out2[3]}))
