@@ -849,6 +849,25 @@ __device__ __forceinline__ bool eig_decide(double gpp, double gqq, double gpq, d
 // Here the workgroup has 8 waves: wave 0 decides the next step's rotations, wave 3 turns its register rows of J, and FIVE waves
 // (1, 2, 4, 5, 6) update G over the 2 x 2 blocks of the upper triangle only (528 instead of 1024 for a 64 x 64 matrix), writing
 // every block and its mirror image, so that G stays exactly symmetric and a thread has two blocks per step instead of eight.
+// -DTN_CLOCKS: thread 0 of group 0 of the persistent SVD kernel accumulates the 100 MHz wall clock per phase of the eigenproblem:
+// [0] partial sums -> G  [1] measure + fast path  [2] cyclic sweeps  [3] Newton-Schulz  [4] store  [5] calls  [6] calls with cyclic sweeps
+#ifdef TN_CLOCKS
+__device__ long long eig_clk[8];
+}  // namespace tn
+extern "C" int tn_debug_eig_clocks(long long* host, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tn::eig_clk), sizeof(long long) * 8);
+    if (reset) { long long z[8] = {}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(tn::eig_clk), z, sizeof(z)); }
+    return rc;
+}
+namespace tn {
+#define EIG_CLK(k) do { if (COH && threadIdx.x == 0 && grp == 0) { const long long now_ = wall_clock64(); eig_clk[k] += now_ - eclk_last_; eclk_last_ = now_; } } while (0)
+#define EIG_CNT(k) do { if (COH && threadIdx.x == 0 && grp == 0) eig_clk[k] += 1; } while (0)
+#define EIG_CLK_INIT long long eclk_last_ = wall_clock64()
+#else
+#define EIG_CLK(k) do {} while (0)
+#define EIG_CNT(k) do {} while (0)
+#define EIG_CLK_INIT do {} while (0)
+#endif
 // (The body is a device function: the standalone kernel below runs it once per launch, the persistent SVD kernels once per Jacobi
 // round.  pool: LDS, 4 x NB x (NB + 1) doubles (the two copies of G, J, and the fast path's R), supplied by the caller, who may use
 // it for something else between calls.  COH: the partial sums / the
@@ -874,6 +893,8 @@ __device__ __forceinline__ void eig_small3_body(double* pool, const int grp, con
     __shared__ double red[512];
     constexpr int NT_ = 512;
     const int tid = threadIdx.x;
+    EIG_CLK_INIT;
+    EIG_CNT(5);
     const double* pg = part + (int64_t)grp * nchunk * nvec * nvec;
     double* G = Gb[0];
     {
@@ -954,6 +975,7 @@ __device__ __forceinline__ void eig_small3_body(double* pool, const int grp, con
         }
         __syncthreads();
     };
+    EIG_CLK(0);
     measure(G);
     if (tid == 0 && maxoff_out) stc(maxoff_out + grp, red[0]);
     // ---- near-diagonal fast path (SVD pair step, 64 x 64): in the quadratic regime -- every relative off-diagonal below fast_thr, which
@@ -1084,6 +1106,8 @@ __device__ __forceinline__ void eig_small3_body(double* pool, const int grp, con
     const bool fast_on = (NB == 64) && mode == 2 && nvec >= 2 && fast_thr > 0.0;
     if (fast_on && red[0] > 8.881784197001252e-16 && red[0] <= fast_thr) fast_try(Gb[0], Gb[1]);
     const bool need = (mode != 1) && (nvec >= 2) && !fast_done && (red[0] > 8.881784197001252e-16);
+    EIG_CLK(1);
+    if (need) EIG_CNT(6);
     int cur = 0;
     if (need) {
         constexpr int HP = NB / 2;
@@ -1345,6 +1369,7 @@ __device__ __forceinline__ void eig_small3_body(double* pool, const int grp, con
         }
         __syncthreads();
     }
+    EIG_CLK(2);
     double* Gf = Gb[cur];                                  // the rotated Gram matrix
     double* Gs = Gb[cur ^ 1];                              // scratch for the Newton-Schulz step
     if (tid == 0 && nrot_out) {
@@ -1401,6 +1426,7 @@ __device__ __forceinline__ void eig_small3_body(double* pool, const int grp, con
         __syncthreads();
     }
     (void)Gf;
+    EIG_CLK(3);
     double* o = out + (int64_t)grp * nvec * nvec;
     for (int e = tid; e < nvec * nvec; e += NT_) {
         const int i = e / nvec, j = e % nvec;
@@ -1412,6 +1438,7 @@ __device__ __forceinline__ void eig_small3_body(double* pool, const int grp, con
         }
         stc(o + e, v);
     }
+    EIG_CLK(4);
 }
 
 template <int NB>
