@@ -109,7 +109,11 @@ int tn_qr_batched(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, doubl
  * _mps_truncateC (:802-811): keep = min(#(S > S0*max(eps,tol)), Dmax), discarded = sqrt(sum S[keep:]^2)/S0.
  * C: k x n.  U: k x keep, S: keep values, Vt: keep x n are written for the first `keep` vectors only; buffers must
  * hold min(k, n, Dmax) vectors.  keep_host/discarded_host/sweeps_host/info_host are HOST pointers (may be NULL
- * except keep_host).  info: 0 converged, 1 sweep cap reached. */
+ * except keep_host).  info: 0 converged, 1 sweep cap reached.
+ * With up to 192 live vectors all Jacobi rounds run in ONE launch with the vectors resident in LDS (svdl_kernel: in-kernel barriers,
+ * within the co-residency budget of the panel step; TN_SVD_FUSED=0 keeps three launches per round): same results bit for bit.  A launch
+ * in which a barrier gave up reports it, the rounds are redone as separate launches inside the same call and the stream stays off the
+ * single-launch forms (message on stderr); nothing non-finite is returned. */
 int tn_svd_trunc(const double* C, int64_t crs, int64_t ccs, int64_t k, int64_t n, int64_t Dmax, double tol, double* U,
                  int64_t urs, int64_t ucs, double* S, double* Vt, int64_t vrs, int64_t vcs, int64_t* keep_host,
                  double* discarded_host, int* sweeps_host, int* info_host, void* ws, int64_t ws_bytes, void* stream);
@@ -262,7 +266,8 @@ int tn_apply_truncation(const double* Al, int64_t ml, int64_t k0, const double* 
  * reset: launches, summed duration (ms), algorithmic flops and bytes (SURVEY.md §8d counts).
  * Counter-only families (no events; active whenever any family is enabled): 15 tn_qr nominal (calls, 4mn^2-4/3n^3,
  * 8(2mn+n^2)), 16 tn_svd_trunc nominal (14mn^2+8n^3, 8(2mn+n^2+n)), 17 Jacobi streaming model (calls = executed
- * sweeps, bytes = sweeps*(n-1)*16*n*(m+n)), 18 tn_svdvals nominal (4mn^2-4/3n^3, 8(mn+n)).
+ * sweeps, bytes = sweeps*(n-1)*16*n*(m+n)), 18 tn_svdvals nominal (4mn^2-4/3n^3, 8(mn+n)), 19 block-Jacobi rounds (calls =
+ * executed rounds of all tn_svd_trunc / tn_svdvals calls, flops = pair eigenproblems).
  * tn_profile_get_phase splits the same totals by the entry point that issued the launch: phase 0 other (attach /
  * projector / environment GEMMs, scaling), 1 tn_absorb, 2 tn_qr, 3 tn_svd_trunc, 4 tn_svdvals, 5 MPO builders;
  * phase -1 = all. */
