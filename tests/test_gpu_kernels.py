@@ -320,6 +320,52 @@ def test_svd_one_launch_rounds_that_give_up_are_redone_as_separate_launches():
     assert 'CHILD_OK' in out and '[libtnpeps]' not in out, out
 
 
+def test_svd_one_launch_rounds_under_uneven_load(ops):
+    """The grid barriers and hand-offs of svdl_kernel (partial Gram matrices, J, status) under uneven load: four chains run truncated
+    SVDs of different shapes on four streams while a fifth keeps the device full of large GEMMs; every result equals the one obtained
+    alone, bit for bit, and no launch gave up (no fallback message would change the bits, so the sweep counts are compared too)."""
+    import threading
+    mats = [dev(_svd_case(128, 300, 1)), dev(_svd_case(192, 600, 2)), dev(_svd_case(192, 900, 1)), dev(_svd_case(100, 1000, 2))]
+    ref = [ops.svd_trunc(T, 64, 1e-8) for T in mats]
+    torch.cuda.synchronize()
+    g = torch.Generator(device='cpu').manual_seed(43)
+    big_a = torch.randn(4096, 4096, dtype=torch.float64, generator=g).cuda()
+    big_b = torch.randn(4096, 4096, dtype=torch.float64, generator=g).cuda()
+    streams = [torch.cuda.Stream() for _ in range(5)]
+    bad, err = [0] * 4, []
+    stop = threading.Event()
+
+    def chain(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(12):
+                    U, S, V, k, d, info = ops.svd_trunc(mats[i], 64, 1e-8)
+                    same = (k == ref[i][3] and d == ref[i][4] and info['sweeps'] == ref[i][5]['sweeps'] and torch.equal(U, ref[i][0])
+                            and torch.equal(S, ref[i][1]) and torch.equal(V, ref[i][2]))
+                    if not same:
+                        bad[i] += 1
+                streams[i].synchronize()
+        except BaseException as e:          # noqa: BLE001
+            err.append(e)
+
+    def load():
+        with torch.cuda.stream(streams[4]):
+            while not stop.is_set():
+                ops.mm(big_a, big_b)
+                streams[4].synchronize()
+    th = [threading.Thread(target=chain, args=(i,)) for i in range(4)]
+    tl = threading.Thread(target=load)
+    tl.start()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    stop.set()
+    tl.join()
+    assert not err, err
+    assert bad == [0, 0, 0, 0], bad
+
+
 def test_svd_triangular_lowrank(ops):
     # the shape the sweep produces: an upper-triangular factor of a numerically low-rank matrix
     rng = np.random.default_rng(21)
