@@ -902,7 +902,11 @@ __device__ __forceinline__ void eig_small3_body(double* pool, const int grp, con
         double acc[EPT];
 #pragma unroll
         for (int t = 0; t < EPT; ++t) acc[t] = 0.0;
-        // four partial sums per memory round trip, added in chunk order (an absent one adds +0.0, which changes nothing: acc is never -0.0)
+        // four partial sums per memory round trip, added in chunk order (an absent one adds +0.0, which changes nothing: acc is never -0.0).
+        // Full pairs of the SVD (64 vectors): only the 16 x 16 tiles on and above the diagonal are read, an element below them is taken
+        // from its mirror image -- the same products summed in the same order, bit for bit -- so the persistent SVD kernel need not
+        // publish the lower tiles at all (a third of what its workgroups exchange).
+        const bool upper_only = (NB == 64) && nvec == 64 && mode == 2;
         for (int c = 0; c < nchunk; c += 4) {
             double v0[EPT], v1[EPT], v2[EPT], v3[EPT];
             const bool two = (c + 1 < nchunk), three = (c + 2 < nchunk), four = (c + 3 < nchunk);
@@ -911,7 +915,8 @@ __device__ __forceinline__ void eig_small3_body(double* pool, const int grp, con
             for (int t = 0; t < EPT; ++t) {
                 const int e = tid + NT_ * t, i = e / NB, j = e % NB;
                 const bool in = (i < nvec && j < nvec);
-                const int64_t o = (int64_t)c * nn + i * nvec + j;
+                const bool mirror = upper_only && (i >> 4) > (j >> 4);
+                const int64_t o = (int64_t)c * nn + (mirror ? j * nvec + i : i * nvec + j);
                 v0[t] = in ? ldc(pg + o) : 0.0;
                 v1[t] = (in && two) ? ldc(pg + o + nn) : 0.0;
                 v2[t] = (in && three) ? ldc(pg + o + 2 * nn) : 0.0;
@@ -1623,22 +1628,26 @@ __global__ __launch_bounds__(512) void svdl_kernel(SvdlArgs a) {
                     const int b0 = s_pairs[2 * z], b1 = s_pairs[2 * z + 1];
                     auto prow = [&](int v) -> int { return v < W ? b0 * W + v : b1 * W + (v - W); };
                     const int ra = prow(ti * 16 + li), rb0 = prow(tj0 * 16 + li), rb1 = prow((tj0 + 1) * 16 + li);
+                    // (the eigenproblem reads the tiles on and above the diagonal only: the others are neither formed nor published)
+                    const bool on0 = ti <= tj0, on1 = ti <= tj0 + 1;          // (wave-uniform)
                     d4l acc0 = d4l{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+                    if (on1) {
 #pragma unroll
-                    for (int k4 = 0; k4 < 16; ++k4) {
-                        const int k = k4 * 4 + lk;
-                        const bool in = c0 + k < a.L;
-                        const double fa = in ? Xc[ra * XP + k] : 0.0;
-                        const double f0 = in ? Xc[rb0 * XP + k] : 0.0, f1 = in ? Xc[rb1 * XP + k] : 0.0;
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, f0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, f1, acc1, 0, 0, 0);
+                        for (int k4 = 0; k4 < 16; ++k4) {
+                            const int k = k4 * 4 + lk;
+                            const bool in = c0 + k < a.L;
+                            const double fa = in ? Xc[ra * XP + k] : 0.0;
+                            const double f0 = in ? Xc[rb0 * XP + k] : 0.0, f1 = in ? Xc[rb1 * XP + k] : 0.0;
+                            if (on0) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, f0, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, f1, acc1, 0, 0, 0);
+                        }
                     }
                     gd o = (gd)(a.part + ((int64_t)z * a.nchunk + blk) * (NB * NB));
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int row = ti * 16 + lk + 4 * q;
-                        __hip_atomic_store(o + row * NB + tj0 * 16 + li, acc0[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(o + row * NB + (tj0 + 1) * 16 + li, acc1[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (on0) __hip_atomic_store(o + row * NB + tj0 * 16 + li, acc0[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (on1) __hip_atomic_store(o + row * NB + (tj0 + 1) * 16 + li, acc1[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
