@@ -903,20 +903,57 @@ __device__ __forceinline__ void eig_small3_body(double* pool, const int grp, con
 #pragma unroll
         for (int t = 0; t < EPT; ++t) acc[t] = 0.0;
         // four partial sums per memory round trip, added in chunk order (an absent one adds +0.0, which changes nothing: acc is never -0.0).
-        // Full pairs of the SVD (64 vectors): only the 16 x 16 tiles on and above the diagonal are read, an element below them is taken
-        // from its mirror image -- the same products summed in the same order, bit for bit -- so the persistent SVD kernel need not
-        // publish the lower tiles at all (a third of what its workgroups exchange).
+        // Full pairs of the SVD (64 vectors): only the ten 16 x 16 tiles on and above the diagonal are read (dealt to the threads tile by
+        // tile, 16 consecutive elements of a row per 16 lanes) and an element below them is the mirror image of its transpose -- the
+        // same products summed in the same order, bit for bit -- so the persistent SVD kernel need not publish the lower tiles at all
+        // (a third of what its workgroups exchange).
         const bool upper_only = (NB == 64) && nvec == 64 && mode == 2;
+        const int64_t nn = (int64_t)nvec * nvec;
+        if (upper_only) {
+            constexpr int UPT = 5;                           // 10 tiles x 256 elements over 512 threads
+            double au[UPT];
+            int ui[UPT], uj[UPT];
+#pragma unroll
+            for (int t = 0; t < UPT; ++t) {
+                const int u = tid + NT_ * t, q = u >> 8, r = (u >> 4) & 15, c2 = u & 15;
+                // tile q of the row-by-row list (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+                const int ti = q < 4 ? 0 : q < 7 ? 1 : q < 9 ? 2 : 3, tj = q < 4 ? q : q < 7 ? q - 3 : q < 9 ? q - 5 : 3;
+                ui[t] = ti * 16 + r; uj[t] = tj * 16 + c2;
+                au[t] = 0.0;
+            }
+            for (int c = 0; c < nchunk; c += 4) {
+                double v0[UPT], v1[UPT], v2[UPT], v3[UPT];
+                const bool two = (c + 1 < nchunk), three = (c + 2 < nchunk), four = (c + 3 < nchunk);
+#pragma unroll
+                for (int t = 0; t < UPT; ++t) {
+                    const int64_t o = (int64_t)c * nn + ui[t] * nvec + uj[t];
+                    v0[t] = ldc(pg + o);
+                    v1[t] = two ? ldc(pg + o + nn) : 0.0;
+                    v2[t] = three ? ldc(pg + o + 2 * nn) : 0.0;
+                    v3[t] = four ? ldc(pg + o + 3 * nn) : 0.0;
+                }
+#pragma unroll
+                for (int t = 0; t < UPT; ++t) au[t] = (((au[t] + v0[t]) + v1[t]) + v2[t]) + v3[t];
+            }
+#pragma unroll
+            for (int t = 0; t < UPT; ++t) {
+                G[ui[t] * P + uj[t]] = au[t];
+                if ((ui[t] >> 4) != (uj[t] >> 4)) G[uj[t] * P + ui[t]] = au[t];
+            }
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) {
+                const int e = tid + NT_ * t, i = e / NB, j = e % NB;
+                J[i * P + j] = (i == j) ? 1.0 : 0.0;
+            }
+        } else {
         for (int c = 0; c < nchunk; c += 4) {
             double v0[EPT], v1[EPT], v2[EPT], v3[EPT];
             const bool two = (c + 1 < nchunk), three = (c + 2 < nchunk), four = (c + 3 < nchunk);
-            const int64_t nn = (int64_t)nvec * nvec;
 #pragma unroll
             for (int t = 0; t < EPT; ++t) {
                 const int e = tid + NT_ * t, i = e / NB, j = e % NB;
                 const bool in = (i < nvec && j < nvec);
-                const bool mirror = upper_only && (i >> 4) > (j >> 4);
-                const int64_t o = (int64_t)c * nn + (mirror ? j * nvec + i : i * nvec + j);
+                const int64_t o = (int64_t)c * nn + i * nvec + j;
                 v0[t] = in ? ldc(pg + o) : 0.0;
                 v1[t] = (in && two) ? ldc(pg + o + nn) : 0.0;
                 v2[t] = (in && three) ? ldc(pg + o + 2 * nn) : 0.0;
@@ -931,6 +968,7 @@ __device__ __forceinline__ void eig_small3_body(double* pool, const int grp, con
             const bool in = (i < nvec && j < nvec);
             G[i * P + j] = in ? acc[t] : (i == j ? 1.0 : 0.0);
             J[i * P + j] = (i == j) ? 1.0 : 0.0;
+        }
         }
     }
     if (tid == 0) total = 0;
