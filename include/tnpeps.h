@@ -240,6 +240,19 @@ int tn_gram_weights(const double* G, int64_t n, double floor_rel, double* d2_out
 int tn_rows_norm2(const double* A, int64_t rows, int64_t cols, double* out, void* stream);
 int tn_gather_scale_rows(const double* A, int64_t rows, int64_t cols, const int64_t* perm, const double* w2, double* out, int inverse,
                          void* stream);
+/* ---- a truncation that cannot truncate (reference: MPS.truncateC, mps.py:562-585 -> _mps_truncateC, mps.py:802-811, as called by the
+ * 4 chi / 2 chi passes of compress_mps, mps.py:192-195).  With min(C.shape) <= Dmax and tol <= eps the reference's rule only removes
+ * singular values below eps S0 and turns the bond into the Schmidt basis; inside an intermediate pass neither is visible afterwards
+ * (the next canonisation step's triangular factor does not depend on an orthogonal change of the bond, the variational sweep is
+ * covariant under it).  tn_bond_deflate removes the same noise without a decomposition: C sits between an orthonormal site Q and a
+ * canonical rest, so zeroing bond index i changes the state by exactly the norm of row (side 0) / column (side 1) i of C; indices are
+ * dropped in ascending order of that norm while the dropped squares add up to at most eps^2 max_i ||C_i||^2 (<= (eps S0)^2), and C and
+ * Q are gathered to the kept indices (in their order).
+ *   side 0 (left sweep):  C (k x n), Q (m x k)  ->  C_out (k' x n), Q_out (m x k')        side 1: C (n x k), Q (k x m) -> (n x k'), (k' x m)
+ * all row-major and contiguous, 1 <= k <= 256.  *k_out_host = k'; when k' == k nothing was written and the caller keeps C and Q.
+ * *dropped2_rel_host = dropped squares / max_i ||C_i||^2.  ws: k doubles.  One read-back (synchronises the stream). */
+int tn_bond_deflate(int side, const double* C, int64_t k, int64_t n, const double* Q, int64_t m, double* C_out, double* Q_out,
+                    int64_t* k_out_host, double* dropped2_rel_host, void* ws, int64_t ws_bytes, void* stream);
 /* out (c, s, c2) = RL (c x a) . A (a, s, a2) . RR (a2 x c2)      (MPS._mps_RAR, mps.py:748-751) */
 int64_t tn_rar_ws_bytes(int64_t c, int64_t a, int64_t s, int64_t a2, int64_t c2);
 int tn_rar(const double* RL, const double* A, const double* RR, int64_t c, int64_t a, int64_t s, int64_t a2, int64_t c2, double* out,

@@ -52,6 +52,7 @@ int site_qr(hipStream_t, int, double*, int64_t, int64_t, int64_t, const double*,
             void*, int64_t, double*, int, int64_t*);
 int gram_weights(hipStream_t, const double*, int64_t, double, double*, double*);
 int rows_norm2(hipStream_t, const double*, int64_t, int64_t, double*);
+int bond_deflate(hipStream_t, int, const double*, int64_t, int64_t, const double*, int64_t, double*, double*, int64_t*, double*, void*, int64_t);
 int gather_scale_rows(hipStream_t, const double*, int64_t, int64_t, const int64_t*, const double*, double*, int);
 int64_t rar_ws_bytes(int64_t, int64_t, int64_t, int64_t, int64_t);
 int rar(hipStream_t, const double*, const double*, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double*, void*, int64_t);
@@ -75,7 +76,7 @@ using namespace tn;
 
 extern "C" {
 
-int tn_version(void) { return 7; }
+int tn_version(void) { return 8; }
 
 #ifndef TN_SRC_HASH
 #define TN_SRC_HASH "unknown"
@@ -372,6 +373,10 @@ int tn_gram_weights(const double* G, int64_t n, double floor_rel, double* d2_out
 int tn_rows_norm2(const double* A, int64_t rows, int64_t cols, double* out, void* stream) {
     TN_CHECK_ARG(rows == 0 || (A && out), "null operand");
     return rows_norm2(ST, A, rows, cols, out);
+}
+int tn_bond_deflate(int side, const double* C, int64_t k, int64_t n, const double* Q, int64_t m, double* C_out, double* Q_out, int64_t* k_out_host,
+                    double* dropped2_rel_host, void* ws, int64_t ws_bytes, void* stream) {
+    return bond_deflate(ST, side, C, k, n, Q, m, C_out, Q_out, k_out_host, dropped2_rel_host, ws, ws_bytes);
 }
 int tn_gather_scale_rows(const double* A, int64_t rows, int64_t cols, const int64_t* perm, const double* w2, double* out, int inverse,
                          void* stream) {

@@ -17,8 +17,10 @@
 #include <cmath>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -44,6 +46,7 @@ int site_qr(hipStream_t, int, double*, int64_t, int64_t, int64_t, const double*,
             void*, int64_t, double*, int, int64_t*);
 int gram_weights(hipStream_t, const double*, int64_t, double, double*, double*);
 int rows_norm2(hipStream_t, const double*, int64_t, int64_t, double*);
+int bond_deflate(hipStream_t, int, const double*, int64_t, int64_t, const double*, int64_t, double*, double*, int64_t*, double*, void*, int64_t);
 int gather_scale_rows(hipStream_t, const double*, int64_t, int64_t, const int64_t*, const double*, double*, int);
 int64_t rar_ws_bytes(int64_t, int64_t, int64_t, int64_t, int64_t);
 int rar(hipStream_t, const double*, const double*, const double*, int64_t, int64_t, int64_t, int64_t, int64_t, double*, void*, int64_t);
@@ -251,6 +254,42 @@ constexpr double CH_RANK_TOL = 1.3877787807814457e-17;      // 2^-56 (ops.RANK_T
 constexpr double CH_PASS1_ACCEPT = 1.3877787807814457e-17;  // 2^-56
 constexpr double CH_PASS1_FLOOR = 1e-14;
 constexpr int64_t CH_PASS1_MIN_BOND = 256;
+
+// TN_CHAIN_PASSES=1 (diagnostics): the stream is synchronised at every pass boundary of compress_mps and the wall time booked per pass;
+// table at exit (the synchronisations cost a few microseconds per pass: not for timed runs).
+namespace {
+struct PassClock {
+    bool on;
+    std::mutex mu;
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long calls = 0;
+    PassClock() { const char* e = getenv("TN_CHAIN_PASSES"); on = e && e[0] == '1'; }
+    ~PassClock() {
+        if (!on || !calls) return;
+        static const char* nm[8] = {"absorb", "pass 1 (canonise_right, weighted)", "pass 2 (canonise_left, 4 chi)", "variational, 1 sweep",
+                                    "pass 3 (canonise_right, 2 chi)", "pass 4 (canonise_left, chi)", "variational, final", "results"};
+        double tot = 0.0;
+        for (double v : ms) tot += v;
+        fprintf(stderr, "[tn_compress_mps passes] %ld calls, %.1f ms in total\n", calls, tot);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, "  %-36s %9.1f ms  %5.1f %%\n", nm[i], ms[i], 100.0 * ms[i] / (tot > 0 ? tot : 1));
+    }
+};
+PassClock g_pass_clock;
+struct PassMark {
+    hipStream_t st;
+    std::chrono::steady_clock::time_point t0;
+    explicit PassMark(hipStream_t s) : st(s) { if (g_pass_clock.on) { (void)hipStreamSynchronize(st); t0 = std::chrono::steady_clock::now(); } }
+    void lap(int k) {
+        if (!g_pass_clock.on) return;
+        (void)hipStreamSynchronize(st);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> lk(g_pass_clock.mu);
+        g_pass_clock.ms[k] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        if (k == 7) g_pass_clock.calls += 1;
+        t0 = t1;
+    }
+};
+}  // namespace
 
 class Chain {
 public:
@@ -510,12 +549,34 @@ public:
         o = res;
         return 0;
     }
+    int pass_id = 0;
+    bool intermediate_pass = false;          // the 4 chi / 2 chi passes of graduate_truncation (their bonds are internal to compress_mps)
     int truncateC(int64_t Dmax, double tol) {
         if (!(0 < pC && pC < L)) return 0;
         const int64_t Dcap = std::min(Dmax, std::min(C.r, C.c));
+        if (intermediate_pass && gauge_svd_skippable(Dmax, tol)) { gauge_skipped += 1; return deflate_bond(); }
         SvdOut o;
         CH(svd_trunc_full(C, Dcap, tol, o));
         const int64_t keep = o.keep;
+        {   // TN_DEFLATE_TRACE=1 (diagnostics): what every truncation kept, next to what tn_bond_deflate would keep of the same bond
+            static const bool trace = [] { const char* e = getenv("TN_DEFLATE_TRACE"); return e && e[0] == '1'; }();
+            if (trace) {
+                const int64_t k = pass_side == 0 ? C.r : C.c, n = pass_side == 0 ? C.c : C.r;
+                int64_t kk = k;
+                if (k >= 2 && k <= 256) {
+                    T3& site = pass_side == 0 ? A[pC - 1] : A[pC];
+                    const int64_t m = pass_side == 0 ? site.a * site.b : site.b * site.c;
+                    M2 Cn; T3 Sn;
+                    CH(new_m2(C.r, C.c, Cn, "trace")); CH(new_t3(site.a, site.b, site.c, Sn, "trace"));
+                    void* w = nullptr;
+                    CH(scratch(3, 8192, w));
+                    double d2 = 0.0;
+                    CH(bond_deflate(st, pass_side, C.p, k, n, site.p, m, Cn.p, Sn.p, &kk, &d2, w, 8192));
+                }
+                fprintf(stderr, "[deflate trace] pass %d bond %lld C %lld x %lld Dmax %lld svd keep %lld deflate keep %lld\n", pass_id, (long long)pC,
+                        (long long)C.r, (long long)C.c, (long long)Dmax, (long long)keep, (long long)kk);
+            }
+        }
         if (keep <= 0) { set_error("tn_compress_mps: centre matrix at bond %lld is zero", (long long)pC); return -5; }
         const int64_t nl = pC - 1, nr = pC;
         const T3 Al = A[nl], Ar = A[nr];
@@ -534,7 +595,51 @@ public:
         discarded[pC] = std::max(discarded[pC], o.disc);
         return 0;
     }
+    // A truncation that cannot truncate.  With min(C.shape) <= Dmax and tol <= eps the rule of mps.py:805-806 only removes singular values
+    // below eps S0 -- rounding noise of the factorisations before it (LAPACK itself resolves a singular value to eps S0) -- and turns the
+    // bond into the Schmidt basis.  Both are invisible outside an INTERMEDIATE pass of graduate_truncation: the next canonisation step
+    // factors C A[n+1], whose triangular factor does not depend on an orthogonal change of the bond between A[n] and C A[n+1] (uniqueness of
+    // QR with diag >= 0), the variational sweep is covariant under it, and the noise directions carry <= sqrt(k) eps of the state's norm,
+    // which the next real truncation removes.  The centre matrix then simply stays with the next site (C = R, no projectors), the bond
+    // keeps the rank the rank-revealing QR accepted.  The final pass (Dmax = chi) always decomposes: its bonds are the result.
+    // TN_GAUGE_SVD=1 keeps every decomposition (A/B and the tests that compare the two forms).
+    int64_t gauge_skipped = 0;
+    bool gauge_svd_skippable(int64_t Dmax, double tol) const {
+        static const int keep_mode = [] { const char* e = getenv("TN_GAUGE_SVD"); return e ? atoi(e) : 0; }();   // 1: all, 2: those of the 2 chi pass
+        if (keep_mode == 1 || (keep_mode == 2 && pass_id == 3)) return false;
+        return tol <= CH_EPS && std::min(C.r, C.c) <= Dmax;
+    }
+    // ... what is left to do at such a bond: drop the bond indices that carry nothing (tn_bond_deflate; TN_BOND_DEFLATE=0: keep them all)
+    int pass_side = 0;                       // 0: left sweep (C = R, bond = rows of C / columns of A[pC-1]), 1: right sweep (C = R^T, bond = columns of C / rows of A[pC])
+    int deflate_bond() {
+        static const bool off = [] { const char* e = getenv("TN_BOND_DEFLATE"); return e && e[0] == '0'; }();
+        const int64_t k = pass_side == 0 ? C.r : C.c, n = pass_side == 0 ? C.c : C.r;
+        if (off || k < 2 || k > 256) return 0;
+        T3& site = pass_side == 0 ? A[pC - 1] : A[pC];
+        const int64_t m = pass_side == 0 ? site.a * site.b : site.b * site.c;
+        if ((pass_side == 0 ? site.c : site.a) != k) { set_error("tn_compress_mps: centre matrix does not fit its site"); return -1; }
+        M2 Cn;
+        T3 Sn;
+        if (pass_side == 0) { CH(new_m2(k, n, Cn, "deflated centre")); CH(new_t3(site.a, site.b, k, Sn, "deflated site")); }
+        else { CH(new_m2(n, k, Cn, "deflated centre")); CH(new_t3(k, site.b, site.c, Sn, "deflated site")); }
+        void* w = nullptr;
+        CH(scratch(3, 8192, w));
+        int64_t kk = k;
+        double d2 = 0.0;
+        CH(bond_deflate(st, pass_side, C.p, k, n, site.p, m, Cn.p, Sn.p, &kk, &d2, w, 8192));
+        if (kk == k) return 0;
+        if (pass_side == 0) { Cn.r = kk; Sn.c = kk; ar.shrink((char*)Cn.p, kk * n * 8); ar.shrink((char*)Sn.p, m * kk * 8); }
+        else { Cn.c = kk; Sn.a = kk; ar.shrink((char*)Cn.p, n * kk * 8); ar.shrink((char*)Sn.p, kk * m * 8); }
+        site = Sn;
+        C = Cn;
+        D[pC] = kk;
+        discarded[pC] = std::max(discarded[pC], std::sqrt(d2));
+        bonds_deflated += k - kk;
+        return 0;
+    }
+    int64_t bonds_deflated = 0;
     int canonise_left(bool compress, int64_t Dmax, double tol) {
+        pass_side = 0;
         CH(ones11(C));
         pC = 0;
         for (int64_t n = 0; n < L; ++n) {
@@ -546,6 +651,7 @@ public:
         return 0;
     }
     int canonise_right(bool compress, int64_t Dmax, double tol) {
+        pass_side = 1;
         CH(ones11(C));
         pC = L;
         for (int64_t n = L - 1; n >= 0; --n) {
@@ -1036,6 +1142,7 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
     ch.hconj = hconj;
     const bool weighted = (flags & 1) != 0, structured = (flags & 2) != 0, lazy = (flags & 4) != 0;
     int rc;
+    PassMark pm(st);
     // ---- apply_mpo (mps.py:353-359): K1 into the arena; the factors are kept for the structured Gram recursion
     bool any_mpo = false;
     if (mpo_host && mpo_dims_host) {
@@ -1074,6 +1181,7 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
         ch.D[n + 1] = ch.A[n].c;
     }
     if (!any_mpo || !structured) { ch.facA.clear(); ch.facW.clear(); }
+    pm.lap(0);
     // ---- compress_mps (mps.py:175-200)
     const int64_t Dbig = *std::max_element(ch.D.begin(), ch.D.end());
     for (int64_t d : ch.D) ch.bonds_before += d;
@@ -1095,13 +1203,24 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
     const std::vector<T3> phi = ch.A;                              // shares the buffers: later passes replace psi's sites, never write them
     std::fill(ch.discarded.begin(), ch.discarded.end(), 0.0);
     for (int64_t i = 0; i <= L; ++i) if ((rc = ch.ones11(ch.R[i]))) return rc;
+    pm.lap(1);
     if (graduate) {
+        ch.intermediate_pass = true;
+        ch.pass_id = 2;
         if ((rc = ch.canonise_left(true, Dmax * 4, tolS / 10))) return rc;
+        pm.lap(2);
         if ((rc = ch.variational_compress(phi, tolV, 1, lazy))) return rc;
+        pm.lap(3);
+        ch.pass_id = 3;
         if ((rc = ch.canonise_right(true, Dmax * 2, tolS / 2))) return rc;
+        ch.intermediate_pass = false;
+        pm.lap(4);
     }
+    ch.pass_id = 4;
     if ((rc = ch.canonise_left(true, Dmax, tolS))) return rc;
+    pm.lap(5);
     if ((rc = ch.variational_compress(phi, tolV, max_sweeps, lazy))) return rc;
+    pm.lap(6);
     // ---- results
     for (int64_t n = 0; n < L; ++n) {
         const T3& t = ch.A[n];
@@ -1110,6 +1229,7 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
         if (e != hipSuccess) return hip_fail(e, "copy result");
         out_dims_host[3 * n] = t.a; out_dims_host[3 * n + 1] = t.b; out_dims_host[3 * n + 2] = t.c;
     }
+    pm.lap(7);
     if (overlap_host) *overlap_host = ch.overlap;
     if (discarded_host) for (int64_t i = 0; i <= L; ++i) discarded_host[i] = ch.discarded[i];
     if (schmidt_host && schmidt_len_host) {
@@ -1138,7 +1258,7 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
         info_host[4] = (double)ch.bonds_before;
         info_host[5] = (double)ch.bonds_after;
         info_host[6] = 0.0;
-        info_host[7] = 0.0;
+        info_host[7] = (double)ch.gauge_skipped;
     }
     // the results are copied out of the arena by the stream; the caller may reuse the arena for the next call on the SAME stream at once
     return 0;

@@ -8,6 +8,8 @@
 //   tn_rar               MPS._mps_RAR  (mps.py:748-751)           optimise_site of the variational sweep
 //   tn_env_mix           MPS._mps_RL / _mps_RR (mps.py:655-663)   mixed environments
 //   tn_apply_truncation  projectors of truncateC into the neighbouring sites + diagonal centre (mps.py:579-583)
+#include <algorithm>
+
 #include "common.h"
 
 namespace tn {
@@ -261,6 +263,117 @@ int gather_scale_rows(hipStream_t st, const double* A, int64_t rows, int64_t col
     else
         TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(gather_scale_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, A, cols, perm, w2, out));
     TN_CHECK_LAUNCH("gather_scale_rows_kernel");
+    return 0;
+}
+
+// ---- deflation of a bond whose centre matrix cannot be truncated (chain.hip: gauge_svd_skippable) ------------------------------
+// An intermediate pass of graduate_truncation meets bonds at which mps.py:805-806 cannot truncate (min(C.shape) <= Dmax, tol <= eps): its
+// SVD would only remove singular values below eps S0.  The same noise is removed here without a decomposition.  The centre matrix sits
+// between an orthonormal site and a canonical rest, so the state's norm is ||C||_F and zeroing bond index i changes the state by exactly
+// the norm of row (side 0) / column (side 1) i of C.  The indices are dropped in ascending order of that norm for as long as the dropped
+// squares add up to at most eps^2 max_i ||C_i||^2 <= (eps S0)^2 -- no more than ONE singular value at the reference's threshold would
+// carry -- and C and the neighbouring site are gathered to the kept indices (kept in their order).
+//   side 0 (left sweep):  C (k x n) row-major, bond = rows;     Q (m x k) row-major, bond = columns  -> C_out (k' x n), Q_out (m x k')
+//   side 1 (right sweep): C (n x k) row-major, bond = columns;  Q (k x m) row-major, bond = rows     -> C_out (n x k'), Q_out (k' x m)
+// k <= 256.  *k_out = k' (host); nothing is written when k' == k.  ws: k doubles.  One read-back.
+struct KeepList { int idx[256]; };
+__global__ __launch_bounds__(256) void bond_norm2_kernel(const double* __restrict__ C, int64_t vs, int64_t es, int64_t len, double* __restrict__ out) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const double* c = C + (int64_t)blockIdx.x * vs;
+    double s = 0.0;
+    for (int64_t j = tid; j < len; j += 256) { const double x = c[j * es]; s += x * x; }
+    red[tid] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+    if (tid == 0) out[blockIdx.x] = red[0];
+}
+// out[j, :] = in[idx[j], :]   (row-major, `cols` columns; one workgroup per kept row)
+__global__ __launch_bounds__(256) void gather_rows_idx_kernel(const double* __restrict__ in, int64_t cols, KeepList kl, double* __restrict__ out) {
+    const double* a = in + (int64_t)kl.idx[blockIdx.x] * cols;
+    double* o = out + (int64_t)blockIdx.x * cols;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) o[c] = a[c];
+}
+// out[r, j] = in[r, idx[j]]   (row-major rows x kin -> rows x kout; the index list sits in LDS)
+__global__ __launch_bounds__(256) void gather_cols_idx_kernel(const double* __restrict__ in, int64_t rows, int kin, int kout, KeepList kl,
+                                                              double* __restrict__ out) {
+    __shared__ int idx[256];
+    if (threadIdx.x < kout) idx[threadIdx.x] = kl.idx[threadIdx.x];
+    __syncthreads();
+    const int64_t total = rows * kout;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / kout;
+        const int j = (int)(e - r * kout);
+        out[e] = in[r * kin + idx[j]];
+    }
+}
+int bond_deflate(hipStream_t st, int side, const double* C, int64_t k, int64_t n, const double* Q, int64_t m, double* C_out, double* Q_out,
+                 int64_t* k_out, double* dropped2_rel_out, void* ws, int64_t ws_bytes) {
+    TN_CHECK_ARG(side == 0 || side == 1, "side must be 0 (left sweep) or 1 (right sweep)");
+    TN_CHECK_ARG(C && Q && C_out && Q_out && k_out && ws, "null operand");
+    TN_CHECK_ARG(k >= 1 && k <= 256 && n >= 1 && m >= 1, "bad dimensions (1 <= k <= 256)");
+    TN_CHECK_ARG(ws_bytes >= k * 8, "workspace too small");
+    double* dn = (double*)ws;
+    if (side == 0) TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(bond_norm2_kernel, dim3((unsigned)k), dim3(256), 0, st, C, n, 1, n, dn));
+    else TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(bond_norm2_kernel, dim3((unsigned)k), dim3(256), 0, st, C, 1, k, n, dn));
+    TN_CHECK_LAUNCH("bond_norm2_kernel");
+    double h[256];
+    {
+        hipError_t e;
+        double* stage = (double*)pinned_host((size_t)k * 8, 2);
+        if ((e = hipMemcpyAsync(stage ? stage : h, dn, (size_t)k * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(e, "memcpy norms");
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync norms");
+        if (stage) memcpy(h, stage, (size_t)k * 8);
+    }
+    double nmax = 0.0;
+    for (int64_t i = 0; i < k; ++i) {
+        if (!(h[i] == h[i]) || h[i] > 1.7e308) { set_error("bond_deflate: non-finite centre matrix"); return -2; }
+        if (h[i] > nmax) nmax = h[i];
+    }
+    *k_out = k;
+    if (dropped2_rel_out) *dropped2_rel_out = 0.0;
+    if (!(nmax > 0.0) || k == 1) return 0;
+    int order[256];
+    for (int i = 0; i < (int)k; ++i) order[i] = i;
+    // ascending norms, ties by index (insertion sort: k <= 256, and the list is nearly sorted for a triangular factor read backwards)
+    for (int i = 1; i < (int)k; ++i) {
+        const int v = order[i];
+        int j = i - 1;
+        while (j >= 0 && (h[order[j]] > h[v] || (h[order[j]] == h[v] && order[j] > v))) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = v;
+    }
+    const double eps = 2.220446049250313e-16;
+    const double budget = eps * eps * nmax;
+    bool drop[256];
+    for (int i = 0; i < (int)k; ++i) drop[i] = false;
+    double acc = 0.0;
+    int ndrop = 0;
+    for (int t = 0; t < (int)k - 1; ++t) {
+        const double v = h[order[t]];
+        if (!(acc + v <= budget)) break;
+        acc += v;
+        drop[order[t]] = true;
+        ++ndrop;
+    }
+    if (ndrop == 0) return 0;
+    KeepList kl;
+    int kk = 0;
+    for (int i = 0; i < (int)k; ++i) if (!drop[i]) kl.idx[kk++] = i;
+    for (int i = kk; i < 256; ++i) kl.idx[i] = 0;
+    const int64_t rowsA = side == 0 ? m : n;           // the operand gathered by columns: Q (m x k) resp. C (n x k)
+    const double* colsrc = side == 0 ? Q : C;
+    double* coldst = side == 0 ? Q_out : C_out;
+    const double* rowsrc = side == 0 ? C : Q;          // the operand gathered by rows: C (k x n) resp. Q (k x m)
+    double* rowdst = side == 0 ? C_out : Q_out;
+    const int64_t rowlen = side == 0 ? n : m;
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(gather_rows_idx_kernel, dim3((unsigned)kk), dim3(256), 0, st, rowsrc, rowlen, kl, rowdst));
+    TN_CHECK_LAUNCH("gather_rows_idx_kernel");
+    const int64_t total = rowsA * kk;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 2048);
+    TN_PROF_LAUNCH(st, PROF_MISC, hipLaunchKernelGGL(gather_cols_idx_kernel, dim3(grid), dim3(256), 0, st, colsrc, rowsA, (int)k, kk, kl, coldst));
+    TN_CHECK_LAUNCH("gather_cols_idx_kernel");
+    *k_out = kk;
+    if (dropped2_rel_out) *dropped2_rel_out = acc / nmax;
     return 0;
 }
 

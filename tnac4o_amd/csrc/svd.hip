@@ -514,6 +514,18 @@ static int jacobi_core(hipStream_t st, const double* M, int64_t vs, int64_t es, 
     for (int64_t i = 0; i < nv; ++i)
         if (hn[i] > thr) live.push_back((int)i);
     if (live.empty()) live.push_back(0);                      // all-zero input: one (zero) vector
+    {   // TN_SVD_NORMS=1 (diagnostics): how the input vectors' norms are spread below the largest one
+        static const bool norms_trace = [] { const char* e = getenv("TN_SVD_NORMS"); return e && e[0] == '1'; }();
+        if (norms_trace) {
+            int c[7] = {0, 0, 0, 0, 0, 0, 0};
+            const int ex[7] = {-56, -54, -53, -52, -50, -44, -30};
+            for (int64_t i = 0; i < nv; ++i)
+                for (int t = 0; t < 7; ++t)
+                    if (hn[i] > nmax * std::ldexp(1.0, 2 * ex[t])) ++c[t];
+            fprintf(stderr, "[tn_svd norms] nv=%lld L=%lld above 2^-56:%d -54:%d -53:%d -52:%d -50:%d -44:%d -30:%d\n", (long long)nv, (long long)L,
+                    c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
+        }
+    }
     // de Rijk ordering: vectors enter the tournament sorted by decreasing norm, so that the blocks are graded (large
     // vectors meet large ones first) -- the classical remedy for the slow start of Jacobi on strongly graded matrices.
     // Only the initial order changes (TN_SVD_SORT=0 keeps the input order for A/B measurements).

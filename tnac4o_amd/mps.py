@@ -442,6 +442,18 @@ class MPS:
             if tol is None:
                 tol = self.zero
             Dcap = int(min(Dmax, min(self.C.shape)))
+            if (getattr(self, '_intermediate_pass', False) and not ops.GAUGE_SVD and tol <= np.finfo(float).eps
+                    and min(self.C.shape) <= Dmax):
+                # a truncation that cannot truncate (chain.hip: gauge_svd_skippable): it would only remove singular values below
+                # eps S0 and turn the bond into the Schmidt basis, neither of which is visible outside an intermediate pass --
+                # the centre matrix stays with the next site, less the bond indices that carry nothing (tn_bond_deflate)
+                if ops.BOND_DEFLATE:
+                    side = self._pass_side
+                    ns = self.pC - 1 if side == 0 else self.pC
+                    self.C, self.A[ns], kk, d2 = ops.bond_deflate(side, self.C, self.A[ns])
+                    self.D[self.pC] = kk
+                    self.discarded[self.pC] = max(self.discarded[self.pC], float(np.sqrt(d2)))
+                return 0.0
             U, S, Vt, keep, disc, _ = ops.svd_trunc(self.C, Dcap, tol)
             nl, nr = self.pC - 1, self.pC
             if ops.FUSED_SITE and keep > 0:
@@ -461,6 +473,7 @@ class MPS:
         """mps.py:202-218."""
         self.C = torch.ones((1, 1), dtype=torch.float64, device=self.A[0].device)
         self.pC = 0
+        self._pass_side = 0
         for n in range(self.L):
             # truncating pass: left part canonical, right part canonical -> the scale of C is the Schmidt scale, so rows of
             # R below 2^-56 of it can be skipped already in the QR (they are deflated by the SVD of truncateC)
@@ -478,6 +491,7 @@ class MPS:
         """mps.py:220-236."""
         self.C = torch.ones((1, 1), dtype=torch.float64, device=self.A[0].device)
         self.pC = self.L
+        self._pass_side = 1
         for n in range(self.L - 1, -1, -1):
             rank_tol = ops.RANK_TOL if (compress and 0 < n < self.L) else 0.0
             if ops.FUSED_SITE:
@@ -779,8 +793,12 @@ class MPS:
         phi = self.copy()
         self.discarded = [0] * (self.L + 1)
         if graduate_truncation:
-            self.canonise_left(compress=True, Dmax=Dmax * 4, tol=tolS / 10)
-            self.variational_compress(phi, tol=tolV, max_sweeps=1)
-            self.canonise_right(compress=True, Dmax=Dmax * 2, tol=tolS / 2)
+            self._intermediate_pass = True
+            try:
+                self.canonise_left(compress=True, Dmax=Dmax * 4, tol=tolS / 10)
+                self.variational_compress(phi, tol=tolV, max_sweeps=1)
+                self.canonise_right(compress=True, Dmax=Dmax * 2, tol=tolS / 2)
+            finally:
+                self._intermediate_pass = False
         self.canonise_left(compress=True, Dmax=Dmax, tol=tolS)
         return self.variational_compress(phi, tol=tolV, max_sweeps=max_sweeps)

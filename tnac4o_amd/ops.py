@@ -494,6 +494,7 @@ def weighted_sum(a, b):
 
 
 NATIVE_CHAIN = os.environ.get('TN_NATIVE_CHAIN', '1') != '0'     # compress_mps (and the absorption in front of it) as one library call
+GAUGE_SVD = os.environ.get('TN_GAUGE_SVD', '0') == '1'           # keep the decompositions of the intermediate passes that cannot truncate (chain.hip: gauge_svd_skippable)
 _arena = {}
 
 
@@ -580,8 +581,43 @@ def compress_mps_native(sites, mpo_sites, hconj, Dmax, tolS, tolV, max_sweeps, g
         k = int(slen[i])
         S.append(None if k < 0 else np.array(sch[i * pitch:i * pitch + k], dtype=np.float64))
     return dict(A=A, overlap=float(overlap.value), discarded=[float(x) for x in disc], S=S, nfs=[nfs[i] for i in range(int(ncount.value))],
-                info=dict(reveal_error_bound=float(info[0]), reveal_fallbacks=int(info[1]), weighted_used=bool(info[2]), arena_peak=int(info[3]), bonds_before=int(info[4]), bonds_after=int(info[5]),
+                info=dict(reveal_error_bound=float(info[0]), reveal_fallbacks=int(info[1]), weighted_used=bool(info[2]), arena_peak=int(info[3]), bonds_before=int(info[4]), bonds_after=int(info[5]), redone=int(info[6]), gauge_skipped=int(info[7]),
                           arena_bytes=int(arena.numel())))
+
+
+BOND_DEFLATE = os.environ.get('TN_BOND_DEFLATE', '1') != '0'
+
+
+def bond_deflate(side, Cm, site):
+    """tn_bond_deflate: drop the bond indices between the centre matrix and its orthonormal site that carry at most eps^2 of the
+    largest one's weight in total (see include/tnpeps.h).  side 0: Cm (k, n), site (Dl, p, k); side 1: Cm (n, k), site (k, p, Dr).
+    Returns (Cm', site', k', dropped2_rel); the inputs themselves when nothing is dropped."""
+    _need_gpu(Cm)
+    Cm = Cm if Cm.is_contiguous() else Cm.contiguous()
+    site = site if site.is_contiguous() else site.contiguous()
+    if side == 0:
+        k, n = Cm.shape
+        m = site.shape[0] * site.shape[1]
+        assert site.shape[2] == k
+    else:
+        n, k = Cm.shape
+        m = site.shape[1] * site.shape[2]
+        assert site.shape[0] == k
+    if k < 2 or k > 256:
+        return Cm, site, k, 0.0
+    Co = torch.empty_like(Cm)
+    So = torch.empty_like(site)
+    ws = workspace(8192, 3)
+    kk = C.c_int64(k)
+    d2 = C.c_double(0.0)
+    check(lib().tn_bond_deflate(side, Cm.data_ptr(), k, n, site.data_ptr(), m, Co.data_ptr(), So.data_ptr(), C.byref(kk), C.byref(d2),
+                                ws.data_ptr(), 8192, _stream()))
+    kk = int(kk.value)
+    if kk == k:
+        return Cm, site, k, 0.0
+    if side == 0:
+        return Co.view(-1)[:kk * n].view(kk, n), So.view(-1)[:m * kk].view(site.shape[0], site.shape[1], kk), kk, float(d2.value)
+    return Co.view(-1)[:n * kk].view(n, kk), So.view(-1)[:kk * m].view(kk, site.shape[1], site.shape[2]), kk, float(d2.value)
 
 
 def rar(RL, A, RR):
