@@ -1200,3 +1200,48 @@ def test_barrier_timeouts_recovered_bit_identical_to_the_multi_launch_forms():
     assert out_t.count('[libtnpeps]') >= 2 and '[libtnpeps]' not in out_c, (out_t, out_c)
     dig = lambda o: [l for l in o.splitlines() if l.startswith('DIGEST')][0]
     assert dig(out_t) == dig(out_c), (out_t, out_c)
+
+
+@pytest.mark.parametrize('shape', [(256, 16, 24, 40), (1024, 16, 40, 100), (300, 8, 33, 70), (64, 4, 100, 20)])
+def test_pivoted_site_qr_device_selection(ops, shape):
+    """The pivoted, truncating site QR of the weighted first pass (tn_site_qr side 1, Frobenius exit, panel pivoting) with the pivots
+    chosen on the device (pivot_select_kernel: norms added up, exit test, rank counting, swap list and permutation in device memory,
+    the host one panel ahead) against the host selection (TN_PIVOT_DEVICE=0): Q orthonormal, Q^T-form factors reproduce the permuted
+    input up to the dropped block, the dropped norm is what is really left, and both forms accept the same rank (ties aside they
+    choose the same columns: R agrees to rounding)."""
+    Dl, p, r, keep = shape
+    g = torch.Generator(device='cpu').manual_seed(5 + Dl)
+    m = p * r
+    nr = min(Dl, m, 3 * keep)
+    U = torch.linalg.qr(torch.randn((Dl, nr), generator=g, dtype=torch.float64))[0]
+    V = torch.linalg.qr(torch.randn((m, nr), generator=g, dtype=torch.float64))[0]
+    sv = torch.logspace(0, -20, nr, dtype=torch.float64)
+    B = ((U * sv[None, :]) @ V.t())
+    B = B[torch.argsort(B.norm(dim=1), descending=True)].contiguous()
+    tol = float(sv[min(keep, nr - 1)])
+    outs = []
+    for mode in ('1', '0'):
+        info = {}
+        Bd = B.cuda().view(Dl, p, r).clone()
+        Qt, Ct, k, _ = _with_env('TN_PIVOT_DEVICE', mode, lambda: ops.site_qr(1, Bd, None, rank_tol=tol, normalise=False, info=info,
+                                                                                frobenius_exit=True, pivot=True))
+        perm = info['perm'].cpu().numpy()
+        assert sorted(perm.tolist()) == list(range(Dl))
+        Qh, Ch = Qt.cpu().numpy(), Ct.cpu().numpy()              # Q^T (k x m), R^T (Dl x k): B[perm]^T = Q R  <=>  B[perm] = R^T Q^T
+        assert np.abs(Qh @ Qh.T - np.eye(k)).max() < 1e-13
+        Bp = B.numpy()[perm]
+        # factored in the pivoted order: R^T is lower trapezoidal (row j of R^T = input column perm[j])
+        assert np.abs(np.triu(Ch[:k, :k], 1)).max() <= 1e-13 * np.abs(Ch).max()
+        res = Bp - Ch @ Qh
+        fro = np.linalg.norm(B.numpy())
+        assert abs(np.linalg.norm(res) - np.sqrt(info['dropped2'])) <= 1e-12 * fro + 1e-3 * np.sqrt(info['dropped2'])
+        assert np.linalg.norm(res) <= tol * fro * 1.0000001 or k == min(m, Dl)
+        assert np.all(np.diag(Ch[:k, :k]) >= 0)
+        outs.append((k, perm, Ch, info['dropped2']))
+    (k1, p1, C1, d1), (k0, p0, C0, d0) = outs
+    assert k1 == k0
+    if np.array_equal(p1[:k1], p0[:k0]):            # (the columns behind the accepted ones may sit in another order: compare by input column)
+        A1, A0 = np.empty_like(C1), np.empty_like(C0)
+        A1[p1], A0[p0] = C1, C0
+        assert np.abs(A1[:, :k1] - A0[:, :k0]).max() <= 1e-12 * np.abs(C0).max()
+        assert abs(d1 - d0) <= 1e-9 * max(d0, 1e-300)

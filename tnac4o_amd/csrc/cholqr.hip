@@ -663,13 +663,14 @@ __device__ __forceinline__ int cq_load_scaled_tile(const double* __restrict__ X,
 
 // ---- pass 0: Gram matrix of the input panel -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cq_gram_kernel(const double* __restrict__ X, int64_t rs, int64_t cs, int64_t nrows, int b, int nblk,
-                                                      double* part, int* bexp, CqState* stt, double* Rg, int slot) {
+                                                      double* part, int* bexp, CqState* stt, double* Rg, int slot, const int* active) {
     __shared__ double T[CQ_RB * CQ_P];
     __shared__ double Gs[32 * CQ_P];
     __shared__ __attribute__((aligned(16))) double Rs[32 * 32];
     __shared__ double red[4];
     __shared__ int s_ticket;
     const int tid = threadIdx.x, blk = blockIdx.x;
+    if (active && *active == 0) return;                      // the factorisation this panel belongs to has stopped (device-side exit test, qr.hip)
     int64_t r0;
     int nr;
     cq_block_rows(nrows, nblk, blk, r0, nr);
@@ -761,13 +762,14 @@ __device__ __forceinline__ void cq_store_tile(const double* T, double* Y, int64_
 // first: the source is the caller's panel (scaled by 2^-emax on the way in), later passes work in place on Y.
 __global__ __launch_bounds__(256) void cq_pass_kernel(const double* Xsrc, int64_t srs, int64_t scs, double* Y, int64_t rs, int64_t cs,
                                                       int64_t nrows, int b, int nblk, int first, int launch_no, double* part, CqState* stt,
-                                                      double* Rg, uint64_t seed, double* lu, double* Tp, int maxpass, int slot) {
+                                                      double* Rg, uint64_t seed, double* lu, double* Tp, int maxpass, int slot, const int* active) {
     __shared__ double T[CQ_RB * CQ_P];
     __shared__ double Gs[32 * CQ_P];
     __shared__ __attribute__((aligned(16))) double Rs[32 * 32 + 32 + 32 * 32];      // factor + reciprocals | Cholesky rows of the tail
     __shared__ int s_ticket;
     __shared__ int s_st[4];
     const int tid = threadIdx.x, blk = blockIdx.x;
+    if (active && *active == 0) return;
     CQ_CLK_DECL;
     CQ_CLK(0);
     int64_t r0;
@@ -988,12 +990,13 @@ __device__ __forceinline__ void cq_post_tile(int blk, int nblk, int64_t nrows, i
 
 __global__ __launch_bounds__(256) void cq_post_kernel(const double* X, int64_t xrs, int64_t xcs, double* Y, int64_t rs, int64_t cs, int64_t nrows,
                                                       int b, int nblk, CqState* stt, double* lu, double* Tp, double* W, int64_t wrs, int64_t wcs,
-                                                      double* Wq) {
+                                                      double* Wq, const int* active) {
     __shared__ double tile[CQ_RB * CQ_P];
     __shared__ double Ss[3 * 1024];
     __shared__ double scr[4 * 32 * 33 + 64];
     __shared__ int s_st[2];
     const int tid = threadIdx.x, blk = blockIdx.x;
+    if (active && *active == 0) return;
     if (tid == 0) { s_st[0] = cq_ldi(&stt->fallback); s_st[1] = cq_ldi(&stt->emax); }
     __syncthreads();
     if (!s_st[0]) {
@@ -1238,7 +1241,11 @@ __device__ __forceinline__ int cq_slice_reduce(const double* part, const int* be
 __global__ __launch_bounds__(256) void cq_fused_kernel(const double* X, int64_t xrs, int64_t xcs, double* Y, int64_t rs, int64_t cs, int64_t nrows,
                                                        int b, int nblk, double* part, int* bexp, double* topblk, CqState* stt, int base,
                                                        uint64_t seed, double* lu_all, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq,
-                                                       int maxpass, int slot, unsigned spin_limit, double* gsum) {
+                                                       int maxpass, int slot, unsigned spin_limit, double* gsum, const int* active) {
+    if (active && *active == 0) {                            // the factorisation has stopped (device-side exit test, qr.hip): every workgroup leaves,
+        if (threadIdx.x == 0) atomicAdd(&stt->fcounter, (maxpass + 1) * (nblk > CQ_SLICE_FROM ? 2 : 1));      // its arrivals booked as the host counted them
+        return;
+    }
     __shared__ double T[CQ_RB * CQ_P];
     __shared__ __attribute__((aligned(16))) double GR[3 * 1024];      // Gram 32 x 33 | factor 1024 + 32; later the three S matrices of the post step
     __shared__ __attribute__((aligned(16))) double scr[4 * 32 * 33 + 64];
@@ -1655,7 +1662,7 @@ static void cq_capture(hipStream_t st, const double* X, int64_t irs, int64_t ics
 // in the launch slots that would otherwise return at once.
 int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws,
                  int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq, int* fused_base,
-                 void* state) {
+                 void* state, const int* active) {
     TN_CHECK_ARG(b >= 1 && b <= 32, "panel width must be <= 32");
     TN_CHECK_ARG(nrows >= b, "panel must have at least b rows");
     TN_CHECK_ARG(ws_bytes >= cholqr_ws_bytes(nrows, b), "workspace too small");
@@ -1696,7 +1703,7 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
         // leaves LDS in between; flops: Gram + post at launch time, the passes are booked from the device counter (cq_stats[3])
         prof_begin(st, PROF_TSQR);
         hipLaunchKernelGGL(cq_fused_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, part, bexp, topblk, stt,
-                           *fused_base, seed, lu, Tp, W, wrs, wcs, Wq, maxpass, slot, spin_limit, gsum);
+                           *fused_base, seed, lu, Tp, W, wrs, wcs, Wq, maxpass, slot, spin_limit, gsum, active);
         TN_CHECK_LAUNCH("cq_fused_kernel");
         if (tall) { cq_big_launched(st, slot); big_lock.unlock(); }
         *fused_base += (maxpass + 1) * nblk * (nblk > CQ_SLICE_FROM ? 2 : 1);
@@ -1706,20 +1713,20 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
         return 0;
     }
     prof_begin(st, PROF_TSQR);
-    hipLaunchKernelGGL(cq_gram_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, nrows, b, nblk, part, bexp, stt, Rg, slot);
+    hipLaunchKernelGGL(cq_gram_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, nrows, b, nblk, part, bexp, stt, Rg, slot, active);
     TN_CHECK_LAUNCH("cq_gram_kernel");
     prof_end(st, PROF_TSQR, 2.0 * nrows * b * b, 8.0 * nrows * b);
     for (int t = 1; t <= maxpass; ++t) {
         prof_begin(st, PROF_TSQR);
         hipLaunchKernelGGL(cq_pass_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, t == 1 ? 1 : 0, t, part, stt,
-                           Rg, seed + 0x9E3779B97F4A7C15ULL * (uint64_t)t, lu, Tp, maxpass, slot);
+                           Rg, seed + 0x9E3779B97F4A7C15ULL * (uint64_t)t, lu, Tp, maxpass, slot, active);
         TN_CHECK_LAUNCH("cq_pass_kernel");
         // (the passes that really run are booked from the device counter cq_stats[7] by the caller of tn_panel_stats:
         //  3 n b^2 flops and 16 n b bytes per applied pass; a launch that finds the panel converged moves nothing)
         prof_end(st, PROF_TSQR, 0.0, 0.0);
     }
     prof_begin(st, PROF_TSQR);
-    hipLaunchKernelGGL(cq_post_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, stt, lu, Tp, W, wrs, wcs, Wq);
+    hipLaunchKernelGGL(cq_post_kernel, dim3(nblk), dim3(256), 0, st, X, irs, ics, Y, rs, cs, nrows, b, nblk, stt, lu, Tp, W, wrs, wcs, Wq, active);
     TN_CHECK_LAUNCH("cq_post_kernel");
     prof_end(st, PROF_TSQR, reconstruct ? (Wq ? 6.0 : 4.0) * nrows * b * b : 0.0, reconstruct ? (Wq ? 32.0 : 24.0) * nrows * b : 0.0);
     cq_capture(st, X, irs, ics, nrows, b, stt);
@@ -1728,7 +1735,7 @@ int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, doub
 
 int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows,
                           int b, void* ws, int64_t ws_bytes, uint64_t seed, int* fused_base, void* state) {
-    return cholqr_panel(st, X, irs, ics, Y, rs, cs, nrows, b, ws, ws_bytes, seed, 0, nullptr, nullptr, 0, 0, nullptr, fused_base, state);
+    return cholqr_panel(st, X, irs, ics, Y, rs, cs, nrows, b, ws, ws_bytes, seed, 0, nullptr, nullptr, 0, 0, nullptr, fused_base, state, nullptr);
 }
 
 // diagnostics: state block of the last panel (synchronises the stream) and the process-wide counters

@@ -190,7 +190,7 @@ int cholqr_orthonormalize(hipStream_t st, const double* X, int64_t irs, int64_t 
 // the whole panel step: orthonormal basis, and with reconstruct != 0 the Householder reconstruction (Y, T, W = Y T^T, Wq = Y T)
 int cholqr_panel(hipStream_t st, const double* X, int64_t irs, int64_t ics, double* Y, int64_t rs, int64_t cs, int64_t nrows, int b, void* ws,
                  int64_t ws_bytes, uint64_t seed, int reconstruct, double* Tp, double* W, int64_t wrs, int64_t wcs, double* Wq, int* fused_base,
-                 void* state = nullptr);
+                 void* state = nullptr, const int* active = nullptr);       // active (DEVICE, may be null): 0 = every launch of this panel returns at once
 // launches with in-kernel barriers (cq_fused_kernel, sq_kernel): co-residency budget and time-outs, see cholqr.hip
 bool fused_forms_allowed(hipStream_t st, int nwg);
 void fused_forms_disable(hipStream_t st);

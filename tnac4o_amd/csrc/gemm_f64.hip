@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP g) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int zb = blockIdx.y;
     if (e >= mn) return;
+    if (g.skip && g.skip[zb] == 0) return;
     const double* W = g.ws + (int64_t)zb * g.splitk * mn + e;
     double s = 0.0;
     int k = 0;
@@ -400,7 +401,7 @@ static int gemm_ex_impl(hipStream_t st, int64_t M, int64_t N, int64_t K, double 
     // order (element by element: the same K sequence, the same splits) with C^T row-major -- full 128-byte segments.  Not for the
     // block-pair indirection / raw partials of the Jacobi SVD, whose index maps and partial layout are tied to the operand roles.
     static const bool swap_on = [] { const char* e = getenv("TN_GEMM_SWAP"); return !(e && e[0] == '0'); }();
-    if (swap_on && rsc == 1 && csc != 1 && N > 1 && !(x && (x->pairs || x->raw_partials || x->skip)))
+    if (swap_on && rsc == 1 && csc != 1 && N > 1 && !(x && (x->pairs || x->raw_partials)))          // (skip flags are per batch item: they follow)
         return gemm_ex_impl(st, N, M, K, alpha, B, csb, rsb, A, csa, rsa, beta, C, csc, rsc, batch, bsb, bsa, bsc, ws, ws_bytes, x);
     GemmP g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;

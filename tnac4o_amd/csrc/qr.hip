@@ -828,6 +828,7 @@ struct QrWs {
     double *T, *X, *X2, *part, *Js, *Uinv, *Z, *Tri, *gemm_ws, *cn;
     int* dead;
     int* pairs;          // swap list of the pivoted panel step (2 nb ints)
+    char* piv;           // PivState + int permutation (device-side panel pivoting)
     int64_t gemm_ws_bytes;
     void* tsqr_ws;
     int64_t tsqr_bytes;
@@ -855,6 +856,7 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     int* dead = (int*)take(nb * 4);
     double* cn = (double*)take(2 * n * 8);            // column norms^2: [input | current trailing block]
     int* pairs = (int*)take((int64_t)2 * nb * 4);
+    char* piv = (char*)take(1024 + n * 4);           // PivState | permutation (int) of the device-side panel pivoting
     // split-K scratch for the tall TN products (b x n, K = m)
     int64_t gw = (int64_t)64 * nb * (n > k ? n : k) * 8;      // upper bound of pick_splitk's partial buffers
     {   // ... and of the outer-block products (NBO x n', K = m) of the two-level path: pick_splitk asks for about 512 tiles of
@@ -879,7 +881,7 @@ static int64_t qr_layout(int64_t m, int64_t n, int nb, char* base, QrWs* w) {
     if (w) { w->tsqr_ws = tsw; w->tsqr_bytes = tsb; }
     if (w) { w->Wq = Wq; w->W = Wp; w->W2 = Wp2; w->UT = UT; w->UTq = UTq; w->gemm_ws2 = gws2; }
     if (w) { w->Y = Y; w->T = T; w->X = X; w->X2 = X2; w->part = part; w->Js = Js; w->Uinv = Uinv; w->Z = Z; w->Tri = Tri;
-             w->dead = dead; w->gemm_ws = gws; w->gemm_ws_bytes = gw; w->cn = cn; w->pairs = pairs; }
+             w->dead = dead; w->gemm_ws = gws; w->gemm_ws_bytes = gw; w->cn = cn; w->pairs = pairs; w->piv = piv; }
     return off;
 }
 
@@ -1029,6 +1031,163 @@ static void select_pivots(double* hcn, int64_t ntr, int b, int64_t j0, int64_t* 
     }
 }
 
+// ---- panel pivoting decided on the device ---------------------------------------------------------------------------------------
+// The host-side selection above cost a read-back of the residual norms, a stream synchronisation and the host's tournament per panel --
+// ~25 us of idle device in the one phase of a row where the host was still inside the chain (2 550 panels per sweep).  Here ONE workgroup
+// takes the decisions: it adds the residual norms up (fixed order), applies the exit test, ranks the columns (rank counting in LDS), turns
+// the b largest into the same "successive swaps" the host made (step t: the t-th largest goes to position t) and leaves the moves they
+// amount to, the permutation and the verdict in device memory.  Every later launch of the factorisation -- column swap, panel step,
+// trailing update -- looks at `active` and returns at once after the exit.  The host runs one panel ahead: it reads the verdict of panel
+// p - 1 (32 bytes, copied behind the selection launch) before it enqueues panel p, so an exit costs one panel's worth of empty launches
+// instead of a synchronisation per panel.  Ties between equal norms go to the lower ORIGINAL position (the host took the lower CURRENT
+// one): only exact ties differ.  TN_PIVOT_DEVICE=0 keeps the host selection.
+struct PivHead { int active, k_exit, stamp, swap_n; double scale2, dropped2; };      // what the host reads back (32 bytes)
+struct PivState { PivHead h; int ticket; int pad[3]; int sel[32]; int dst[64]; int src[64]; };
+constexpr int PIV_MAXN = 4096;
+__device__ __forceinline__ void piv_sti(int* q, int v) { __hip_atomic_store((__attribute__((address_space(1))) int*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int piv_ldi(const int* q) { return __hip_atomic_load((const __attribute__((address_space(1))) int*)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ __launch_bounds__(256) void pivot_init_kernel(PivState* S, int* __restrict__ perm, int n) {      // once per factorisation
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) perm[i] = i;
+    if (i < (int)(sizeof(PivState) / 4)) ((int*)S)[i] = 0;
+}
+// grid = ceil(ntr / 16) workgroups.  Every workgroup adds up all norms (same order: same sum everywhere) and applies the exit test; then it
+// ranks ITS 16 columns against all (16 threads per column, a sixteenth of the comparisons each -- fp64 compares: the loop is VALU-bound)
+// and publishes the ones among the b largest; the last workgroup to finish (ticket) turns the selection into moves with one wave:
+//   position t < b receives the t-th largest column; the front columns that are not selected go, in ascending order, to the positions
+//   the selected columns from behind the front vacate, in ascending order; nothing else moves.
+// The kernel is a chain of dependent memory round trips (~2 us each): state and norms are fetched together, the permutation is
+// brought up to date by the column swap that follows (swap_columns_dev_kernel), not here.
+// mail (page-locked HOST memory): the verdict for the host as ONE 8-byte word, (stamp << 32) | (active << 31) | columns accepted, written
+// with a relaxed system-scope store -- no copy launch, no event, no release fence; the dropped norm is read at the end of the call
+struct PivMail { unsigned long long word; };
+__device__ __forceinline__ void piv_post(PivMail* mail, int active, int k_exit, unsigned stamp) {
+    const unsigned long long w = ((unsigned long long)stamp << 32) | ((unsigned long long)(active ? 1u : 0u) << 31) | (unsigned long long)(unsigned)k_exit;
+    __hip_atomic_store(&mail->word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+constexpr int PIV_CPB = 16;         // columns per workgroup
+__global__ __launch_bounds__(256) void pivot_select_kernel(const double* __restrict__ cn, int ntr, int b, int j0, int p, double tol2, PivState* S,
+                                                           PivMail* mail, unsigned stamp) {
+    __shared__ double v[PIV_MAXN];
+    __shared__ double red[256];
+    __shared__ int cnt[16][PIV_CPB];
+    __shared__ int vpos[32];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, blk = blockIdx.x, nblk = gridDim.x;
+    // one round trip: the state words and this thread's norms
+    const int act = (p > 0) ? S->h.active : 1;
+    const double scale_prev = (p > 0) ? S->h.scale2 : 0.0;
+    double part = 0.0;
+    for (int j = tid; j < ntr; j += 256) {
+        const double x = cn[j];
+        part += x;                                            // (a NaN stays a NaN in the sum: the exit test then fails, as on the host)
+        v[j] = (x == x) ? x : -1.0;                           // ... and never wins a selection
+    }
+    if (act == 0) {                                           // (written by an earlier launch: the same answer in every workgroup)
+        if (blk == 0 && tid == 0) piv_post(mail, 0, S->h.k_exit, stamp);
+        return;
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+    const double fro2 = red[0];
+    const double scale2 = (p == 0) ? fro2 : scale_prev;
+    if (p > 0 && fro2 <= tol2 * scale2) {                     // what is left is below the threshold: stop before this panel
+        if (blk == 0 && tid == 0) {
+            S->h.k_exit = j0; S->h.dropped2 = fro2; S->h.stamp = p + 1; S->h.swap_n = 0; S->h.active = 0;
+            piv_post(mail, 0, j0, stamp);
+        }
+        return;
+    }
+    {
+        const int c = tid & (PIV_CPB - 1), q = tid / PIV_CPB, j = blk * PIV_CPB + c;       // q: 0 .. 15
+        const double mine = j < ntr ? v[j] : -2.0;
+        const int chunk = (ntr + 15) >> 4, i0 = q * chunk, i1 = (i0 + chunk < ntr) ? i0 + chunk : ntr;
+        int r = 0;
+        int i = i0;
+        for (; i + 8 <= i1; i += 8) {                         // eight LDS reads in flight
+            double o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = v[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r += (o[u] > mine || (o[u] == mine && i + u < j)) ? 1 : 0;
+        }
+        for (; i < i1; ++i) { const double o = v[i]; r += (o > mine || (o == mine && i < j)) ? 1 : 0; }
+        cnt[q][c] = r;
+        __syncthreads();
+        if (q == 0 && j < ntr) {
+            int rank = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) rank += cnt[u][c];
+            if (rank < b) piv_sti(&S->sel[rank], j);
+        }
+    }
+    // (the selections are agent-scope stores: they go through to memory, the publisher only waits for their completion -- no release
+    //  fence, which would write back the XCD's L2; the last workgroup reads them with agent-scope loads)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&S->ticket, 1) == nblk - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    const int lane = tid;                                     // (the first wave decides; the barriers below are reached by all 256 threads)
+    const int st = (lane < b) ? piv_ldi(&S->sel[lane]) : -1;  // original trailing position of the lane-th largest column
+    bool selfront = false;
+    int rankV = 0;
+    const bool isV = lane < b && st >= b;
+    if (lane < 64) {
+        for (int t = 0; t < b; ++t) {
+            const int x = __shfl(st, t, 64);
+            selfront = selfront || x == lane;
+            rankV += (isV && x >= b && x < st) ? 1 : 0;
+        }
+    }
+    const bool isD = lane < b && !selfront;
+    const bool mv1 = lane < b && st != lane;
+    unsigned long long bD = 0ull, b1 = 0ull;
+    if (lane < 64) { bD = __ballot(isD); b1 = __ballot(mv1); }
+    if (isV) vpos[rankV] = st;
+    __syncthreads();
+    const unsigned long long below = (lane < 64) ? ((1ull << lane) - 1ull) : 0ull;
+    const int n1 = __popcll(b1), nD = __popcll(bD);
+    if (mv1) { const int i = __popcll(b1 & below); S->dst[i] = j0 + lane; S->src[i] = j0 + st; }
+    if (isD) { const int i = __popcll(bD & below); S->dst[n1 + i] = j0 + vpos[i]; S->src[n1 + i] = j0 + lane; }
+    if (tid == 0) {
+        S->ticket = 0;
+        S->h.swap_n = n1 + nD;
+        S->h.k_exit = j0 + b;
+        S->h.stamp = p + 1;
+        if (p == 0) { S->h.scale2 = fro2; S->h.dropped2 = 0.0; }
+        S->h.active = 1;
+        piv_post(mail, 1, j0 + b, stamp);
+    }
+}
+// the moves of the selection applied to every row: 64 rows per workgroup, the (at most 64) moves dealt to 4 threads per row, all values
+// of a workgroup's rows fetched before the first one is stored (the moves permute columns: sources and destinations overlap)
+// (the workgroup after the last one applies the moves to the permutation: perm[dst] <- perm[src])
+__global__ __launch_bounds__(256) void swap_columns_dev_kernel(double* __restrict__ A, int64_t rs, int64_t cs, int64_t m, const PivState* __restrict__ S,
+                                                               int* __restrict__ perm) {
+    if (S->h.active == 0) return;
+    const int ns = S->h.swap_n;
+    if (ns == 0) return;
+    if (blockIdx.x == gridDim.x - 1) {
+        int old = 0;
+        if ((int)threadIdx.x < ns) old = perm[S->src[threadIdx.x]];
+        __syncthreads();
+        if ((int)threadIdx.x < ns) perm[S->dst[threadIdx.x]] = old;
+        return;
+    }
+    const int g = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool in = r < m;
+    double* row = A + (in ? r : 0) * rs;
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int t = g * 16 + i; v[i] = (in && t < ns) ? row[(int64_t)S->src[t] * cs] : 0.0; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int t = g * 16 + i; if (in && t < ns) row[(int64_t)S->dst[t] * cs] = v[i]; }
+}
 // Look-ahead (aux != nullptr, nb = 32): the trailing update of panel p is split.  The columns of the next panel (and the
 // panel's own) are updated on the caller's stream, which then factors panel p+1 right away -- a chain of latency-bound
 // single-workgroup kernels -- while the device-filling update of everything to the right of it runs on `aux`.  Ordering:
@@ -1229,12 +1388,66 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
         }
         return 0;
     };
+    // device-side panel pivoting (see pivot_select_kernel): the host runs one panel ahead of the verdicts it reads back
+    const bool piv_dev_on = [] { const char* e = getenv("TN_PIVOT_DEVICE"); return !(e && e[0] == '0'); }();      // (read per call: the tests switch it)
+    const bool piv_dev = pivot && piv_dev_on && n <= PIV_MAXN && !lookahead && !use_tsqr;
+    PivState* pst = (PivState*)w.piv;
+    int* pperm = (int*)(w.piv + 1024);
+    const int* active = piv_dev ? &pst->h.active : nullptr;
+    PivMail* ring = piv_dev ? (PivMail*)pinned_host(4 * sizeof(PivMail), 7) : nullptr;
+    if (piv_dev && !ring) { set_error("tn_qr: no page-locked memory for the pivoting verdicts"); return 1; }
+    thread_local unsigned piv_seq = 0;                        // stamps are unique per host thread (the ring is the thread's own; wrap-around after 2^32 panels is harmless: four entries)
+    const unsigned seq0 = piv_seq;
+    if (piv_dev) piv_seq += (unsigned)P + 1u;
+    bool piv_stopped = false;
+    GemmExtra gx_active;
+    gx_active.skip = active;
+    // verdict of panel q (the selection launch in front of it): true = the exit test fired there
+    auto piv_verdict = [&](int q, bool& stop) -> int {
+        const PivMail* h = &ring[q & 3];
+        const unsigned want = seq0 + (unsigned)q + 1u;
+        unsigned long long wd = __atomic_load_n(&h->word, __ATOMIC_ACQUIRE);
+        for (long spins = 0; (unsigned)(wd >> 32) != want; ++spins) {
+            if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) != hipErrorNotReady) {          // the stream has drained (or failed): look once more, then give up
+                wd = __atomic_load_n(&h->word, __ATOMIC_ACQUIRE);
+                if ((unsigned)(wd >> 32) == want) break;
+                set_error("tn_qr: the pivoting verdict of panel %d never arrived", q);
+                return 1;
+            }
+            wd = __atomic_load_n(&h->word, __ATOMIC_ACQUIRE);
+        }
+        stop = ((wd >> 31) & 1ull) == 0ull;
+        if (stop) {
+            k = (int64_t)(wd & 0x7fffffffull);
+            P = (int)(k / nb);
+            piv_stopped = true;
+        }
+        return 0;
+    };
+    if (piv_dev) {
+        TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(pivot_init_kernel, dim3((unsigned)cdiv(std::max<int64_t>(n, 256), 256)), dim3(256), 0, st, pst, pperm, (int)n));
+        TN_CHECK_LAUNCH("pivot_init_kernel");
+    }
     for (int p = 0; p < P; ++p) {
         const int64_t j0 = (int64_t)p * nb;
         const int b = (int)((k - j0 < nb) ? k - j0 : nb);
         const int64_t mp = m - j0, ntr = n - j0;
         Mat Ap = sub(Am, j0, j0), Yp = sub(Ym, j0, j0);
-        if (pivot) {
+        if (piv_dev) {
+            if (p >= 1) {
+                bool stop = false;
+                if ((rc = piv_verdict(p - 1, stop))) return rc;
+                if (stop) break;
+            }
+            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_kernel, dim3((unsigned)ntr), dim3(256), 0, st, Ap.p, rs, cs, mp, ntr, w.cn));
+            TN_CHECK_LAUNCH("colnorm2_kernel");
+            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(pivot_select_kernel, dim3((unsigned)cdiv(ntr, PIV_CPB)), dim3(256), 0, st, (const double*)w.cn, (int)ntr, b, (int)j0, p,
+                               rank_tol * rank_tol, pst, &ring[p & 3], seq0 + (unsigned)p + 1u));
+            TN_CHECK_LAUNCH("pivot_select_kernel");
+            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(swap_columns_dev_kernel, dim3((unsigned)cdiv(m, 64) + 1), dim3(256), 0, st, A, rs, cs, m,
+                               (const PivState*)pst, pperm));
+            TN_CHECK_LAUNCH("swap_columns_dev_kernel");
+        } else if (pivot) {
             TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(colnorm2_kernel, dim3((unsigned)ntr), dim3(256), 0, st, Ap.p, rs, cs, mp, ntr, w.cn));
             TN_CHECK_LAUNCH("colnorm2_kernel");
             std::vector<double> hcn_pageable;
@@ -1267,7 +1480,7 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
             double* Tpf = w.T + (int64_t)p * nb * nb;
             Mat Wpf = sub(Wqm, j0, j0);
             if ((rc = cholqr_panel(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, (uint64_t)p + 1, 1, Tpf, Wpf.p, yrs, ycs,
-                                   nullptr, &fbase, w.cq_state)))
+                                   nullptr, &fbase, w.cq_state, active)))
                 return rc;
         } else if (nb == 32) {
             if ((rc = panel_orthonormalize(st, Ap.p, rs, cs, Yp.p, yrs, ycs, mp, b, w.tsqr_ws, w.tsqr_bytes, use_tsqr, (uint64_t)p + 1, &fbase, w.cq_state))) return rc;
@@ -1335,8 +1548,16 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
             if ((rc = join_wide())) return rc;
         }
         Mat Xm = mat(w.X, nnar, 1);
+        if (piv_dev) {         // (the same two products, skipped on the device once the exit test has fired)
+            const Mat Yt = tr(Yp);
+            if ((rc = gemm_ex(st, b, nnar, mp, 1.0, Yt.p, Yt.rs, Yt.cs, Ap.p, Ap.rs, Ap.cs, 0.0, Xm.p, Xm.rs, Xm.cs, 1, 0, 0, 0, w.gemm_ws, w.gemm_ws_bytes,
+                              &gx_active)))
+                return rc;
+            if ((rc = gemm_ex(st, mp, nnar, b, -1.0, Wp.p, Wp.rs, Wp.cs, Xm.p, Xm.rs, Xm.cs, 1.0, Ap.p, Ap.rs, Ap.cs, 1, 0, 0, 0, nullptr, 0, &gx_active))) return rc;
+        } else {
         if ((rc = gemm(st, b, nnar, mp, 1.0, tr(Yp), Ap, 0.0, Xm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
         if ((rc = gemm(st, mp, nnar, b, -1.0, Wp, Xm, 1.0, Ap))) return rc;
+        }
         if (reveal && (p & 1) == 1 && p + 1 < P) {
             if ((rc = join_wide())) return rc;                  // the norms below read the whole trailing block
             const int64_t j1 = j0 + b;
@@ -1375,6 +1596,21 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
         }
     }
     if ((rc = join_wide())) return rc;
+    if (piv_dev) {
+        // the last panel's own verdict (it may have stopped the factorisation in front of itself), then the permutation
+        if (P >= 1 && k == kfull) {
+            bool stop = false;
+            if ((rc = piv_verdict(P - 1, stop))) return rc;
+        }
+        // state block (1024 bytes, for the dropped norm) and permutation are neighbours in the workspace: one copy
+        std::vector<int> hp_pageable;
+        int* hp = (int*)pinned_host(1024 + (size_t)n * 4, 0);
+        if (!hp) { hp_pageable.resize(256 + (size_t)n); hp = hp_pageable.data(); }
+        if ((he = hipMemcpyAsync(hp, w.piv, 1024 + (size_t)n * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(he, "memcpy permutation");
+        if ((he = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(he, "sync permutation");
+        for (int64_t j = 0; j < n; ++j) pivot_perm_host[j] = hp[256 + j];
+        if (piv_stopped && dropped2_host) *dropped2_host = ((const PivState*)hp)->h.dropped2;
+    }
     if (keff_host) *keff_host = k;
     // --- triangularise the diagonal blocks, assemble R
     if (nb == 32) TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL((diag_qr_kernel<32>), dim3(P), dim3(256), 0, st, A, rs, cs, nb, k, w.Z, w.Tri, (int*)w.cq_state));

@@ -42,5 +42,5 @@ for t in tot:
         if t.get('bytes') and t['ms']:
             extra += '  %.0f GB/s' % (t['bytes'] / t['ms'] / 1e6)
         print('   %-60s %6d launches %8.3f ms%s' % (t['kernel'], t['calls'], t['ms'], extra))
-err = (Q.t() @ Q - torch.eye(k, dtype=torch.float64, device='cuda')).abs().max()
+err = (Q @ Q.t() - torch.eye(k, dtype=torch.float64, device="cuda")).abs().max()
 print('orthonormality of the basis: %.2e' % float(err))
