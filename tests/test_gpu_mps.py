@@ -553,6 +553,10 @@ def test_weighted_first_pass_matches_plain_pass(L, chi):
     res = []
     saved = ops.PASS1_WEIGHTED, os.environ.get('TN_QR_NBO')
     mps.MPS._compress_native = spy
+    # (the comparison is about the FIRST pass: the later stages run the same way in all three runs -- the shortcuts that depend on
+    #  what the 4 chi pass met, see test_pass_shortcuts_match_full_passes, would take different branches behind a plain first pass)
+    saved_sw = {k: os.environ.get(k) for k in ('TN_VAR_TARGET', 'TN_VAR1_SKIP')}
+    os.environ['TN_VAR_TARGET'], os.environ['TN_VAR1_SKIP'] = 'phi', '0'
     try:
         # plain pass twice (two-level and single-level QR blocking: a pure rounding-level change), then the weighted pass
         for weighted, nbo in ((False, '256'), (False, '0'), (True, '256')):
@@ -570,6 +574,11 @@ def test_weighted_first_pass_matches_plain_pass(L, chi):
         else:
             os.environ['TN_QR_NBO'] = saved[1]
         mps.MPS._compress_native = orig
+        for k, v in saved_sw.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     a, a2, b = res
     assert bounds and all(ok and 0.0 <= e <= 2.0 ** -57 for ok, e in bounds)
     print('bond sums before / after the weighted pass:', bonds)
@@ -589,6 +598,48 @@ def test_weighted_first_pass_matches_plain_pass(L, chi):
         worst = max(worst, got / (1e-13 + 3.0 * max(spread, 0.0)))
         assert got < 1e-13 + 3.0 * max(spread, 0.0)
     print('fidelity, weighted vs plain: largest (1 - F) / allowance = %.3f' % worst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('L,chi', [(128, 32), (512, 32), (2048, 64)])
+def test_pass_shortcuts_match_full_passes(L, chi, monkeypatch):
+    """The three shortcuts of the intermediate stages of compress_mps (csrc/chain.hip) against the reference's full sequence
+    (mps.py:187-199) run with the same kernels: (i) no decomposition at a bond of the 4 chi / 2 chi pass where the truncation rule cannot
+    truncate (min(C.shape) <= Dmax, tol <= eps: only singular values below eps S0 would go) -- the bond indices that carry nothing are
+    dropped by their norms instead (tn_bond_deflate); (ii) a 4 chi pass that truncated nothing leaves phi itself with smaller bonds: that
+    copy is the target of the variational sweeps; (iii) the one sweep of the 4 chi stage towards the state itself is not run.  All three
+    change the state by O(L eps): the compressed boundary MPS of every row are the same states (fidelity >= 1 - 1e-13), the overlaps agree
+    to 1e-12, the bonds up to the decisions that fall on the eps floor, and the discarded weights to 1e-6 relative or the first-order
+    bound of what an O(L eps) change of the state does to the tail of its Schmidt spectrum (sqrt(tail) x 1e-14 S0 ~ 2e-13)."""
+    from tnac4o_amd.auxx import synthetic_chimera
+    kw = dict(graduate_truncation=True, Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20)
+    res = []
+    for full in (True, False):
+        if full:
+            monkeypatch.setenv('TN_GAUGE_SVD', '1'); monkeypatch.setenv('TN_VAR_TARGET', 'phi'); monkeypatch.setenv('TN_VAR1_SKIP', '0')
+        else:
+            for k in ('TN_GAUGE_SVD', 'TN_VAR_TARGET', 'TN_VAR1_SKIP'):
+                monkeypatch.delenv(k, raising=False)
+        s = gpu_solver(L=L, rot=0) if L < 2048 else gpu_solver(L=L, J=synthetic_chimera(16, 16, 20260004))
+        s._setup_rhoT(**kw)
+        res.append(s)
+    a, b = res
+    info = [m.native_info for m in b.rhoT if m is not None and hasattr(m, 'native_info')]
+    if L == 2048:
+        assert sum(i['gauge_skipped'] for i in info) > 100 and sum(i['var1_skipped'] for i in info) >= 10        # the shortcuts are what ran
+    np.testing.assert_allclose(np.array(a.rhoT_overlap, dtype=float), np.array(b.rhoT_overlap, dtype=float), rtol=0, atol=1e-12)
+    da, db = (np.array(x.rhoT_discarded, dtype=float) for x in (a, b))
+    allow = 1e-6 * da + 2e-13
+    print('discarded weights, shortcuts vs full passes: largest |difference| / allowance = %.3f' % float((np.abs(db - da) / allow).max()))
+    assert np.all(np.abs(db - da) <= allow), (da, db)
+    worst = 0.0
+    for x, y in zip(a.rhoT, b.rhoT):
+        if x is None:
+            continue
+        worst = max(worst, 1.0 - fidelity(host_chain(x), host_chain(y)))
+        assert max(abs(p - q) for p, q in zip(x.D, y.D)) <= 2, (x.D, y.D)
+    print('1 - fidelity, shortcuts vs full passes: largest %.2e' % worst)
+    assert worst < 1e-13
 
 
 @pytest.mark.gpu

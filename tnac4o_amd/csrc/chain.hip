@@ -550,6 +550,7 @@ public:
         return 0;
     }
     int pass_id = 0;
+    bool pass_truncated = false;             // a truncation of the current pass discarded more than rounding noise (> 32 eps S0)
     bool intermediate_pass = false;          // the 4 chi / 2 chi passes of graduate_truncation (their bonds are internal to compress_mps)
     int truncateC(int64_t Dmax, double tol) {
         if (!(0 < pC && pC < L)) return 0;
@@ -558,6 +559,7 @@ public:
         SvdOut o;
         CH(svd_trunc_full(C, Dcap, tol, o));
         const int64_t keep = o.keep;
+        if (o.disc > 32.0 * CH_EPS) pass_truncated = true;          // this pass has changed the state by more than rounding
         {   // TN_DEFLATE_TRACE=1 (diagnostics): what every truncation kept, next to what tn_bond_deflate would keep of the same bond
             static const bool trace = [] { const char* e = getenv("TN_DEFLATE_TRACE"); return e && e[0] == '1'; }();
             if (trace) {
@@ -604,15 +606,16 @@ public:
     // keeps the rank the rank-revealing QR accepted.  The final pass (Dmax = chi) always decomposes: its bonds are the result.
     // TN_GAUGE_SVD=1 keeps every decomposition (A/B and the tests that compare the two forms).
     int64_t gauge_skipped = 0;
+    int target_swapped = 0, var1_skipped = 0;
     bool gauge_svd_skippable(int64_t Dmax, double tol) const {
-        static const int keep_mode = [] { const char* e = getenv("TN_GAUGE_SVD"); return e ? atoi(e) : 0; }();   // 1: all, 2: those of the 2 chi pass
+        const int keep_mode = [] { const char* e = getenv("TN_GAUGE_SVD"); return e ? atoi(e) : 0; }();   // 1: all, 2: those of the 2 chi pass (read per call: the tests switch it)
         if (keep_mode == 1 || (keep_mode == 2 && pass_id == 3)) return false;
         return tol <= CH_EPS && std::min(C.r, C.c) <= Dmax;
     }
     // ... what is left to do at such a bond: drop the bond indices that carry nothing (tn_bond_deflate; TN_BOND_DEFLATE=0: keep them all)
     int pass_side = 0;                       // 0: left sweep (C = R, bond = rows of C / columns of A[pC-1]), 1: right sweep (C = R^T, bond = columns of C / rows of A[pC])
     int deflate_bond() {
-        static const bool off = [] { const char* e = getenv("TN_BOND_DEFLATE"); return e && e[0] == '0'; }();
+        const bool off = [] { const char* e = getenv("TN_BOND_DEFLATE"); return e && e[0] == '0'; }();
         const int64_t k = pass_side == 0 ? C.r : C.c, n = pass_side == 0 ? C.c : C.r;
         if (off || k < 2 || k > 256) return 0;
         T3& site = pass_side == 0 ? A[pC - 1] : A[pC];
@@ -638,15 +641,18 @@ public:
         return 0;
     }
     int64_t bonds_deflated = 0;
+    std::vector<M2> pass_C;                  // the centre matrix a truncating left pass leaves at every bond (index = bond)
     int canonise_left(bool compress, int64_t Dmax, double tol) {
         pass_side = 0;
         CH(ones11(C));
         pC = 0;
+        pass_C.assign((size_t)L + 1, M2());
         for (int64_t n = 0; n < L; ++n) {
             const double rank_tol = (compress && 0 < n + 1 && n + 1 < L) ? CH_RANK_TOL : 0.0;
             const M2 Cm = C;
             CH(site_left(n, &Cm, rank_tol));
             if (compress) CH(truncateC(Dmax, tol));
+            if (compress && intermediate_pass) pass_C[pC] = C;
         }
         return 0;
     }
@@ -1201,15 +1207,41 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
     ch.facA.clear(); ch.facW.clear();
     for (int64_t d : ch.D) ch.bonds_after += d;
     const std::vector<T3> phi = ch.A;                              // shares the buffers: later passes replace psi's sites, never write them
+    std::vector<T3> phi_small;
+    const std::vector<T3>* target = &phi;
     std::fill(ch.discarded.begin(), ch.discarded.end(), 0.0);
     for (int64_t i = 0; i <= L; ++i) if ((rc = ch.ones11(ch.R[i]))) return rc;
     pm.lap(1);
     if (graduate) {
         ch.intermediate_pass = true;
         ch.pass_id = 2;
+        ch.pass_truncated = false;
         if ((rc = ch.canonise_left(true, Dmax * 4, tolS / 10))) return rc;
         pm.lap(2);
-        if ((rc = ch.variational_compress(phi, tolV, 1, lazy))) return rc;
+        // The target of the variational sweeps.  When the 4 chi pass has truncated nothing but rounding noise (no bond above 4 chi: every
+        // step either kept the centre matrix or dropped at most eps of it, and the rank-revealing factorisations stop at 2^-56), the state
+        // it leaves IS phi up to ~L eps -- in left-canonical form and with the bonds that pass found (~100 where the first pass, which
+        // cannot see the left part's null space, had to keep ~500).  Overlaps and optimised sites only depend on the STATE the target
+        // represents, so that copy serves as the target from here on: the environment and projector products shrink with the square of
+        // its bonds.  TN_VAR_TARGET=phi keeps the first pass's tensors (A/B, tests).
+        const bool target_phi = [] { const char* e = getenv("TN_VAR_TARGET"); return e && e[0] == 'p'; }();          // (read per call: the tests switch it)
+        if (!ch.pass_truncated && !target_phi && tolS / 10 <= CH_EPS) { phi_small = ch.A; target = &phi_small; ch.target_swapped = 1; }
+        // ... and then the one variational sweep of this stage has nothing to do: it would optimise every site of the state towards the
+        // state itself (overlap 1 - O(L eps)), i.e. return it in another gauge of the same left-canonical form, which the 2 chi pass
+        // does not see (it factors from the right end).  What the sweep leaves behind for the final stage are the Schmidt values of
+        // every bond (update_S, mps.py:550-560, compared only with later values of the same length): they are the singular values of
+        // the centre matrices the 4 chi pass itself met at those bonds, recorded here the way the sweep records them -- unevaluated
+        // (_LazyS).  Needs the lazy bookkeeping; TN_VAR1_SKIP=0 runs the sweep.
+        const bool var1_run = [] { const char* e = getenv("TN_VAR1_SKIP"); return e && e[0] == '0'; }();
+        if (ch.target_swapped && lazy && !var1_run) {
+            for (int64_t b = 1; b <= L; ++b) {
+                if (!ch.pass_C[b].p) continue;
+                Chain::SState& ss = ch.Sst[b];
+                ss.is_lazy = true; ss.lazy = ch.pass_C[b]; ss.has = false; ss.val.clear();
+            }
+            ch.var1_skipped = 1;
+        } else if ((rc = ch.variational_compress(*target, tolV, 1, lazy))) return rc;
+        ch.pass_C.clear();
         pm.lap(3);
         ch.pass_id = 3;
         if ((rc = ch.canonise_right(true, Dmax * 2, tolS / 2))) return rc;
@@ -1219,7 +1251,7 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
     ch.pass_id = 4;
     if ((rc = ch.canonise_left(true, Dmax, tolS))) return rc;
     pm.lap(5);
-    if ((rc = ch.variational_compress(phi, tolV, max_sweeps, lazy))) return rc;
+    if ((rc = ch.variational_compress(*target, tolV, max_sweeps, lazy))) return rc;
     pm.lap(6);
     // ---- results
     for (int64_t n = 0; n < L; ++n) {
@@ -1258,7 +1290,7 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
         info_host[4] = (double)ch.bonds_before;
         info_host[5] = (double)ch.bonds_after;
         info_host[6] = 0.0;
-        info_host[7] = (double)ch.gauge_skipped;
+        info_host[7] = (double)ch.gauge_skipped + 65536.0 * (double)ch.target_swapped + 131072.0 * (double)ch.var1_skipped;    // (three diagnostics in one word)
     }
     // the results are copied out of the arena by the stream; the caller may reuse the arena for the next call on the SAME stream at once
     return 0;

@@ -25,6 +25,17 @@ BATCHED_SCHMIDT = os.environ.get('TN_BATCHED_SCHMIDT', '1') != '0'        # smal
 PASS1_STRUCTURED = os.environ.get('TN_PASS1_STRUCTURED', '1') != '0'     # Gram recursion through the MPS (x) MPO structure
 
 
+def _var1_skip():
+    """TN_VAR1_SKIP=0 runs the 4 chi stage's variational sweep even when the state is its own target (chain.hip; read per call)."""
+    return os.environ.get('TN_VAR1_SKIP', '1') != '0'
+
+
+def _var_target_phi():
+    """TN_VAR_TARGET=phi keeps the first pass's tensors as the target of the variational sweeps (chain.hip; read per call)."""
+    return os.environ.get('TN_VAR_TARGET', '')[:1] == 'p'
+
+
+
 def _gram_step_structured(G, A, W, hconj):
     """One step of the left Gram recursion of the weighted first pass, G' = T^T (G (x) 1_t) T summed over the physical index,
     for an absorbed site T = A (x) W (tn_absorb) WITHOUT touching the absorbed tensor: with a = (alpha, l), b = (beta, r)
@@ -442,12 +453,12 @@ class MPS:
             if tol is None:
                 tol = self.zero
             Dcap = int(min(Dmax, min(self.C.shape)))
-            if (getattr(self, '_intermediate_pass', False) and not ops.GAUGE_SVD and tol <= np.finfo(float).eps
+            if (getattr(self, '_intermediate_pass', False) and ops.gauge_svd_mode() != 1 and not (ops.gauge_svd_mode() == 2 and self._pass_side == 1) and tol <= np.finfo(float).eps
                     and min(self.C.shape) <= Dmax):
                 # a truncation that cannot truncate (chain.hip: gauge_svd_skippable): it would only remove singular values below
                 # eps S0 and turn the bond into the Schmidt basis, neither of which is visible outside an intermediate pass --
                 # the centre matrix stays with the next site, less the bond indices that carry nothing (tn_bond_deflate)
-                if ops.BOND_DEFLATE:
+                if ops.bond_deflate_on():
                     side = self._pass_side
                     ns = self.pC - 1 if side == 0 else self.pC
                     self.C, self.A[ns], kk, d2 = ops.bond_deflate(side, self.C, self.A[ns])
@@ -455,6 +466,8 @@ class MPS:
                     self.discarded[self.pC] = max(self.discarded[self.pC], float(np.sqrt(d2)))
                 return 0.0
             U, S, Vt, keep, disc, _ = ops.svd_trunc(self.C, Dcap, tol)
+            if disc > 32.0 * np.finfo(float).eps:
+                self._pass_truncated = True          # this pass has changed the state by more than rounding (chain.hip: pass_truncated)
             nl, nr = self.pC - 1, self.pC
             if ops.FUSED_SITE and keep > 0:
                 self.A[nl], self.A[nr], self.C = ops.apply_truncation(self.A[nl], U, S, Vt, self.A[nr])
@@ -474,6 +487,7 @@ class MPS:
         self.C = torch.ones((1, 1), dtype=torch.float64, device=self.A[0].device)
         self.pC = 0
         self._pass_side = 0
+        self._pass_C = [None] * (self.L + 1)
         for n in range(self.L):
             # truncating pass: left part canonical, right part canonical -> the scale of C is the Schmidt scale, so rows of
             # R below 2^-56 of it can be skipped already in the QR (they are deflated by the SVD of truncateC)
@@ -485,6 +499,8 @@ class MPS:
                 self.orth_left(n, rank_tol=rank_tol)
             if compress:
                 self.truncateC(Dmax, tol)
+                if getattr(self, '_intermediate_pass', False):
+                    self._pass_C[self.pC] = self.C           # the centre matrix this pass leaves at the bond (chain.hip: pass_C)
         self.R[-1] = None
 
     def canonise_right(self, compress=False, Dmax=np.inf, tol=None):
@@ -795,8 +811,22 @@ class MPS:
         if graduate_truncation:
             self._intermediate_pass = True
             try:
+                self._pass_truncated = False
                 self.canonise_left(compress=True, Dmax=Dmax * 4, tol=tolS / 10)
-                self.variational_compress(phi, tol=tolV, max_sweeps=1)
+                # a 4 chi pass that truncated nothing but rounding noise leaves phi itself, with smaller bonds: the target of the variational
+                # sweeps from here on (chain.hip, tn_compress_mps)
+                swapped = not self._pass_truncated and not _var_target_phi() and tolS / 10 <= np.finfo(float).eps
+                if swapped:
+                    phi = self.copy()
+                if swapped and LAZY_SCHMIDT and _var1_skip():
+                    # ... and the one sweep of this stage has nothing to do (the state IS its target): only the Schmidt values it would
+                    # leave for the final stage are recorded, unevaluated, from the centre matrices of the 4 chi pass
+                    for b in range(1, self.L + 1):
+                        if self._pass_C[b] is not None:
+                            list.__setitem__(self.S, b, _LazyS(self._pass_C[b]))
+                else:
+                    self.variational_compress(phi, tol=tolV, max_sweeps=1)
+                self._pass_C = None
                 self.canonise_right(compress=True, Dmax=Dmax * 2, tol=tolS / 2)
             finally:
                 self._intermediate_pass = False

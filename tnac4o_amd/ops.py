@@ -494,7 +494,20 @@ def weighted_sum(a, b):
 
 
 NATIVE_CHAIN = os.environ.get('TN_NATIVE_CHAIN', '1') != '0'     # compress_mps (and the absorption in front of it) as one library call
-GAUGE_SVD = os.environ.get('TN_GAUGE_SVD', '0') == '1'           # keep the decompositions of the intermediate passes that cannot truncate (chain.hip: gauge_svd_skippable)
+
+
+def gauge_svd_mode():
+    """TN_GAUGE_SVD: 1 keeps every decomposition of the intermediate passes that cannot truncate, 2 those of the 2 chi pass
+    (chain.hip: gauge_svd_skippable; read per call)."""
+    try:
+        return int(os.environ.get('TN_GAUGE_SVD', '0'))
+    except ValueError:
+        return 0
+
+
+def bond_deflate_on():
+    return os.environ.get('TN_BOND_DEFLATE', '1') != '0'
+
 _arena = {}
 
 
@@ -581,11 +594,8 @@ def compress_mps_native(sites, mpo_sites, hconj, Dmax, tolS, tolV, max_sweeps, g
         k = int(slen[i])
         S.append(None if k < 0 else np.array(sch[i * pitch:i * pitch + k], dtype=np.float64))
     return dict(A=A, overlap=float(overlap.value), discarded=[float(x) for x in disc], S=S, nfs=[nfs[i] for i in range(int(ncount.value))],
-                info=dict(reveal_error_bound=float(info[0]), reveal_fallbacks=int(info[1]), weighted_used=bool(info[2]), arena_peak=int(info[3]), bonds_before=int(info[4]), bonds_after=int(info[5]), redone=int(info[6]), gauge_skipped=int(info[7]),
+                info=dict(reveal_error_bound=float(info[0]), reveal_fallbacks=int(info[1]), weighted_used=bool(info[2]), arena_peak=int(info[3]), bonds_before=int(info[4]), bonds_after=int(info[5]), redone=int(info[6]), gauge_skipped=int(info[7]) % 65536, target_swapped=(int(info[7]) // 65536) % 2, var1_skipped=(int(info[7]) // 131072) % 2,
                           arena_bytes=int(arena.numel())))
-
-
-BOND_DEFLATE = os.environ.get('TN_BOND_DEFLATE', '1') != '0'
 
 
 def bond_deflate(side, Cm, site):
