@@ -37,16 +37,18 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 FAMILIES = ['gemm_kernel<128,128>', 'gemm_kernel<128,32>', 'gemm_kernel<32,128>', 'gemm_kernel<64,64>',
-            'splitk_reduce_kernel', 'absorb_kernel', 'gram_partial_kernel', 'eig_small_kernel',
-            'rows_times_small_kernel', 'small_t_times_vecs_kernel', 'panel step (cq_fused / cq_gram / cq_pass / cq_post)',
+            'splitk_reduce_kernel', 'absorb_kernel', 'gram_partial_kernel', 'Jacobi rounds (svdl_kernel; eig_small3_kernel on separate launches)',
+            'rows_times_small_kernel', 'small_t_times_vecs_kernel', 'panel step (cq_fused_kernel, sq_kernel; cq_gram / cq_pass / cq_post on the six-launch chain)',
             'lu_reconstruct_kernel', 'qr_aux (diag_qr, assemble_R, init_Q, norms, copies)',
             'svd_aux (norms, init, gather)', 'misc (nfactor, scaling, builders)']
 COUNTERS = {'qr_nominal': 15, 'svd_nominal': 16, 'svd_stream': 17, 'svdvals_nominal': 18, 'svd_rounds': 19}   # counter-only families
 PHASES = ['gemm_var (attach / projector / environment GEMMs, scaling)', 'absorb', 'qr', 'svd_trunc', 'svdvals', 'mpo_build']
 MFMA_FAM = {0, 1, 2, 3}
-SERIAL_FAM = {7: ('eig_small_kernel', 'round of the block-Jacobi SVD (pair Gram matrices from LDS, up to 2 x 63 Jacobi steps of 32 plane rotations on the 64 x 64 '
+PMC_ALIASES = {7: ('Jacobi rounds (svdl_kernel)', 'eig_small_kernel'),
+               10: ('panel step (cq_fused_kernel, sq_kernel)', 'panel step (cq_fused / cq_gram / cq_pass / cq_post)')}   # keys of profiles/rNN_pmc_traffic.json
+SERIAL_FAM = {7: ('svdl_kernel', 'round of the block-Jacobi SVD (pair Gram matrices from LDS, up to 2 x 63 Jacobi steps of 32 plane rotations on the 64 x 64 '
                    'Gram matrix or its Newton-like fast path, rotation of the vectors in LDS; all rounds of a call in ONE launch, svdl_kernel)', None),
-              10: ('panel step (cq_fused / cq_gram / cq_pass / cq_post)',
+              10: ('cq_fused_kernel',
                    'launch of the panel step (ONE per panel of up to 4096 rows: Gram, 32-step one-wave Cholesky, substitution passes, '
                    'Householder reconstruction and reflector products behind in-kernel barriers; six per taller panel, of which the '
                    'passes after convergence return at once); each is a chain of dependent memory round trips and one-wave factorisations', 1)}
@@ -114,7 +116,7 @@ def cpu_model():
 
 
 def load_pmc():
-    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', name)))
             d['file'] = 'profiles/' + name
@@ -246,7 +248,7 @@ def main():
     # events on every kernel family (per-family / per-phase tables), (3) the W warm-up steps.  The timed steps then
     # bracket only the dominant family's launches with events, so the roofline duration is measured inside the timed
     # region at small overhead.
-    warm_prof, single_ms, single_prof_ms, phases, panel_stats = None, None, None, None, None
+    warm_prof, single_ms, single_prof_ms, phases, panel_stats, chain_info, census = None, None, None, None, None, None, None
     mask_all = (1 << len(FAMILIES)) - 1
     if owner and rank == 0 and not args.no_profile and args.warmup > 0:
         torch.cuda.synchronize()
@@ -268,6 +270,36 @@ def main():
         warm_prof = profile_totals(lib)
         phases = phase_report(lib, pmc)
         lib.tn_profile_enable(0)
+        # what the chain driver did on rotation 0 (tn_compress_mps info, summed over the rows of that sweep)
+        infos = [m.native_info for m in solver.rhoT if m is not None and getattr(m, 'native_info', None)]
+        chain_info = {'rows': len(infos),
+                      'plain_pass_fallbacks_per_sweep': sum(i['reveal_fallbacks'] for i in infos),
+                      'reveal_error_bound_max': max([i['reveal_error_bound'] for i in infos] or [0.0]),
+                      'reveal_error_bound_limit': 2.0 ** -56,
+                      'redone_rows_after_barrier_timeouts': sum(i.get('redone', 0) for i in infos),
+                      'bonds_without_decomposition_in_intermediate_passes': sum(i.get('gauge_skipped', 0) for i in infos),
+                      'rows_with_the_4chi_pass_as_variational_target': sum(i.get('target_swapped', 0) for i in infos),
+                      'rows_without_the_4chi_stage_sweep': sum(i.get('var1_skipped', 0) for i in infos),
+                      'what': 'rotation 0, one sweep: fallbacks of the weighted first pass to the plain one (the big plain tn_qr shape), its '
+                              'a-posteriori bound, and how often the shortcuts of the intermediate stages applied (csrc/chain.hip)'}
+        # launch census of the OTHER rotations (the timed step averages all four; their launch mix differs): one instrumented single-chain
+        # sweep each, same events-on-every-launch form as the rotation-0 tables
+        census = {'0': {'launches': sum(p['calls'] for p in warm_prof), 'kernel_ms': round(sum(p['ms'] for p in warm_prof), 1),
+                        'jacobi_round_launches': warm_prof[7]['calls'], 'panel_step_launches': warm_prof[10]['calls']}}
+        if world == 1 and len(solvers) > 1:
+            for r_i, s_i in enumerate(solvers[1:], start=1):
+                lib.tn_profile_reset()
+                lib.tn_profile_enable(mask_all)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s_i._setup_rhoT(**kw)
+                torch.cuda.synchronize()
+                ms_i = 1e3 * (time.perf_counter() - t0)
+                t_i = profile_totals(lib)
+                lib.tn_profile_enable(0)
+                census[str(my_rots[r_i])] = {'launches': sum(p['calls'] for p in t_i), 'kernel_ms': round(sum(p['ms'] for p in t_i), 1),
+                                             'jacobi_round_launches': t_i[7]['calls'], 'panel_step_launches': t_i[10]['calls'],
+                                             'single_chain_sweep_with_events_ms': round(ms_i, 1)}
     for _ in range(args.warmup):
         step()
     if not args.no_profile:
@@ -401,18 +433,21 @@ def main():
                          'algorithmic_bytes_per_launch': d['bytes'] / max(1, d['calls'])})
             if dom in SERIAL_FAM:
                 _, what, nser = SERIAL_FAM[dom]
-                if nser is None:             # rounds per launch are data dependent: device-side counter over the same timed region
+                if nser is None:             # rounds per launch are data dependent: library counter over the SAME timed region
                     rounds = _get(lib, -1, COUNTERS['svd_rounds'])
-                    rounds_per_sweep = rounds['calls'] / max(1, args.steps * len(my_rots))
-                    launches_per_sweep = warm_prof[dom]['calls'] if warm_prof is not None else d['calls'] * max(1, args.sample) / max(1, args.steps * len(my_rots))
-                    nser = max(1.0, rounds_per_sweep / max(1, launches_per_sweep))
+                    nsw_timed = max(1, args.steps * len(my_rots))
+                    rounds_per_sweep = rounds['calls'] / nsw_timed
+                    launches_per_sweep = d['calls'] * max(1, args.sample) / nsw_timed        # sampled launches x sampling interval
+                    nser = max(1.0, rounds_per_sweep / max(1.0, launches_per_sweep))
                     roof['rounds_per_launch'] = nser
                     roof['rounds_per_sweep'] = rounds_per_sweep
-                roof['limited_by'] = ('latency: serial steps of a single workgroup / dependent memory round trips (the bytes moved are '
-                                      'close to the algorithmic minimum, see traffic); figure of merit = time per serial step')
+                    roof['launches_per_sweep_timed_region'] = launches_per_sweep
                 roof['us_per_serial_step'] = 1e3 * avg_ms / nser
                 roof['serial_step'] = '%s, %.1f per launch' % (what, nser)
-            fam = (pmc or {}).get('families', {}).get(d['kernel']) if pmc else None
+            fam = None
+            if pmc:
+                for key in (d['kernel'],) + PMC_ALIASES.get(dom, ()):
+                    fam = pmc.get('families', {}).get(key) or fam
             if fam:
                 roof['traffic'] = fam['traffic_bytes_per_launch']
                 roof['traffic_shape'] = fam.get('probe_shape', 'tn_qr 16384 x 1024 (tools/pmc_probe.py): per-launch mean of the probe, NOT of '
@@ -425,11 +460,17 @@ def main():
                     'fetch': fam['fetch_bytes_per_launch'], 'write': fam['write_bytes_per_launch'],
                     'algorithmic_bytes_per_launch_same_probe': fam.get('algorithmic_bytes_per_launch'),
                     'traffic_over_algorithmic': fam.get('traffic_over_algorithmic')}
+            if dom in SERIAL_FAM:
+                ratio = (fam or {}).get('traffic_over_algorithmic')
+                roof['limited_by'] = ('latency: serial steps of single workgroups and dependent memory round trips, not bytes (measured HBM traffic of '
+                                      'this family on the probe: %s its algorithmic bytes); figure of merit = time per serial step' %
+                                      ('%.2fx' % ratio if ratio else 'not collected for'))
             out['roofline'] = roof
             table = warm_prof if warm_prof is not None else prof
             nsw = 1 if warm_prof is not None else args.steps * len(my_rots)
-            out['kernel_table_source'] = ('one single-chain sweep before the timed region (events on all families)'
-                                          if warm_prof is not None else 'timed sweeps')
+            out['kernel_table_source'] = ('ROTATION 0 alone: one single-chain sweep before the timed region with events on every launch '
+                                          '(kernel_time_ms_per_sweep, kernel_launches_per_sweep, launches_per_sweep, the phase table, gemm_mfma); '
+                                          'the other rotations: launch_census_by_rotation' if warm_prof is not None else 'timed sweeps')
             out['kernel_time_ms_per_sweep'] = {p['kernel']: round(p['ms'] / nsw, 3) for p in table}
             out['kernel_launches_per_sweep'] = {p['kernel']: p['calls'] // nsw for p in table}
             out['launches_per_sweep'] = sum(p['calls'] for p in table) // nsw
@@ -454,6 +495,10 @@ def main():
                                      'frac': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS}
         if panel_stats is not None:
             out['panel_step'] = panel_stats
+        if chain_info is not None:
+            out['chain_driver'] = chain_info
+        if census is not None:
+            out['launch_census_by_rotation'] = census
         if full is not None:
             out['full_solve'] = full
         if args.cpu_rows > 0 and world == 1 and kind == 'Ising' and solver is not None:
@@ -528,10 +573,13 @@ def cpu_baseline(n, args, solver, kw, single_ms):
         proxy_ms[str(nt)] = min(limited(nt, proxy) for _ in range(2))
     threads = int(min(proxy_ms, key=proxy_ms.get))
 
-    # ---- whole bulk rows
+    # ---- whole bulk rows.  The thread count that enters `value` is chosen on a REAL row (the first one, timed at 8 / 16 / 32 BLAS threads
+    # plus the proxy's winner): the rows are dominated by 16384 x 1024 factorisations, the proxy is a quarter of that
     kwc = dict(Dmax=kw['Dmax'], tolS=1e-16, tolV=1e-10, max_sweeps=20, graduate_truncation=True)
     rows = [n // 2 - i for i in range(max(1, args.cpu_rows))]
     per_row = []
+    row_ms_by_threads = {}
+    cand = [threads] if threadpoolctl is None else sorted({c for c in (8, 16, 32, threads) if c <= logical})
     for ny in rows:
         psi = solver.rhoT[ny + 1]
         mpo = solver._row_mpo(ny)
@@ -549,7 +597,16 @@ def cpu_baseline(n, args, solver, kw, single_ms):
             o.apply_mpo(M, Hconj=True)
             ov = o.compress_mps(**kwc)
             return 1e3 * (time.perf_counter() - t0), o, ov
-        cpu_ms, o, ov_ref = limited(threads, cpu_row)
+        if not row_ms_by_threads and len(cand) > 1:
+            best = None
+            for nt in cand:
+                r_ = limited(nt, cpu_row)
+                row_ms_by_threads[str(nt)] = r_[0]
+                if best is None or r_[0] < best[0][0]:
+                    best = (r_, nt)
+            (cpu_ms, o, ov_ref), threads = best
+        else:
+            cpu_ms, o, ov_ref = limited(threads, cpu_row)
         out = psi.copy()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -590,10 +647,10 @@ def cpu_baseline(n, args, solver, kw, single_ms):
     except Exception as e:                                 # noqa: BLE001 -- a sub-field must not take the bench line down
         first_pass = {'error': repr(e)}
     return {'value': cpu_row_ms, 'unit': 'ms per bulk row (apply_mpo + compress_mps)', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
-            'physical_cores': phys, 'logical_cores': logical, 'proxy_ms_by_blas_threads': proxy_ms,
+            'physical_cores': phys, 'logical_cores': logical, 'proxy_ms_by_blas_threads': proxy_ms, 'row_ms_by_blas_threads': row_ms_by_threads,
             'sample': 'whole bulk rows %s of the %d-row sweep (chi = %d): MPS.apply_mpo + MPS.compress_mps of the reference algorithm (oracle/, '
-                      'numpy + scipy LAPACK) from the boundary MPS the GPU sweep fed into each row; %d BLAS threads = the fastest of %s on a '
-                      '4096 x 1024 attach + QR proxy' % (rows, n, kw['Dmax'], threads, sorted(int(k) for k in proxy_ms)),
+                      'numpy + scipy LAPACK) from the boundary MPS the GPU sweep fed into each row; %d BLAS threads = the fastest of %s on the first of '
+                      'these rows (row_ms_by_blas_threads)' % (rows, n, kw['Dmax'], threads, sorted(int(k) for k in row_ms_by_threads) or [threads]),
             'rows': per_row, 'gpu_ms_per_row': gpu_row_ms, 'speedup_per_row': cpu_row_ms / gpu_row_ms if gpu_row_ms > 0 else None,
             'full_sweep_cpu_ms_extrapolation': cpu_row_ms * n,
             'extrapolation': 'CPU time per bulk row x %d rows (the two edge rows are cheaper: an upper bound by < 2 rows); no GPU figure enters it' % n,
