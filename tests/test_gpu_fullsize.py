@@ -145,6 +145,78 @@ def _oracle_row(inp_sites, mpo_sites, chi, perturb=None, hconj=True):
     return o, ov
 
 
+def _check_row_against_oracle(tag, psi, mpo, out, ov, hconj, chi, n):
+    """One row step of the product path (psi -> out, overlap ov) against oracle/ from the same input MPS and MPO: fidelity of the
+    compressed states >= 1 - 1e-12, overlaps to 1e-12, discarded weights to 1e-6 relative / 1e-14 absolute -- or, should a row exceed
+    that, to 3x the oracle's own movement under a 1e-16 perturbation of its QR inputs (printed with the margins)."""
+    import time
+    from oracle import mps_ref as mr
+    inp = [a.cpu().numpy() for a in psi.A]
+    Ws = [w.cpu().numpy() for w in mpo.W]
+    t0 = time.perf_counter()
+    o, ov_ref = _oracle_row(inp, Ws, chi, hconj=hconj)
+    t_cpu = time.perf_counter() - t0
+    got = mr.RefMPS(d=[a.shape[1] for a in out.A], L=n, Dmax=1, canonise=None)
+    got.A = [a.cpu().numpy() for a in out.A]
+    fid = abs(mr.mps_dot(got, o)) / np.sqrt(mr.mps_dot(got, got) * mr.mps_dot(o, o))
+    dg, dr = max(out.discarded), max(o.discarded)
+    rel = abs(dg - dr) / max(dr, 1e-300)
+    print('%s: input bonds up to %d, oracle %.1f s; 1 - fidelity %.2e (allowed 1e-12), |d overlap| %.2e (allowed 1e-12), discarded %.6e vs %.6e '
+          '(rel %.2e), D %s vs %s' % (tag, max(a.shape[0] for a in inp), t_cpu, 1.0 - fid, abs(ov - ov_ref), dg, dr, rel, out.D, o.D))
+    assert 1.0 - fid < 1e-12, tag
+    assert abs(ov - ov_ref) < 1e-12, tag
+    if not (rel < 1e-6 or abs(dg - dr) < 1e-14):
+        o2, _ = _oracle_row(inp, Ws, chi, perturb=1e-16, hconj=hconj)
+        spread = abs(max(o2.discarded) - dr)
+        print('%s: oracle eps-probe moves its discarded weight by %.3e (rel %.2e); HIP differs by %.3e' % (tag, spread, spread / dr, abs(dg - dr)))
+        assert abs(dg - dr) <= 3.0 * spread, tag
+
+
+@pytest.mark.parametrize('beta', [1.0, 3.0])
+def test_config5_rows_hip_vs_oracle(beta):
+    """BASELINE config 5's bond shape against the CPU oracle (reference tnac4o.py:1609-1670 for the dense RMF tensors, mps.py:175-200):
+    Random Markov Field with d = 8, chi = 128 on a 16 x 16 lattice (generator and seed of the bench's rmf64 workload, 20260005), row 12
+    of the top-down sweep (Hconj=True) and the mirror row 3 of the bottom-up sweep (Hconj=False: the other absorption orientation),
+    each from the GPU sweep's own input MPS, p = b = 8.  beta = 1 is config 5 itself: its boundary MPS saturate at the eps floor
+    (bonds ~80 of the 128 allowed, on the 64 x 64 lattice too -- profiles/r04_bench_rmf64.json), so the rows run the eps rule of
+    mps.py:805-806; beta = 3 is the same lattice with chi = 128 SATURATED along the chain: absorbed bond 128 x 8 = 1024, 8192 x 1024
+    factorisations, 1024 x 1024 centre matrices, truncations to 4 chi / 2 chi / chi.  Same assertions as the headline rows: fidelity
+    >= 1 - 1e-12, overlaps to 1e-12, discarded weights to 1e-6 relative / 1e-14 absolute or 3x the oracle's own eps-probe spread."""
+    import tnac4o_amd
+    from tnac4o_amd import mps
+    from tnac4o_amd.auxx import synthetic_rmf
+    try:
+        import threadpoolctl
+        limit = threadpoolctl.threadpool_limits(limits=16)
+    except ImportError:
+        limit = None
+    n, chi = 16, 128
+    s = tnac4o_amd.tnac4o(mode='RMF', Nx=n, Ny=n, J=synthetic_rmf(n, n, 8, 20260005), beta=beta)
+    kw = dict(Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20, graduate_truncation=True)
+    try:
+        psi = mps.MPS(d=1, L=n, Dmax=1, initial='X')
+        for ny in range(n - 1, 11, -1):                      # _setup_rhoT: rows 15 .. 12
+            mpo = s._row_mpo(ny)
+            out = psi.copy()
+            ov = out.apply_mpo_compress(mpo, Hconj=True, **kw)
+            if ny == 12:
+                assert max(w.shape[0] for w in mpo.W) == 8 and (max(psi.D) == chi if beta == 3.0 else 64 < max(psi.D) < chi)
+                _check_row_against_oracle('RMF d=8 chi=128 beta=%g rhoT row %d' % (beta, ny), psi, mpo, out, ov, True, chi, n)
+            psi = out
+        psi = mps.MPS(d=1, L=n, Dmax=1, initial='X')
+        for ny in range(0, 4):                               # _setup_rhoB: rows 0 .. 3
+            mpo = s._row_mpo(ny)
+            out = psi.copy()
+            ov = out.apply_mpo_compress(mpo, Hconj=False, **kw)
+            if ny == 3:
+                assert beta != 3.0 or max(psi.D) == chi
+                _check_row_against_oracle('RMF d=8 chi=128 beta=%g rhoB row %d (Hconj=False)' % (beta, ny), psi, mpo, out, ov, False, chi, n)
+            psi = out
+    finally:
+        if limit is not None:
+            limit.restore_original_limits() if hasattr(limit, 'restore_original_limits') else limit.unregister()
+
+
 def test_headline_rows_hip_vs_oracle():
     """BASELINE's headline size against the CPU oracle (reference tnac4o.py:1674-1718 at L = 2048, chi = 64, seed 20260004): rows 14
     (absorbed bond 256, the first truncating row), 13 (absorbed bond 1024: the bulk shape, 16384 x 1024 QRs and 1024 x 1024 centre
@@ -170,25 +242,7 @@ def test_headline_rows_hip_vs_oracle():
     kw = dict(Dmax=chi, tolS=1e-16, tolV=1e-10, max_sweeps=20, graduate_truncation=True)
 
     def check(tag, psi, mpo, out, ov, hconj):
-        inp = [a.cpu().numpy() for a in psi.A]
-        Ws = [w.cpu().numpy() for w in mpo.W]
-        t0 = time.perf_counter()
-        o, ov_ref = _oracle_row(inp, Ws, chi, hconj=hconj)
-        t_cpu = time.perf_counter() - t0
-        got = mr.RefMPS(d=[a.shape[1] for a in out.A], L=n, Dmax=1, canonise=None)
-        got.A = [a.cpu().numpy() for a in out.A]
-        fid = abs(mr.mps_dot(got, o)) / np.sqrt(mr.mps_dot(got, got) * mr.mps_dot(o, o))
-        dg, dr = max(out.discarded), max(o.discarded)
-        rel = abs(dg - dr) / max(dr, 1e-300)
-        print('%s: input bonds up to %d, oracle %.1f s; 1 - fidelity %.2e (allowed 1e-12), |d overlap| %.2e (allowed 1e-12), discarded %.6e vs %.6e '
-              '(rel %.2e), D %s vs %s' % (tag, max(a.shape[0] for a in inp), t_cpu, 1.0 - fid, abs(ov - ov_ref), dg, dr, rel, out.D, o.D))
-        assert 1.0 - fid < 1e-12, tag
-        assert abs(ov - ov_ref) < 1e-12, tag
-        if not (rel < 1e-6 or abs(dg - dr) < 1e-14):
-            o2, _ = _oracle_row(inp, Ws, chi, perturb=1e-16, hconj=hconj)
-            spread = abs(max(o2.discarded) - dr)
-            print('%s: oracle eps-probe moves its discarded weight by %.3e (rel %.2e); HIP differs by %.3e' % (tag, spread, spread / dr, abs(dg - dr)))
-            assert abs(dg - dr) <= 3.0 * spread, tag
+        _check_row_against_oracle(tag, psi, mpo, out, ov, hconj, chi, n)
     try:
         psi = mps.MPS(d=1, L=n, Dmax=1, initial='X')
         for ny in range(n - 1, 0, -1):                       # _setup_rhoT: rows 15 .. 1

@@ -262,6 +262,7 @@ struct PassClock {
     bool on;
     std::mutex mu;
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double sub[4] = {0, 0, 0, 0};      // inside pass 1: Gram recursion + weights | attach, norms, sort, gather | pivoted factorisation | un-weighting, normalisation
     long calls = 0;
     PassClock() { const char* e = getenv("TN_CHAIN_PASSES"); on = e && e[0] == '1'; }
     ~PassClock() {
@@ -272,6 +273,8 @@ struct PassClock {
         for (double v : ms) tot += v;
         fprintf(stderr, "[tn_compress_mps passes] %ld calls, %.1f ms in total\n", calls, tot);
         for (int i = 0; i < 8; ++i) fprintf(stderr, "  %-36s %9.1f ms  %5.1f %%\n", nm[i], ms[i], 100.0 * ms[i] / (tot > 0 ? tot : 1));
+        fprintf(stderr, "  inside pass 1: Gram recursion + weights %.1f ms | attach, norms, sort, gather %.1f ms | pivoted factorisation %.1f ms | un-weighting, "
+                "normalisation %.1f ms\n", sub[0], sub[1], sub[2], sub[3]);
     }
 };
 PassClock g_pass_clock;
@@ -279,6 +282,16 @@ struct PassMark {
     hipStream_t st;
     std::chrono::steady_clock::time_point t0;
     explicit PassMark(hipStream_t s) : st(s) { if (g_pass_clock.on) { (void)hipStreamSynchronize(st); t0 = std::chrono::steady_clock::now(); } }
+    void sublap(int k) {
+        if (!g_pass_clock.on) return;
+        (void)hipStreamSynchronize(st);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> lk(g_pass_clock.mu);
+        g_pass_clock.sub[k] += std::chrono::duration<double, std::milli>(t1 - ts).count();
+        ts = t1;
+    }
+    void substart() { if (g_pass_clock.on) { (void)hipStreamSynchronize(st); ts = std::chrono::steady_clock::now(); } }
+    std::chrono::steady_clock::time_point ts;
     void lap(int k) {
         if (!g_pass_clock.on) return;
         (void)hipStreamSynchronize(st);
@@ -722,6 +735,8 @@ public:
         std::vector<Wt> wts(L + 1);
         std::vector<double*> gfac(L + 1, nullptr);
         M2 G;
+        PassMark sm(st);
+        sm.substart();
         CH(ones11(G));
         for (int64_t n = 0; n < L; ++n) {
             const int64_t Dl = A[n].a, p = A[n].b, Dr = A[n].c;
@@ -746,6 +761,7 @@ public:
                 CH(gram_weights(st, G.p, Dr, CH_PASS1_FLOOR, w.d2, w.st65));
             }
         }
+        sm.sublap(0);
         std::vector<int64_t> used;
         for (int64_t n = 0; n < L; ++n) if (wts[n].on) used.push_back(n);
         if (used.empty()) {
@@ -824,7 +840,9 @@ public:
             ab.reset();
             T3 Bt; Bt.blk = bb_; Bt.p = B; Bt.a = Dl; Bt.b = p; Bt.c = r;
             SiteOut o;
+            sm.sublap(1);
             CH(site_qr_step(1, Bt, nullptr, rel_tol, false, true, true, o));
+            sm.sublap(2);
             // sort order followed by the panel pivoting: perm <- perm[piv]
             std::vector<int64_t> comp((size_t)Dl);
             for (int64_t j = 0; j < Dl; ++j) comp[j] = order[(size_t)o.piv[j]];
@@ -845,6 +863,7 @@ public:
             D[n] = o.k; D[n + 1] = r;
             pC = n;
             err += scale * sqrt(o.dropped2);
+            sm.sublap(3);
         }
         reveal_error_bound = err;
         accepted = err <= CH_PASS1_ACCEPT;
