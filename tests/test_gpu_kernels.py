@@ -1245,3 +1245,26 @@ def test_pivoted_site_qr_device_selection(ops, shape):
         A1[p1], A0[p0] = C1, C0
         assert np.abs(A1[:, :k1] - A0[:, :k0]).max() <= 1e-12 * np.abs(C0).max()
         assert abs(d1 - d0) <= 1e-9 * max(d0, 1e-300)
+
+
+@pytest.mark.parametrize('shape,gap', [((128, 300), 1e-10), ((192, 192), 1e-12), ((100, 100), 1e-11), ((64, 64), 1e-10)])
+def test_svd_clustered_spectrum_orthogonality(ops, shape, gap):
+    """Singular values that are close but distinct (relative gaps 1e-10 .. 1e-12: rotation angles inside a cluster are O(1) however
+    small the off-diagonals) -- the case the quadratic-convergence shortcut of the Jacobi sweeps (a sweep that met nothing above 1e-9
+    is not followed by a verification sweep) has to survive: U and V^T orthonormal to 1e-13, values to 1e-13 S0, U S V^T = C."""
+    k, n = shape
+    r = min(k, n)
+    g = np.random.default_rng(int(1e12 * gap) + k)
+    U0, _ = np.linalg.qr(g.standard_normal((k, r)))
+    V0, _ = np.linalg.qr(g.standard_normal((n, r)))
+    sv = np.exp(-0.05 * np.arange(r))
+    for c0 in (0, 10, r // 2):                       # three clusters of 8 values each
+        sv[c0:c0 + 8] = sv[c0] * (1.0 - gap * np.arange(8))
+    sv = np.sort(sv)[::-1]
+    A = (U0 * sv) @ V0.T
+    U, S, Vt, keep, disc, info = ops.svd_trunc(dev(A), r, 1e-16)
+    Uh, Sh, Vh = U.cpu().numpy(), S.cpu().numpy(), Vt.cpu().numpy()
+    assert keep == r and info['info'] == 0
+    assert np.abs(Uh.T @ Uh - np.eye(r)).max() < 1e-13 and np.abs(Vh @ Vh.T - np.eye(r)).max() < 1e-13
+    assert np.abs(Sh - sv).max() <= 1e-13 * sv[0]
+    assert np.abs((Uh * Sh) @ Vh - A).max() <= 1e-13 * sv[0]

@@ -113,6 +113,11 @@ def build(verbose=False):
     objdir = os.path.join(HERE, '..', 'build', 'obj')
     os.makedirs(objdir, exist_ok=True)
     hh = hashlib.sha256(' '.join(flags).encode())
+    hh.update(os.path.realpath(hipcc).encode())                 # the compiler is part of the key: a toolchain upgrade must not link stale objects
+    try:
+        hh.update(subprocess.run([hipcc, '--version'], capture_output=True, check=False).stdout)
+    except OSError:
+        pass
     for f in sorted(os.listdir(CSRC)):
         if f.endswith('.h'):
             hh.update(open(os.path.join(CSRC, f), 'rb').read())
@@ -132,16 +137,23 @@ def build(verbose=False):
             for old in os.listdir(objdir):
                 if old.startswith(s[:-4] + '.') and old.endswith('.o'):
                     os.unlink(os.path.join(objdir, old))
-            cmd = [hipcc] + flags + extra + ['-c', src, '-o', obj + '.tmp']
+            import tempfile
+            fd, tmp = tempfile.mkstemp(prefix=s[:-4] + '.', suffix='.o.part', dir=objdir)     # (two builds at once must not share a temp name)
+            os.close(fd)
+            cmd = [hipcc] + flags + extra + ['-c', src, '-o', tmp]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
-            os.replace(obj + '.tmp', obj)
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, obj)
+            finally:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
         return obj
 
     with ThreadPoolExecutor(max_workers=int(os.environ.get('TN_BUILD_JOBS', '6'))) as ex:
         objs = list(ex.map(one, SOURCES))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + os.environ.get('TN_EXTRA_HIPCC_FLAGS', '').split() + ['-o', LIB_PATH] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)

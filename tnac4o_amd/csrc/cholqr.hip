@@ -1760,8 +1760,11 @@ int cholqr_stats(unsigned long long* out16, int reset, hipStream_t st_or_null, i
     if (all_streams) {
         for (int s = 0; s <= CQ_STAT_SLOTS; ++s)
             for (int i = 0; i < 16; ++i) out16[i] += raw[s * 16 + i];
+        // (word [10], the sticky count of launches that gave up at a barrier, is NOT a statistic: fused_timeouts compares it with the value
+        //  it saw last, so a reset keeps it -- zeroing it would turn the next comparison into a huge unsigned difference, or lose a time-out)
         if (reset) {
-            memset(raw, 0, sizeof(raw));
+            for (int s = 0; s <= CQ_STAT_SLOTS; ++s)
+                for (int i = 0; i < 16; ++i) if (i != 10) raw[s * 16 + i] = 0;
             if ((e = hipMemcpyToSymbol(HIP_SYMBOL(cq_stats), raw, sizeof(raw))) != hipSuccess) return hip_fail(e, "reset panel statistics");
         }
         return 0;
@@ -1770,6 +1773,7 @@ int cholqr_stats(unsigned long long* out16, int reset, hipStream_t st_or_null, i
     for (int i = 0; i < 16; ++i) out16[i] = raw[slot * 16 + i];
     if (reset) {
         unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        z[10] = raw[slot * 16 + 10];
         if ((e = hipMemcpyToSymbol(HIP_SYMBOL(cq_stats), z, sizeof(z), (size_t)slot * sizeof(z))) != hipSuccess) return hip_fail(e, "reset panel statistics");
     }
     return 0;

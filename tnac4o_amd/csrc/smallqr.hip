@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void sq_kernel(SqArgs a) {
                 unsigned long long m0 = mred[0] > mred[1] ? mred[0] : mred[1], m1 = mred[2] > mred[3] ? mred[2] : mred[3];
                 m0 = m0 > m1 ? m0 : m1;
                 const double f = ldexp(1.0, (int)((long long)(m0 >> 52) - 1023));
-                inv = 1.0 / f;
+                inv = (m0 == 0ull) ? 1.0 : 1.0 / f;            // an all-zero factor stays zero whatever the denormal mode (f = 2^-1023 as mps.py:76-85)
                 if (tid == 0) { a.nf_out2[0] = f; a.nf_out2[1] = inv; }
             }
             if (wave < NT) {
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void sq_kernel(SqArgs a) {
                 __syncthreads();
                 unsigned long long m0 = fred[0] > fred[1] ? fred[0] : fred[1], m1 = fred[2] > fred[3] ? fred[2] : fred[3];
                 m0 = m0 > m1 ? m0 : m1;
-                const double f = ldexp(1.0, (int)((long long)(m0 >> 52) - 1023)), inv = 1.0 / f;
+                const double f = ldexp(1.0, (int)((long long)(m0 >> 52) - 1023)), inv = (m0 == 0ull) ? 1.0 : 1.0 / f;
                 if (tid == 0) { a.nf_out2[0] = f; a.nf_out2[1] = inv; }
                 for (int e = tid; e < n * n; e += 256) {
                     double* p = a.R + (int64_t)(e / n) * a.rrs + (int64_t)(e % n) * a.rcs;
@@ -846,8 +846,8 @@ int smallqr_stats(hipStream_t st, unsigned long long* out4, int reset) {
     if (slot >= CHOLQR_SLOTS) return 0;
     hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(sq_stats), 32, (size_t)slot * 32);
     if (e != hipSuccess) return hip_fail(e, "read small-QR statistics");
-    if (reset) {
-        unsigned long long z[4] = {0, 0, 0, 0};
+    if (reset) {             // (word [3], the sticky count of launches that gave up, stays: fused_timeouts compares it with the value it saw last)
+        unsigned long long z[4] = {0, 0, 0, out4[3]};
         if ((e = hipMemcpyToSymbol(HIP_SYMBOL(sq_stats), z, 32, (size_t)slot * 32)) != hipSuccess) return hip_fail(e, "reset small-QR statistics");
     }
     return 0;

@@ -163,9 +163,20 @@ def qr_batched(T, side_streams=(), rank_tol=0.0, nb=None):
     ws = workspace(wsi * batch, 4)
     keff = (C.c_int64 * batch)(*([k] * batch))
     sides = (C.c_void_p * max(1, len(side_streams)))(*[s.cuda_stream for s in side_streams])
-    check(L.tn_qr_batched(T.data_ptr(), T.stride(1), T.stride(2), m, n, Q.data_ptr(), Q.stride(1), Q.stride(2), R.data_ptr(),
-                          R.stride(1), R.stride(2), nb, float(rank_tol), keff, batch, T.stride(0), Q.stride(0), R.stride(0),
-                          ws.data_ptr(), wsi * batch, _stream(), sides, len(side_streams)))
+    # the call destroys T; error -7 (a launch with in-kernel barriers gave up: the streams are on the multi-launch forms from then on)
+    # asks for a rerun from a copy, so one is kept (this entry point is not on the contraction path)
+    T0 = T.clone()
+    for attempt in range(2):
+        rc = L.tn_qr_batched(T.data_ptr(), T.stride(1), T.stride(2), m, n, Q.data_ptr(), Q.stride(1), Q.stride(2), R.data_ptr(),
+                             R.stride(1), R.stride(2), nb, float(rank_tol), keff, batch, T.stride(0), Q.stride(0), R.stride(0),
+                             ws.data_ptr(), wsi * batch, _stream(), sides, len(side_streams))
+        if rc == -7 and attempt == 0:
+            T.copy_(T0)
+            for i in range(batch):
+                keff[i] = k
+            continue
+        check(rc)
+        break
     return Q, R, [int(x) for x in keff]
 
 
@@ -428,9 +439,20 @@ def site_qr(side, A, Cm=None, rank_tol=0.0, normalise=True, info=None, frobenius
     ws = workspace(wsb, 0)
     keff, normd, drop2 = C.c_int64(kf), C.c_int(0), C.c_double(0.0)
     piv = (C.c_int64 * n)() if pivot else None               # panel pivoting: order of the factored matrix's columns
-    check(lib().tn_site_qr(side, A.data_ptr(), Dl, p, Dr, Cm.data_ptr() if attach else None, kc, Q.data_ptr(), R.data_ptr(),
-                           float(rank_tol), C.byref(keff), nf.data_ptr() if normalise else None, C.byref(normd), C.byref(drop2),
-                           1 if frobenius_exit else 0, piv, ws.data_ptr(), wsb, _stream()))
+    # error -7 (a launch with in-kernel barriers gave up; the stream is on the multi-launch forms from then on) asks for a rerun: with
+    # an attach the input is intact (the product lives in the workspace), without one the call consumes A, so a copy is kept
+    A0 = None if attach else A.clone()
+    for attempt in range(2):
+        rc = lib().tn_site_qr(side, A.data_ptr(), Dl, p, Dr, Cm.data_ptr() if attach else None, kc, Q.data_ptr(), R.data_ptr(),
+                              float(rank_tol), C.byref(keff), nf.data_ptr() if normalise else None, C.byref(normd), C.byref(drop2),
+                              1 if frobenius_exit else 0, piv, ws.data_ptr(), wsb, _stream())
+        if rc == -7 and attempt == 0:
+            if A0 is not None:
+                A.copy_(A0)
+            keff, normd, drop2 = C.c_int64(kf), C.c_int(0), C.c_double(0.0)
+            continue
+        check(rc)
+        break
     k = int(keff.value)
     if info is not None:
         info['dropped2'] = float(drop2.value)
