@@ -11,9 +11,29 @@
  *     allocated or freed by the library; outputs never alias inputs unless stated;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.  tn_svd_trunc / tn_svdvals
  *     synchronise the stream internally (rank decisions are made on the host), the rest is asynchronous;
- *   - return 0 = ok, < 0 = argument error (nothing launched), > 0 = HIP runtime error code.  The message is
- *     available from tn_last_error() (thread-local).  Numerical events (non-convergence) are reported through
- *     `info` outputs, never as errors.
+ *   - return 0 = ok, < 0 = argument error (nothing launched; -3 = a caller-sized buffer was too small, -7 = a launch with
+ *     in-kernel barriers gave up and the inputs were consumed: rerun from a copy), > 0 = HIP runtime error code.  The
+ *     message is available from tn_last_error() (thread-local).  Numerical events (non-convergence) are reported
+ *     through `info` outputs, never as errors.
+ *
+ * State the library keeps (SURVEY.md 8b asks for none; what there is, is bookkeeping -- no result depends on it being there):
+ *   - per host thread: the error text; a few page-locked staging buffers for small read-backs / uploads (grown on demand,
+ *     freed when the thread exits); the event ring of the optional profiler (tn_profile_*); the stamp counter of the
+ *     device-side panel pivoting (tn_qr / tn_site_qr with pivot_perm_host);
+ *   - per (device, stream), created at the stream's first use and released by tn_stream_destroy (streams the caller
+ *     destroys otherwise keep their slot: at most 64 slots, the streams beyond share the last one for statistics and do not
+ *     take the single-launch forms): a slot number; a 256-byte __device__ state block for the panel step, one for the
+ *     one-launch factorisation and one for the one-launch Jacobi rounds (barrier counters, cleared by the launch that ends
+ *     a call); DIAGNOSTIC counters (tn_panel_stats*, tn_smallqr_stats); the STICKY count of launches that gave up at an
+ *     in-kernel barrier (read by tn_fused_timeouts, never reset by the statistics calls); a flag "this stream is off the
+ *     single-launch forms" set after such a time-out (from then on the multi-launch forms run: same results bit for bit);
+ *     the event of a tall panel launch in flight (admission control of launches that need co-resident workgroups);
+ *   - process-wide, read once: the co-residency budget (CUs of the device, GPU_MAX_HW_QUEUES, TN_PANEL_CU_BUDGET) and the
+ *     switches of INTEGRATION.md section 3 (the ones marked "per call" are read at every call).
+ * Thread-safety: every entry point may be called concurrently from different host threads on DIFFERENT streams (the
+ * product drives one chain per thread and stream); the tables above are guarded by mutexes.  Two threads must not
+ * enqueue on the SAME stream at once (workspaces and state blocks are per stream).  The library allocates no device
+ * memory; the __device__ state pools are static.
  */
 #ifndef TNPEPS_H
 #define TNPEPS_H
