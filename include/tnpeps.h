@@ -383,6 +383,20 @@ int64_t tn_beam_search_ws_bytes(int64_t Nx, int64_t Ny, int64_t M, int64_t qmax,
 int tn_beam_search(int64_t Nx, int64_t Ny, const tn_beam_cell* cells, int64_t M, int has_cut, double log2_cutoff, double min_dEng, int64_t B,
                    int16_t* states_out, double* energy_out, double* log2p_out, int64_t* deg_out, int64_t* nb_host, double* pd_max_host,
                    double* globalmin_host, void* ws, int64_t ws_bytes, void* stream);
+/* The same walk shared by a TEAM of `team` processes (one per GPU; SURVEY.md 8e-ii: the beam shards of one lattice rotation).  Every rank
+ * holds the whole beam and calls tn_beam_search_team with the same arguments and its own `rank`; the conditional tables of a site-step
+ * (tn_calc_pn, tnac4o.py:444-453) are evaluated for the rank's contiguous slice of the branches, [nb rank / team, nb (rank + 1) / team),
+ * then `exchange` is called on every rank, in the same order, once per site-step:
+ *     exchange(ctx, log2p (DEVICE, nb x q), minp (DEVICE, nb), nb, q, rank, team)
+ * and must return 0 with the slices of ALL ranks in place on every rank (row b of log2p / entry b of minp belongs to the rank whose slice
+ * holds b) -- e.g. one broadcast per rank over the team's communicator, enqueued on `stream` or ordered behind it.  From there on all
+ * ranks run the identical deterministic cut, merge and selection: the results are those of tn_beam_search bit for bit, on every rank.
+ * team = 1 (exchange may be NULL) is tn_beam_search.  Errors as tn_beam_search; -8: the exchange function returned non-zero. */
+typedef int (*tn_beam_exchange_fn)(void* ctx, double* log2p, double* minp, int64_t nb, int64_t q, int rank, int team);
+int tn_beam_search_team(int64_t Nx, int64_t Ny, const tn_beam_cell* cells, int64_t M, int has_cut, double log2_cutoff, double min_dEng, int64_t B,
+                        int16_t* states_out, double* energy_out, double* log2p_out, int64_t* deg_out, int64_t* nb_host, double* pd_max_host,
+                        double* globalmin_host, void* ws, int64_t ws_bytes, void* stream, int rank, int team, tn_beam_exchange_fn exchange,
+                        void* exchange_ctx);
 
 #ifdef __cplusplus
 }

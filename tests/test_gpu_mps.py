@@ -338,8 +338,21 @@ torch.cuda.set_device(0)
 dist.init_process_group('gloo')          # two ranks share the one GPU of the test box, so the exchange runs over gloo
 J = gi.droplet_J(128, 1)
 make = lambda: tnac4o_amd.tnac4o(mode='Ising', Nx=4, Ny=4, Nc=8, J=J, beta=3.0)
+from tnac4o_amd import beam
+calls = {'native_team': 0, 'torch': 0}
+orig_native, orig_device = beam.search_native, beam.search_device
+def spy_native(*a, **k):
+    out = orig_native(*a, **k)
+    if out is not None and k.get('beam_group') is not None:
+        calls['native_team'] += 1
+    return out
+def spy_device(*a, **k):
+    calls['torch'] += 1
+    return orig_device(*a, **k)
+beam.search_native, beam.search_device = spy_native, spy_device
 res = solve_rotations(make, rotations=(0,), beam_shards=2, M=256, relative_P_cutoff=1e-8, Dmax=16)
 res['state'] = [int(x) for x in res['state']]
+res['calls'] = calls
 print('RESULT ' + json.dumps(res), flush=True)
 dist.barrier()
 dist.destroy_process_group()
@@ -347,15 +360,19 @@ dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_beam_sharded_product_path_two_ranks():
+@pytest.mark.parametrize('team_walk', ['native', 'torch'])
+def test_beam_sharded_product_path_two_ranks(team_walk):
     """SURVEY.md 8e-ii on the product path: 2 processes (one GPU, gloo) split every site-step's branches; both must
-    reproduce the single-process result and the reference's golden ground state."""
+    reproduce the single-process result and the reference's golden ground state.  'native': the team walks the search in the
+    library (tn_beam_search_team: the conditional tables split over the ranks, completed by the exchange hook -- here broadcasts
+    over gloo) and must agree with the single-rank library walk BIT FOR BIT; 'torch': the torch driver with its pruned
+    candidate exchange (TN_BEAM_TEAM=torch)."""
     import subprocess
     import sys as _sys
     import json as _json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = BEAM_GPU_WORKER % dict(root=root)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577' if team_walk == 'native' else '29578', TN_BEAM_TEAM=team_walk)
     procs = [subprocess.Popen([_sys.executable, '-c', code], env=dict(env, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0'),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = []
@@ -364,10 +381,13 @@ def test_beam_sharded_product_path_two_ranks():
         assert p.returncode == 0, err[-3000:]
         outs.append(_json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][-1][7:]))
     assert outs[0] == outs[1]
+    assert (outs[0]['calls']['native_team'] == 1 and outs[0]['calls']['torch'] == 0) if team_walk == 'native' else outs[0]['calls']['torch'] == 1
     import tnac4o_amd
     J = gi.droplet_J(128, 1)
     s = tnac4o_amd.tnac4o(mode='Ising', Nx=4, Ny=4, Nc=8, J=J, beta=3.0)
     s.search_ground_state(M=256, relative_P_cutoff=1e-8, Dmax=16)
+    if team_walk == 'native':
+        assert outs[0]['probability'] == float(s.probability[0]) and outs[0]['degeneracy'] == int(s.degeneracy)
     assert outs[0]['energy'] == float(s.energy[0])
     assert outs[0]['state'] == [int(x) for x in s.states[0]]
     assert outs[0]['probability'] == pytest.approx(float(s.probability[0]), abs=1e-12)

@@ -211,3 +211,52 @@ def test_shard_range_partitions():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             sizes = [h - l for l, h in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+TEAM_EXCHANGE_WORKER = r'''
+import ctypes as C, json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from tnac4o_amd import beam, parallel
+dist.init_process_group('gloo')
+world, rank = dist.get_world_size(), dist.get_rank()
+B = %(B)d
+group = parallel._beam_groups(world, B)[rank // B]
+team, trank = dist.get_world_size(group), dist.get_rank(group)
+ok = True
+ws = torch.zeros(1 << 16, dtype=torch.uint8)
+fn, err = beam._team_exchange(ws, group)
+for step, (nb, q) in enumerate([(1, 4), (2, 3), (5, 7), (64, 16), (3, 1)]):       # (fewer branches than ranks: empty slices)
+    lp = ws[256:256 + nb * q * 8].view(torch.float64)
+    mp = ws[32768:32768 + nb * 8].view(torch.float64)
+    lp.fill_(float('nan')); mp.fill_(float('nan'))
+    lo, hi = nb * trank // team, nb * (trank + 1) // team
+    want_lp = torch.arange(nb * q, dtype=torch.float64) * 0.5 + 100.0 * step + 7.0 * (rank // B)
+    want_mp = -torch.arange(nb, dtype=torch.float64) - step - 3.0 * (rank // B)
+    lp[lo * q:hi * q] = want_lp[lo * q:hi * q]
+    mp[lo:hi] = want_mp[lo:hi]
+    # what tn_beam_search_team does at every site-step: call the hook with the DEVICE pointers of the two arrays
+    rc = C.cast(fn, beam._EXCHANGE_FN)(None, lp.data_ptr(), mp.data_ptr(), nb, q, trank, team)
+    ok = ok and rc == 0 and not err and torch.equal(lp, want_lp) and torch.equal(mp, want_mp)
+print('RESULT ' + json.dumps({'ok': bool(ok), 'team': team, 'rank': rank}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('nproc,B', [(2, 2), (3, 3), (8, 2)])
+def test_team_exchange_hook_of_the_library_beam_walk(nproc, B):
+    """The exchange function tn_beam_search_team calls once per site-step (tnac4o_amd/beam.py: _team_exchange; include/tnpeps.h:
+    tn_beam_exchange_fn) over gloo: every rank of a team fills its contiguous slice of the log2 p table and of the minima, the hook
+    must leave the complete arrays on every rank -- teams of 2 and 3, the 4 x 2 layout of `bench.py --gpus 8 --beam-shards 2` (four
+    teams exchanging independently), table sizes with empty slices.  (The walk itself needs the GPU library: the two-process GPU test
+    tests/test_gpu_mps.py::test_beam_sharded_product_path_two_ranks runs it through this hook and compares it bit for bit.)"""
+    code = TEAM_EXCHANGE_WORKER % dict(root=ROOT, B=B)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29560 + nproc + B), OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, '-c', code], env=dict(env, RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(nproc)]
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-2000:]
+        res = json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][-1][7:])
+        assert res['ok'] and res['team'] == B, res

@@ -79,6 +79,8 @@ SIGNATURES = {
     'tn_beam_search_ws_bytes': (_i64, [_i64] * 7),
     'tn_beam_search': (_int, [_i64, _i64, _ptr, _i64, _int, _f64, _f64, _i64, _ptr, _ptr, _ptr, _ptr, C.POINTER(_i64), C.POINTER(_f64),
                        C.POINTER(_f64), _ptr, _i64, _ptr]),
+    'tn_beam_search_team': (_int, [_i64, _i64, _ptr, _i64, _int, _f64, _f64, _i64, _ptr, _ptr, _ptr, _ptr, C.POINTER(_i64), C.POINTER(_f64),
+                            C.POINTER(_f64), _ptr, _i64, _ptr, _int, _int, _ptr, _ptr]),
     'tn_profile_enable': (None, [C.c_uint]),
     'tn_profile_reset': (None, []),
     'tn_profile_sample': (None, [C.c_uint]),
@@ -175,7 +177,7 @@ SHORT_CALLS = ('tn_gemm', 'tn_gemm_ws_bytes', 'tn_qr_ws_bytes', 'tn_svd_ws_bytes
                'tn_balance', 'tn_merge_groups', 'tn_svdvals_async', 'tn_rar', 'tn_rar_ws_bytes', 'tn_env_mix', 'tn_env_mix_ws_bytes',
                'tn_apply_truncation', 'tn_apply_truncation_ws_bytes', 'tn_site_qr_ws_bytes', 'tn_gram_weights', 'tn_argsort_desc', 'tn_weighted_sum', 'tn_rows_norm2', 'tn_gather_scale_rows', 'tn_peps_factor', 'tn_mpo_from_factor', 'tn_last_error')
 _lib = None
-ABI_VERSION = 8          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
+ABI_VERSION = 9          # bumped whenever a signature of include/tnpeps.h changes; must equal tn_version()
 
 
 def lib():

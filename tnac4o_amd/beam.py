@@ -240,12 +240,44 @@ class _Cell(C.Structure):
 NATIVE_BEAM = os.environ.get('TN_NATIVE_BEAM', '1') != '0'      # TN_NATIVE_BEAM=0: the torch driver above (search_device)
 
 
-def search_native(solver, M, relative_P_cutoff, min_dEng):
+_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int)
+
+
+def _team_exchange(ws, group):
+    """The exchange function tn_beam_search_team calls once per site-step (include/tnpeps.h): every rank of the team has filled its
+    contiguous slice of the log2 p table and of the minima; one broadcast per rank and array over the team's communicator (RCCL on
+    GPUs, gloo in the rehearsals) completes them everywhere.  The arrays live in the search's workspace `ws` (a torch byte buffer):
+    the pointers are turned back into views of it, so the collectives see ordinary tensors and order themselves behind the
+    launches the library has enqueued on the current stream."""
+    import torch.distributed as dist
+    base = ws.data_ptr()
+    ranks = dist.get_process_group_ranks(group)
+    err = []
+
+    def exchange(ctx, lp, mp, nb, q, rank, team):
+        try:
+            lpt = ws[lp - base:lp - base + nb * q * 8].view(torch.float64)
+            mpt = ws[mp - base:mp - base + nb * 8].view(torch.float64)
+            for r in range(team):
+                lo, hi = nb * r // team, nb * (r + 1) // team
+                if hi > lo:
+                    dist.broadcast(lpt[lo * q:hi * q], src=ranks[r], group=group)
+                    dist.broadcast(mpt[lo:hi], src=ranks[r], group=group)
+            return 0
+        except Exception as e:                               # noqa: BLE001 -- must not propagate through the C frames
+            err.append(e)
+            return 1
+    return _EXCHANGE_FN(exchange), err
+
+
+def search_native(solver, M, relative_P_cutoff, min_dEng, beam_group=None):
     """search_ground_state's loop over rows and sites in ONE library call (tn_beam_search, csrc/beamsearch.hip): this function only
     builds the per-cell tables (the PEPS factors on the device, the index and energy tables of tnac4o._update_Eng) and hands over
     pointers.  Same canonical order and the same arithmetic as search_device, hence the same results bit for bit.  Returns None when
     a site does not fit the library's walk (tn_env_rr_batched holds Dl x (left PEPS bond) <= 2048 accumulators): the caller then takes
-    search_device."""
+    search_device.  beam_group (a torch.distributed group whose ranks all hold rhoT): the team form, tn_beam_search_team -- every
+    rank walks the whole search, the conditional tables of a site-step are split over the ranks and completed by _team_exchange;
+    every rank returns the same result."""
     from ._lib import lib
     Nx, Ny = solver.Nx, solver.Ny
     dev = solver.rhoT[0].A[0].device
@@ -289,9 +321,18 @@ def search_native(solver, M, relative_P_cutoff, min_dEng):
     deg = torch.empty(M, dtype=torch.int64, device=dev)
     nb, pdm, gmin = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
     has_cut = relative_P_cutoff > 0
-    rc = L.tn_beam_search(Nx, Ny, C.cast(cells, C.c_void_p), M, 1 if has_cut else 0, float(np.log2(relative_P_cutoff)) if has_cut else 0.0,
-                          float(min_dEng), maxidx + 1, states.data_ptr(), Eng.data_ptr(), prob.data_ptr(), deg.data_ptr(), C.byref(nb),
-                          C.byref(pdm), C.byref(gmin), ws.data_ptr(), wsb, ops._stream())
+    team, rank, fn, ferr = 1, 0, None, []
+    if beam_group is not None:
+        import torch.distributed as dist
+        team, rank = dist.get_world_size(beam_group), dist.get_rank(beam_group)
+        if team > 1:
+            fn, ferr = _team_exchange(ws, beam_group)
+    rc = L.tn_beam_search_team(Nx, Ny, C.cast(cells, C.c_void_p), M, 1 if has_cut else 0, float(np.log2(relative_P_cutoff)) if has_cut else 0.0,
+                               float(min_dEng), maxidx + 1, states.data_ptr(), Eng.data_ptr(), prob.data_ptr(), deg.data_ptr(), C.byref(nb),
+                               C.byref(pdm), C.byref(gmin), ws.data_ptr(), wsb, ops._stream(), rank, team,
+                               C.cast(fn, C.c_void_p) if fn is not None else None, None)
+    if ferr:
+        raise ferr[0]
     if rc == -6:                                            # no candidate passed the cut-off at some site (include/tnpeps.h)
         del keep
         raise NoCandidate('tn_beam_search: no candidate survives the cut-off')

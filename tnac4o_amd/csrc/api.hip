@@ -76,7 +76,7 @@ using namespace tn;
 
 extern "C" {
 
-int tn_version(void) { return 8; }
+int tn_version(void) { return 9; }
 
 #ifndef TN_SRC_HASH
 #define TN_SRC_HASH "unknown"

@@ -310,7 +310,21 @@ int64_t tn_beam_search_ws_bytes(int64_t Nx, int64_t Ny, int64_t M, int64_t qmax,
 int tn_beam_search(int64_t Nx, int64_t Ny, const tn_beam_cell* cells, int64_t M, int has_cut, double log2_cutoff, double min_dEng, int64_t B,
                    int16_t* states_out, double* energy_out, double* log2p_out, int64_t* deg_out, int64_t* nb_host, double* pd_max_host,
                    double* globalmin_host, void* ws, int64_t ws_bytes, void* stream) {
+    return tn_beam_search_team(Nx, Ny, cells, M, has_cut, log2_cutoff, min_dEng, B, states_out, energy_out, log2p_out, deg_out, nb_host, pd_max_host,
+                               globalmin_host, ws, ws_bytes, stream, 0, 1, nullptr, nullptr);
+}
+
+// The walk shared by a team of `team` ranks (one process per GPU, tnac4o.py:444-453 is what they split): every rank holds the whole beam
+// and walks every site-step; the conditional tables -- the one part of a site-step whose cost grows with the beam -- are evaluated for the
+// rank's contiguous slice of the branches only, then `exchange` (the caller's collective: RCCL / gloo through torch.distributed in
+// tnac4o_amd/beam.py) completes log2 p and the minima on every rank; from there on all ranks run the identical deterministic cut, merge
+// and selection, so the beams stay replicas without any further traffic.
+int tn_beam_search_team(int64_t Nx, int64_t Ny, const tn_beam_cell* cells, int64_t M, int has_cut, double log2_cutoff, double min_dEng, int64_t B,
+                        int16_t* states_out, double* energy_out, double* log2p_out, int64_t* deg_out, int64_t* nb_host, double* pd_max_host,
+                        double* globalmin_host, void* ws, int64_t ws_bytes, void* stream, int rank, int team, tn_beam_exchange_fn exchange,
+                        void* exchange_ctx) {
     TN_CHECK_ARG(Nx >= 1 && Ny >= 1 && M >= 1 && B >= 1 && cells && ws, "bad arguments");
+    TN_CHECK_ARG(team >= 1 && rank >= 0 && rank < team && (team == 1 || exchange != nullptr), "bad team (a team of several ranks needs an exchange function)");
     TN_CHECK_ARG(states_out && energy_out && log2p_out && deg_out && nb_host && pd_max_host && globalmin_host, "null result pointer");
     hipStream_t st = (hipStream_t)stream;
     const int64_t nsites = Nx * Ny, cap = M, ncol = Nx + 1;
@@ -445,8 +459,17 @@ int tn_beam_search(int64_t Nx, int64_t Ny, const tn_beam_cell* cells, int64_t M,
             TAKE(Pn, double, bump, total, "conditional tables");
             TAKE(LP, double, bump, total, "log2 p");
             TAKE(mP, double, bump, nb, "minima");
-            BS(calc_pn(st, T1, RRs[(size_t)lvl], c.F, c.dmap, c.rmap, b0.pref, b0.sufmat + lvl * cap, b0.vind + nx * cap, b0.vind + (nx + 1) * cap, nb, q,
-                       c.nl, c.nu, c.p, c.Dr, c.br, Pn, mP, b0.prob, LP));
+            {
+                // this rank's slice of the branches (the whole beam for a team of one); the exchange fills in the partners' slices
+                const int64_t lo = team > 1 ? nb * rank / team : 0, hi = team > 1 ? nb * (rank + 1) / team : nb;
+                if (hi > lo)
+                    BS(calc_pn(st, T1, RRs[(size_t)lvl], c.F, c.dmap, c.rmap, b0.pref + lo, b0.sufmat + lvl * cap + lo, b0.vind + nx * cap + lo,
+                               b0.vind + (nx + 1) * cap + lo, hi - lo, q, c.nl, c.nu, c.p, c.Dr, c.br, Pn + lo * q, mP + lo, b0.prob + lo, LP + lo * q));
+                if (team > 1) {
+                    const int rcx = exchange(exchange_ctx, LP, mP, nb, q, rank, team);
+                    if (rcx != 0) { set_error("tn_beam_search_team: the exchange function failed (%d) at site (%lld, %lld)", rcx, (long long)ny, (long long)nx); return -8; }
+                }
+            }
             size_t tb = S.cub_bytes;
             BSH(rocprim::reduce(S.cub_tmp, tb, mP, S.scal + 4, std::numeric_limits<double>::max(), (size_t)nb, rocprim::minimum<double>(), st), "beam search: minimum");
             hipLaunchKernelGGL(scalar_min_kernel, dim3(1), dim3(1), 0, st, S.scal, 1, S.scal + 4);

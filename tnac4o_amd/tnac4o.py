@@ -668,13 +668,15 @@ class tnac4o:
         beam_mode = os.environ.get('TN_BEAM', 'device')
         if beam_mode == 'device' and recorder is None and trace is None:
             from . import beam
-            # one rank on the rotation: the whole loop in the library (tn_beam_search); a beam group shares the site-steps through
-            # torch.distributed and keeps the torch driver.  A site-step at which NO candidate passes the cut-off (every log2 p is -inf or
+            # the whole loop in the library: tn_beam_search for one rank on the rotation, tn_beam_search_team for a beam group (the
+            # conditional tables of a site-step split over its ranks, completed through torch.distributed).  A site-step at which NO candidate passes the cut-off (every log2 p is -inf or
             # NaN: a degenerate contraction) is not handled on the device: the search is redone on the host path, which keeps the single
             # best candidate there like the reference's keep = max(count, 1) (tnac4o.py:460-462).
             try:
-                if beam_group is None and beam.NATIVE_BEAM:
-                    E = beam.search_native(self, M, relative_P_cutoff, min_dEng)
+                if beam.NATIVE_BEAM and not (beam_group is not None and os.environ.get('TN_BEAM_TEAM', 'native') == 'torch'):
+                    # (a beam group walks the search in the library too: tn_beam_search_team with the site-steps' conditional tables
+                    #  split over the ranks; TN_BEAM_TEAM=torch keeps the torch driver with its pruned candidate exchange)
+                    E = beam.search_native(self, M, relative_P_cutoff, min_dEng, beam_group=beam_group)
                     if E is not None:
                         return E
                 return beam.search_device(self, M, relative_P_cutoff, min_dEng, beam_group=beam_group)
