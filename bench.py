@@ -146,9 +146,10 @@ def main():
     ap.add_argument('--no-search', action='store_true', help='skip the (untimed) full ground-state search figure')
     ap.add_argument('--beam-shards', default='auto',
                     help="ranks per rotation team when --gpus exceeds the number of rotations: 'auto' (default) = 1, i.e. one working rank per "
-                         "rotation and the other ranks idle -- the library's beam walk of one rank (tn_beam_search, ~0.2 s per rotation) "
-                         "beats the sharded torch driver (DESIGN.md section 6); an integer forces teams of that size, whose owners "
-                         "broadcast the boundary MPS to their beam partners over RCCL inside the timed step")
+                         "rotation and the other ranks idle in the timed sweep step (a sweep is one sequential chain: a partner has nothing "
+                         "to do there but receive the boundary MPS); an integer forces teams of that size, whose owners broadcast the boundary "
+                         "MPS to their beam partners over RCCL inside the timed step and whose search is walked by the whole team in the "
+                         "library (tn_beam_search_team: the conditional tables of a site-step split over the ranks; DESIGN.md section 6)")
     ap.add_argument('--nrot', type=int, default=4, help='lattice rotations of the instance (4 = the reference driver; fewer only for rehearsals)')
     ap.add_argument('--rehearse-one-gpu', action='store_true',
                     help='multi-rank rehearsal on a single GPU: every rank uses cuda:0 and the exchange runs over gloo')
