@@ -262,6 +262,7 @@ struct PassClock {
     bool on;
     std::mutex mu;
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double tr[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};      // truncating passes 2 / 3 / 4: site factorisation | deflation | decomposition | projectors
     double sub[4] = {0, 0, 0, 0};      // inside pass 1: Gram recursion + weights | attach, norms, sort, gather | pivoted factorisation | un-weighting, normalisation
     long calls = 0;
     PassClock() { const char* e = getenv("TN_CHAIN_PASSES"); on = e && e[0] == '1'; }
@@ -273,6 +274,9 @@ struct PassClock {
         for (double v : ms) tot += v;
         fprintf(stderr, "[tn_compress_mps passes] %ld calls, %.1f ms in total\n", calls, tot);
         for (int i = 0; i < 8; ++i) fprintf(stderr, "  %-36s %9.1f ms  %5.1f %%\n", nm[i], ms[i], 100.0 * ms[i] / (tot > 0 ? tot : 1));
+        for (int q = 0; q < 3; ++q)
+            fprintf(stderr, "  inside pass %d: site factorisations %.1f ms | bond deflation %.1f ms | decompositions %.1f ms | projectors %.1f ms\n", q + 2, tr[q][0], tr[q][1],
+                    tr[q][2], tr[q][3]);
         fprintf(stderr, "  inside pass 1: Gram recursion + weights %.1f ms | attach, norms, sort, gather %.1f ms | pivoted factorisation %.1f ms | un-weighting, "
                 "normalisation %.1f ms\n", sub[0], sub[1], sub[2], sub[3]);
     }
@@ -288,6 +292,14 @@ struct PassMark {
         const auto t1 = std::chrono::steady_clock::now();
         std::lock_guard<std::mutex> lk(g_pass_clock.mu);
         g_pass_clock.sub[k] += std::chrono::duration<double, std::milli>(t1 - ts).count();
+        ts = t1;
+    }
+    void trlap(int pass, int k) {
+        if (!g_pass_clock.on || pass < 2 || pass > 4) return;
+        (void)hipStreamSynchronize(st);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> lk(g_pass_clock.mu);
+        g_pass_clock.tr[pass - 2][k] += std::chrono::duration<double, std::milli>(t1 - ts).count();
         ts = t1;
     }
     void substart() { if (g_pass_clock.on) { (void)hipStreamSynchronize(st); ts = std::chrono::steady_clock::now(); } }
@@ -563,16 +575,23 @@ public:
         return 0;
     }
     int pass_id = 0;
+    PassMark* trmark = nullptr;              // TN_CHAIN_PASSES: clock of the truncating pass in progress
     bool pass_truncated = false;             // a truncation of the current pass discarded more than rounding noise (> 32 eps S0)
     bool intermediate_pass = false;          // the 4 chi / 2 chi passes of graduate_truncation (their bonds are internal to compress_mps)
     int truncateC(int64_t Dmax, double tol) {
         if (!(0 < pC && pC < L)) return 0;
         const int64_t Dcap = std::min(Dmax, std::min(C.r, C.c));
-        if (intermediate_pass && gauge_svd_skippable(Dmax, tol)) { gauge_skipped += 1; return deflate_bond(); }
+        if (intermediate_pass && gauge_svd_skippable(Dmax, tol)) {
+            gauge_skipped += 1;
+            const int rcd = deflate_bond();
+            if (trmark) trmark->trlap(pass_id, 1);
+            return rcd;
+        }
         SvdOut o;
         CH(svd_trunc_full(C, Dcap, tol, o));
         const int64_t keep = o.keep;
         if (o.disc > 32.0 * CH_EPS) pass_truncated = true;          // this pass has changed the state by more than rounding
+        if (trmark) trmark->trlap(pass_id, 2);
         {   // TN_DEFLATE_TRACE=1 (diagnostics): what every truncation kept, next to what tn_bond_deflate would keep of the same bond
             static const bool trace = [] { const char* e = getenv("TN_DEFLATE_TRACE"); return e && e[0] == '1'; }();
             if (trace) {
@@ -606,6 +625,7 @@ public:
         CH(apply_truncation(st, Al.p, Al.a * Al.b, Al.c, o.U.p, o.U.c, 1, keep, o.Vt.p, o.Vt.c, 1, Ar.p, Ar.a, Ar.b * Ar.c, o.S, Aln.p, Arn.p, Cd.p, w,
                             wsb));
         A[nl] = Aln; A[nr] = Arn; C = Cd;
+        if (trmark) trmark->trlap(pass_id, 3);
         D[pC] = keep;
         discarded[pC] = std::max(discarded[pC], o.disc);
         return 0;
@@ -663,8 +683,10 @@ public:
         for (int64_t n = 0; n < L; ++n) {
             const double rank_tol = (compress && 0 < n + 1 && n + 1 < L) ? CH_RANK_TOL : 0.0;
             const M2 Cm = C;
+            PassMark tm(st);
+            if (compress) tm.substart();
             CH(site_left(n, &Cm, rank_tol));
-            if (compress) CH(truncateC(Dmax, tol));
+            if (compress) { tm.trlap(pass_id, 0); trmark = &tm; CH(truncateC(Dmax, tol)); trmark = nullptr; }
             if (compress && intermediate_pass) pass_C[pC] = C;
         }
         return 0;
@@ -676,8 +698,10 @@ public:
         for (int64_t n = L - 1; n >= 0; --n) {
             const double rank_tol = (compress && 0 < n && n < L) ? CH_RANK_TOL : 0.0;
             const M2 Cm = C;
+            PassMark tm(st);
+            if (compress) tm.substart();
             CH(site_right(n, &Cm, rank_tol));
-            if (compress) CH(truncateC(Dmax, tol));
+            if (compress) { tm.trlap(pass_id, 0); trmark = &tm; CH(truncateC(Dmax, tol)); trmark = nullptr; }
         }
         return 0;
     }

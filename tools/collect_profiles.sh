@@ -1,9 +1,9 @@
 #!/bin/bash
-# Profile collection (ROUND=r04 by default) on the GPU box (run through gpurun): rocprofv3 kernel statistics of the bench command and
+# Profile collection (ROUND=r05 by default) on the GPU box (run through gpurun): rocprofv3 kernel statistics of the bench command and
 # PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA counters: separate runs, counters never combined with tracing domains) over
 # tools/pmc_probe.py.  Summaries land in gpurun_out/prof_$ROUND/ and are copied into profiles/ by hand.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 OUT=$ROOT/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get('ROUND', 'r04')
+ROUND = os.environ.get('ROUND', 'r05')
 BASE = os.path.join(ROOT, 'gpurun_out', 'prof_' + ROUND)
 
 
@@ -73,10 +73,10 @@ for p in range(32):
 for p in range(16):
     rows = 4096 - 32 * p
     alg += 24.0 * rows * 32
-fam['panel step (cq_fused / cq_gram / cq_pass / cq_post)'] = {'probe_shape': 'tn_qr 16384 x 1024 (32 panels, %s) + tn_qr 4096 x 512 (16 panels, single-launch form)' % ('six-launch chain' if six_launch else 'single-launch form: 64 workgroups'), 'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
+fam['panel step (cq_fused_kernel, sq_kernel)'] = {'probe_shape': 'tn_qr 16384 x 1024 (32 panels, %s) + tn_qr 4096 x 512 (16 panels, single-launch form)' % ('six-launch chain' if six_launch else 'single-launch form: 64 workgroups'), 'dispatches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
                                    'traffic_bytes_per_launch': (fb + wb) / n, 'algorithmic_bytes_per_launch': alg / n,
                                    'traffic_over_algorithmic': (fb + wb) / alg}
-for name, pat in (('eig_small_kernel', 'svdl_kernel'), ('eig_small3_kernel (rounds as separate launches)', 'eig_small'), ('absorb_kernel', 'absorb_mfma_kernel'),
+for name, pat in (('Jacobi rounds (svdl_kernel)', 'svdl_kernel'), ('eig_small3_kernel (rounds as separate launches)', 'eig_small'), ('absorb_kernel', 'absorb_mfma_kernel'),
                   ('sq_kernel (one-launch factorisation)', 'sq_kernel')):
     ks = [k for k in kern if pat in k]
     if ks:
