@@ -274,7 +274,10 @@ struct GemmPlan { int bm, bn, s; };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int64_t batch) {
     static const int64_t small_work = (int64_t)1 << env_int("TN_GEMM_SMALLWORK_LOG2", 30);
-    static const int big_tiles = env_int("TN_GEMM_BIGTILES", 128);     // small products: 128 x 128 tiles from this many workgroups on
+    // small products: 128 x 128 tiles from this many workgroups on.  Round 5: never (was 128) -- the small products with hundreds of big
+    // tiles are the rank-32 updates of the panel loops, HBM round trips of the trailing matrix with two K steps of arithmetic: four times
+    // the workgroups hide their prologues behind each other's epilogues (first pass -2.4 %, four chains 425.8 -> 418.1 ms/sweep)
+    static const int big_tiles = env_int("TN_GEMM_BIGTILES", 1 << 30);
     static const int target_wg = env_int("TN_GEMM_TARGETWG", 256);
     static const int min_chunk = env_int("TN_GEMM_MINCHUNK", 32);
     static const int smax = env_int("TN_GEMM_SMAX", 64);
