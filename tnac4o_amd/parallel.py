@@ -56,6 +56,9 @@ def _make_chain_streams(n):
     return out
 
 
+_LAST_CALL_S = {}                   # (device, chains) -> wall time of the previous run_concurrent call (de-phased starts)
+
+
 def run_concurrent(fns):
     """Run independent chains concurrently on one GPU: each callable gets its own host thread and its own HIP stream
     (one stream per rotation so that the latency-bound chains interleave on the device).  Returns the
@@ -97,12 +100,25 @@ def run_concurrent(fns):
     # it: 1.51 -> 1.62 s/sweep with fresh streams, 1.64 -> 2.36 with reused ones (tools/stream_regime_experiment.py).
     torch.cuda.current_stream().synchronize()
 
-    stagger = float(__import__('os').environ.get('TN_STAGGER_MS', '0')) * 1e-3
+    # De-phased starts.  The chains are structurally identical and start together, so their device-filling phases (the first pass of every
+    # row: half of a chain since round 5) coincide and serialise while nothing latency-bound is there to fill the gaps; started a fraction
+    # of a row apart, one chain's first pass overlaps with the others' truncating passes (four chains at L = 2048: 419 -> 404 ms/sweep for
+    # any offset between 5 and 30 ms).  The offset scales itself: chain i starts i x TN_STAGGER_FRAC (0.7 %) x the duration of the previous
+    # call with the same number of chains -- 12 ms for the 1.7 s step of the headline workload, nothing for the first call and next to
+    # nothing for small problems.  TN_STAGGER_MS=<ms> fixes the offset (0: all chains start together).
+    import os as _os
+    import time as _time
+    env_ms = _os.environ.get('TN_STAGGER_MS')
+    if env_ms is not None:
+        stagger = float(env_ms) * 1e-3
+    else:
+        stagger = float(_os.environ.get('TN_STAGGER_FRAC', '0.007')) * _LAST_CALL_S.get(key, 0.0)
+    t_call = _time.perf_counter()
 
     def work(i):
         try:
             if stagger > 0.0 and i:
-                __import__('time').sleep(i * stagger)      # (experiment: de-phase the chains' device-filling passes)
+                _time.sleep(i * stagger)
             with torch.cuda.stream(streams[i]):
                 out[i] = fns[i]()
                 streams[i].synchronize()
@@ -113,6 +129,7 @@ def run_concurrent(fns):
         t.start()
     for t in th:
         t.join()
+    _LAST_CALL_S[key] = _time.perf_counter() - t_call
     for e in err:
         if e is not None:
             raise e
