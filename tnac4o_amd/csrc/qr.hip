@@ -1396,6 +1396,7 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
     const int* active = piv_dev ? &pst->h.active : nullptr;
     PivMail* ring = piv_dev ? (PivMail*)pinned_host(4 * sizeof(PivMail), 7) : nullptr;
     if (piv_dev && !ring) { set_error("tn_qr: no page-locked memory for the pivoting verdicts"); return 1; }
+    if (piv_dev) for (int i = 0; i < 4; ++i) __atomic_store_n(&ring[i].word, 0ull, __ATOMIC_RELAXED);       // (the slot is shared with other read-backs of this thread: no stale word may look like a stamp)
     thread_local unsigned piv_seq = 0;                        // stamps are unique per host thread (the ring is the thread's own; wrap-around after 2^32 panels is harmless: four entries)
     const unsigned seq0 = piv_seq;
     if (piv_dev) piv_seq += (unsigned)P + 1u;
