@@ -281,6 +281,7 @@ def main():
                       'bonds_without_decomposition_in_intermediate_passes': sum(i.get('gauge_skipped', 0) for i in infos),
                       'rows_with_the_4chi_pass_as_variational_target': sum(i.get('target_swapped', 0) for i in infos),
                       'rows_without_the_4chi_stage_sweep': sum(i.get('var1_skipped', 0) for i in infos),
+                      'sites_absorbed_inside_the_attach': sum(i.get('attach_fused', 0) for i in infos),
                       'what': 'rotation 0, one sweep: fallbacks of the weighted first pass to the plain one (the big plain tn_qr shape), its '
                               'a-posteriori bound, and how often the shortcuts of the intermediate stages applied (csrc/chain.hip)'}
         # launch census of the OTHER rotations (the timed step averages all four; their launch mix differs): one instrumented single-chain
@@ -493,7 +494,10 @@ def main():
             ab = table[5]
             if ab['ms'] > 0:
                 out['absorb_hbm'] = {'achieved': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                     'frac': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                                     'frac': ab['bytes'] / (ab['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 'launches_per_sweep': ab['calls'] // nsw,
+                                     'what': 'absorb_mfma_kernel over the sites that are still materialised -- since round 5 the edge sites only (small '
+                                             'tensors): the absorption of a bulk site rides on the attach products of the first pass and its 134 MB tensor '
+                                             'is never formed (DESIGN.md 4.7); the kernel at the bulk shape moves 4.35 TB/s (PMC probe, 1.04x algorithmic)'}
         if panel_stats is not None:
             out['panel_step'] = panel_stats
         if chain_info is not None:

@@ -640,6 +640,7 @@ public:
     // TN_GAUGE_SVD=1 keeps every decomposition (A/B and the tests that compare the two forms).
     int64_t gauge_skipped = 0;
     int target_swapped = 0, var1_skipped = 0;
+    int64_t attach_fused = 0;                // sites whose absorption went through the factors (never materialised)
     bool gauge_svd_skippable(int64_t Dmax, double tol) const {
         const int keep_mode = [] { const char* e = getenv("TN_GAUGE_SVD"); return e ? atoi(e) : 0; }();   // 1: all, 2: those of the 2 chi pass (read per call: the tests switch it)
         if (keep_mode == 1 || (keep_mode == 2 && pass_id == 3)) return false;
@@ -754,6 +755,43 @@ public:
         G = Gn;
         return 0;
     }
+    // ---- absorption fused into the first contraction (round 5) ----
+    // On the weighted path an absorbed bulk site (A (x) W, 134 MB at chi = 64) is only ever read by ONE product, the attach M_n = A'_n C.
+    // With Hconj the absorbed index order is MPS-major, A'[(alpha l), t, (beta rb)] = sum_s A[alpha, s, beta] W[l, s, rb, t], and the attach
+    // goes through the factors in two products that never form A':
+    //     T[alpha, s, rb, r'] = sum_beta A[alpha, s, beta] C[(beta rb), r']                  (Dl ps) x (bb r) x Dr   -- C read as Dr x (bb r)
+    //     M[(alpha l), t, r'] = sum_{s, rb} W[l, s, rb, t] T[alpha, s, rb, r']               batched over alpha: (ba pt) x r x (ps bb)
+    // 3.2x fewer multiply-adds than the product with the absorbed tensor (K = 64 and 256 instead of 1024), no 134 MB written and read back
+    // per site.  Such sites stay un-absorbed (`p == nullptr`, dimensions set) until something else asks for the tensor (ensure_absorbed:
+    // the plain fallback pass).  TN_ATTACH_FUSED=0 absorbs every site up front (the round-4 form; the tests compare the two).
+    int ensure_absorbed(int64_t n) {
+        if (A[n].p) return 0;
+        if (facA.empty() || !facA[n]) { set_error("tn_compress_mps: site %lld has neither a tensor nor its factors", (long long)n); return -1; }
+        const int64_t* fd = &facdims[7 * n];
+        T3 t;
+        CH(new_t3(A[n].a, A[n].b, A[n].c, t, "absorbed site"));
+        {
+            ProfPhase ph(PH_ABSORB);
+            CH(absorb(st, facA[n], facW[n], t.p, fd[0], fd[1], fd[2], fd[3], fd[4], fd[5], fd[6], hconj, 1, 0, 0, 0));
+        }
+        A[n] = t;
+        return 0;
+    }
+    // Am (Dl_abs p x r) = A'_n C for an un-absorbed site (hconj orientation), C: (Dr_abs x r)
+    int attach_through_factors(int64_t n, const M2& Cm, double* Am) {
+        const int64_t* fd = &facdims[7 * n];
+        const int64_t Dl = fd[0], ps = fd[1], Dr = fd[2], ba = fd[3], po = fd[4], bb = fd[5], pi = fd[6], r = Cm.c;
+        const int64_t pt = pi;                                                  // hconj: s = po (= ps), t = pi
+        if (Cm.r != Dr * bb || po != ps) { set_error("tn_compress_mps: centre matrix does not fit the factors of site %lld", (long long)n); return -1; }
+        Ref tb; double* T = nullptr;
+        CH(new_block(Dl * ps * bb * r, tb, T, "attach through the factors: T"));
+        CH(mm(Dl * ps, bb * r, Dr, facA[n], Dr, 1, Cm.p, bb * r, 1, T, bb * r, 1));
+        // Wq[(l, t), (s, rb)] = W[l, s, rb, t]   (W: (ba, po, bb, pi) contiguous)
+        Ref wb; double* Wq = nullptr;
+        CH(new_block(ba * pt * ps * bb, wb, Wq, "attach through the factors: W"));
+        CH(permute4(st, facW[n], po * bb * pi, 1, bb * pi, pi, ba, pt, ps, bb, Wq));
+        return bmm(Dl, ba * pt, r, ps * bb, Wq, ps * bb, 1, 0, T, r, 1, ps * bb * r, Am, r, 1, ba * pt * r);
+    }
     int canonise_right_weighted(bool& accepted) {
         struct Wt { Ref blk; double* d2 = nullptr; double* st65 = nullptr; bool on = false; };
         std::vector<Wt> wts(L + 1);
@@ -767,6 +805,7 @@ public:
             const bool structured = !facA.empty() && facA[n] != nullptr && Dl >= CH_PASS1_MIN_BOND && G.r == Dl;
             if (structured) CH(gram_step_structured(G, n));
             else {
+                CH(ensure_absorbed(n));
                 Ref xb; double* X = nullptr;
                 CH(new_block(Dl * p * Dr, xb, X, "Gram step X"));
                 CH(mm(Dl, p * Dr, Dl, G.p, Dl, 1, A[n].p, p * Dr, 1, X, p * Dr, 1));
@@ -820,6 +859,7 @@ public:
         std::vector<double*> pending;
         for (int64_t n = L - 1; n >= 0; --n) {
             if (!wts[n].on) {
+                CH(ensure_absorbed(n));
                 const M2 Cm = C;
                 CH(site_right(n, &Cm, 0.0));
                 pending.push_back(nfs_dev + 2 * (nfs_count - 1));
@@ -829,7 +869,8 @@ public:
             const int64_t Dl = A[n].a, p = A[n].b, Dr = A[n].c, r = C.c;
             Ref ab; double* Am = nullptr;
             CH(new_block(Dl * p * r, ab, Am, "attached site"));
-            CH(mm(Dl * p, r, Dr, A[n].p, Dr, 1, C.p, r, 1, Am, r, 1));                      // M_n (attach_AC), viewed (Dl, p r)
+            if (A[n].p) CH(mm(Dl * p, r, Dr, A[n].p, Dr, 1, C.p, r, 1, Am, r, 1));          // M_n (attach_AC), viewed (Dl, p r)
+            else { CH(attach_through_factors(n, C, Am)); attach_fused += 1; }
             Ref wb; double* wv = nullptr;
             CH(new_block(2 * Dl + 2, wb, wv, "row weights"));
             double* rn = wv + Dl;
@@ -1199,6 +1240,14 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
         ch.facW.assign((size_t)L, nullptr);
         ch.facdims.assign((size_t)7 * L, 0);
     }
+    // (absorbed bonds, to know up front whether the weighted first pass will run: only then may bulk sites stay un-absorbed)
+    int64_t Dbig_abs = 1;
+    for (int64_t n = 0; n < L; ++n) {
+        const bool has = mpo_host && mpo_dims_host && mpo_host[n];
+        Dbig_abs = std::max(Dbig_abs, std::max(site_dims_host[3 * n] * (has ? mpo_dims_host[4 * n] : 1), site_dims_host[3 * n + 2] * (has ? mpo_dims_host[4 * n + 2] : 1)));
+    }
+    const bool fuse_attach = [] { const char* e = getenv("TN_ATTACH_FUSED"); return !(e && e[0] == '0'); }() && weighted && structured && hconj == 1 &&
+                             Dbig_abs >= 2 * CH_PASS1_MIN_BOND;
     for (int64_t n = 0; n < L; ++n) {
         const int64_t Dl = site_dims_host[3 * n], p = site_dims_host[3 * n + 1], Dr = site_dims_host[3 * n + 2];
         TN_CHECK_ARG(Dl >= 1 && p >= 1 && Dr >= 1 && sites_host[n], "bad site");
@@ -1207,8 +1256,10 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
             TN_CHECK_ARG(ba >= 1 && po >= 1 && bb >= 1 && pi >= 1 && p == (hconj ? po : pi), "MPO site does not fit the MPS site");
             const int64_t pnew = hconj ? pi : po;
             T3 t;
-            if ((rc = ch.new_t3(Dl * ba, pnew, Dr * bb, t, "absorbed site"))) return rc;
-            {
+            if (fuse_attach && n >= 1 && Dl * ba >= CH_PASS1_MIN_BOND) {           // a weighted site: its absorption rides on the attach (attach_through_factors)
+                t.p = nullptr; t.a = Dl * ba; t.b = pnew; t.c = Dr * bb;
+            } else {
+                if ((rc = ch.new_t3(Dl * ba, pnew, Dr * bb, t, "absorbed site"))) return rc;
                 ProfPhase ph(PH_ABSORB);
                 if ((rc = absorb(st, sites_host[n], mpo_host[n], t.p, Dl, p, Dr, ba, po, bb, pi, hconj, 1, 0, 0, 0))) return rc;
             }
@@ -1244,6 +1295,7 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
         if (!ok) {                                                 // bound not met: the plain pass on the kept input
             ch.A = keepA; ch.D = keepD; ch.nfs_count = keep_nfs;
             ch.reveal_fallbacks += 1;
+            for (int64_t n = 0; n < L; ++n) if ((rc = ch.ensure_absorbed(n))) return rc;
             if ((rc = ch.canonise_right(false, 0, 0.0))) return rc;
         }
     } else if ((rc = ch.canonise_right(false, 0, 0.0))) return rc;
@@ -1333,7 +1385,7 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
         info_host[4] = (double)ch.bonds_before;
         info_host[5] = (double)ch.bonds_after;
         info_host[6] = 0.0;
-        info_host[7] = (double)ch.gauge_skipped + 65536.0 * (double)ch.target_swapped + 131072.0 * (double)ch.var1_skipped;    // (three diagnostics in one word)
+        info_host[7] = (double)ch.gauge_skipped + 65536.0 * (double)ch.target_swapped + 131072.0 * (double)ch.var1_skipped + 262144.0 * (double)ch.attach_fused;    // (four diagnostics in one word)
     }
     // the results are copied out of the arena by the stream; the caller may reuse the arena for the next call on the SAME stream at once
     return 0;

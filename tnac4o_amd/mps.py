@@ -25,6 +25,11 @@ BATCHED_SCHMIDT = os.environ.get('TN_BATCHED_SCHMIDT', '1') != '0'        # smal
 PASS1_STRUCTURED = os.environ.get('TN_PASS1_STRUCTURED', '1') != '0'     # Gram recursion through the MPS (x) MPO structure
 
 
+def _attach_fused():
+    """TN_ATTACH_FUSED=0: the attach of the weighted first pass multiplies with the absorbed tensor (chain.hip; read per call)."""
+    return os.environ.get('TN_ATTACH_FUSED', '1') != '0'
+
+
 def _var1_skip():
     """TN_VAR1_SKIP=0 runs the 4 chi stage's variational sweep even when the state is its own target (chain.hip; read per call)."""
     return os.environ.get('TN_VAR1_SKIP', '1') != '0'
@@ -540,7 +545,8 @@ class MPS:
         the next pass deflates.  The sum of the actual bounds is re-checked from the dropped norms tn_qr reports.
         Host synchronisations: one before the pass, one small read-back per weighted site."""
         L = self.L
-        T = self.A
+        T = list(self.A)
+        self._D_in = list(self.D)
         dev = T[0].device
         # Gram matrices of the left part, bond by bond (G_L(n) belongs to the left bond of site n; G_L(L) = ||psi||^2)
         G = torch.ones((1, 1), dtype=torch.float64, device=dev)
@@ -589,7 +595,18 @@ class MPS:
             d2, _ = weights[n]
             Dl, p, Dr = self.A[n].shape
             r = self.C.shape[1]
-            A = ops.mm(self.A[n].view(Dl * p, Dr), self.C).view(Dl, p * r)          # M_n (attach_AC)
+            fac = absorbed.get(n)
+            if (_attach_fused() and PASS1_STRUCTURED and fac is not None and fac[2] and fac[3].matches(T[n]) and max(self._D_in) >= 2 * PASS1_MIN_BOND):
+                # the attach through the factors of the absorbed site (chain.hip: attach_through_factors): the native driver never forms
+                # the absorbed tensor of such a site; here it exists (apply_mpo made it) but the product takes the same two steps
+                Af, Wf = fac[0].contiguous(), fac[1].contiguous()
+                Dl0, ps, Dr0 = Af.shape
+                ba, po, bb, pi = Wf.shape
+                Tm = ops.mm(Af.view(Dl0 * ps, Dr0), self.C.contiguous().view(Dr0, bb * r))                       # (alpha, s, rb, r')
+                Wq = Wf.permute(0, 3, 1, 2).contiguous().view(1, ba * pi, ps * bb)               # [(l, t), (s, rb)]
+                A = ops.bmm(Wq, Tm.view(Dl0, ps * bb, r)).view(Dl, p * r)
+            else:
+                A = ops.mm(self.A[n].view(Dl * p, Dr), self.C).view(Dl, p * r)      # M_n (attach_AC)
             w, wsum = ops.weighted_sum(d2, ops.rows_norm2(A))
             host = torch.cat([wsum] + [f[:1] for f in pending]).cpu().numpy()       # the per-site read-back
             for x in host[1:]:

@@ -616,7 +616,7 @@ def compress_mps_native(sites, mpo_sites, hconj, Dmax, tolS, tolV, max_sweeps, g
         k = int(slen[i])
         S.append(None if k < 0 else np.array(sch[i * pitch:i * pitch + k], dtype=np.float64))
     return dict(A=A, overlap=float(overlap.value), discarded=[float(x) for x in disc], S=S, nfs=[nfs[i] for i in range(int(ncount.value))],
-                info=dict(reveal_error_bound=float(info[0]), reveal_fallbacks=int(info[1]), weighted_used=bool(info[2]), arena_peak=int(info[3]), bonds_before=int(info[4]), bonds_after=int(info[5]), redone=int(info[6]), gauge_skipped=int(info[7]) % 65536, target_swapped=(int(info[7]) // 65536) % 2, var1_skipped=(int(info[7]) // 131072) % 2,
+                info=dict(reveal_error_bound=float(info[0]), reveal_fallbacks=int(info[1]), weighted_used=bool(info[2]), arena_peak=int(info[3]), bonds_before=int(info[4]), bonds_after=int(info[5]), redone=int(info[6]), gauge_skipped=int(info[7]) % 65536, target_swapped=(int(info[7]) // 65536) % 2, var1_skipped=(int(info[7]) // 131072) % 2, attach_fused=int(info[7]) // 262144,
                           arena_bytes=int(arena.numel())))
 
 
