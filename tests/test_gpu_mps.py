@@ -663,7 +663,7 @@ def test_pass_shortcuts_match_full_passes(L, chi, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('L,chi,rot,bottom', [(128, 8, 3, False), (128, 32, 0, True), (512, 32, 1, False), (2048, 64, 0, False)])
+@pytest.mark.parametrize('L,chi,rot,bottom', [(128, 8, 3, False), (128, 32, 0, True), (512, 32, 1, False), (2048, 64, 0, False), (2048, 64, 2, True)])
 def test_native_chain_driver_bit_identical_to_python_driver(L, chi, rot, bottom):
     """tn_compress_mps (apply_mpo + compress_mps of a row in ONE library call, walked in C++: csrc/chain.hip) against the Python
     driver that issues the same steps one library call at a time (MPS._compress_python): a whole sweep -- absorption, the weighted

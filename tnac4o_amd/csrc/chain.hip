@@ -777,20 +777,29 @@ public:
         A[n] = t;
         return 0;
     }
-    // Am (Dl_abs p x r) = A'_n C for an un-absorbed site (hconj orientation), C: (Dr_abs x r)
+    // Am (Dl_abs p x r) = A'_n C for an un-absorbed site, C: (Dr_abs x r).  Without Hconj the fused bonds are MPO-major,
+    //     A'[(l alpha), t, (rb beta)] = sum_s W[l, t, rb, s] A[alpha, s, beta]:
+    // the first product runs per rb (C read as bb matrices Dr x r, T written in the same (alpha, s, rb, r') layout), the second is the same
+    // batched product with W[(l, t), (s, rb)], and its (alpha, l, t, r') result is moved to (l, alpha, t, r') by one more pass over it.
     int attach_through_factors(int64_t n, const M2& Cm, double* Am) {
         const int64_t* fd = &facdims[7 * n];
         const int64_t Dl = fd[0], ps = fd[1], Dr = fd[2], ba = fd[3], po = fd[4], bb = fd[5], pi = fd[6], r = Cm.c;
-        const int64_t pt = pi;                                                  // hconj: s = po (= ps), t = pi
-        if (Cm.r != Dr * bb || po != ps) { set_error("tn_compress_mps: centre matrix does not fit the factors of site %lld", (long long)n); return -1; }
+        const int64_t pt = hconj ? pi : po;                                     // hconj: s = po, t = pi; else s = pi, t = po
+        if (Cm.r != Dr * bb || (hconj ? po : pi) != ps) { set_error("tn_compress_mps: centre matrix does not fit the factors of site %lld", (long long)n); return -1; }
         Ref tb; double* T = nullptr;
         CH(new_block(Dl * ps * bb * r, tb, T, "attach through the factors: T"));
-        CH(mm(Dl * ps, bb * r, Dr, facA[n], Dr, 1, Cm.p, bb * r, 1, T, bb * r, 1));
-        // Wq[(l, t), (s, rb)] = W[l, s, rb, t]   (W: (ba, po, bb, pi) contiguous)
+        if (hconj) CH(mm(Dl * ps, bb * r, Dr, facA[n], Dr, 1, Cm.p, bb * r, 1, T, bb * r, 1));
+        else CH(bmm(bb, Dl * ps, r, Dr, facA[n], Dr, 1, 0, Cm.p, r, 1, Dr * r, T, bb * r, 1, r));
+        // Wq[(l, t), (s, rb)] = W[l, s, rb, t] (hconj) | W[l, t, rb, s]   (W: (ba, po, bb, pi) contiguous)
         Ref wb; double* Wq = nullptr;
         CH(new_block(ba * pt * ps * bb, wb, Wq, "attach through the factors: W"));
-        CH(permute4(st, facW[n], po * bb * pi, 1, bb * pi, pi, ba, pt, ps, bb, Wq));
-        return bmm(Dl, ba * pt, r, ps * bb, Wq, ps * bb, 1, 0, T, r, 1, ps * bb * r, Am, r, 1, ba * pt * r);
+        if (hconj) CH(permute4(st, facW[n], po * bb * pi, 1, bb * pi, pi, ba, pt, ps, bb, Wq));
+        else CH(permute4(st, facW[n], po * bb * pi, bb * pi, 1, pi, ba, pt, ps, bb, Wq));
+        if (hconj) return bmm(Dl, ba * pt, r, ps * bb, Wq, ps * bb, 1, 0, T, r, 1, ps * bb * r, Am, r, 1, ba * pt * r);
+        Ref mb; double* Mt = nullptr;
+        CH(new_block(Dl * ba * pt * r, mb, Mt, "attach through the factors: M (MPS-major)"));
+        CH(bmm(Dl, ba * pt, r, ps * bb, Wq, ps * bb, 1, 0, T, r, 1, ps * bb * r, Mt, r, 1, ba * pt * r));
+        return permute4(st, Mt, pt * r, ba * pt * r, r, 1, ba, Dl, pt, r, Am);        // Mt (alpha, l, t, r') -> Am (l, alpha, t, r')
     }
     int canonise_right_weighted(bool& accepted) {
         struct Wt { Ref blk; double* d2 = nullptr; double* st65 = nullptr; bool on = false; };
@@ -1246,7 +1255,7 @@ static int compress_mps_once(int64_t L, const double* const* sites_host, const i
         const bool has = mpo_host && mpo_dims_host && mpo_host[n];
         Dbig_abs = std::max(Dbig_abs, std::max(site_dims_host[3 * n] * (has ? mpo_dims_host[4 * n] : 1), site_dims_host[3 * n + 2] * (has ? mpo_dims_host[4 * n + 2] : 1)));
     }
-    const bool fuse_attach = [] { const char* e = getenv("TN_ATTACH_FUSED"); return !(e && e[0] == '0'); }() && weighted && structured && hconj == 1 &&
+    const bool fuse_attach = [] { const char* e = getenv("TN_ATTACH_FUSED"); return !(e && e[0] == '0'); }() && weighted && structured &&
                              Dbig_abs >= 2 * CH_PASS1_MIN_BOND;
     for (int64_t n = 0; n < L; ++n) {
         const int64_t Dl = site_dims_host[3 * n], p = site_dims_host[3 * n + 1], Dr = site_dims_host[3 * n + 2];

@@ -596,15 +596,22 @@ class MPS:
             Dl, p, Dr = self.A[n].shape
             r = self.C.shape[1]
             fac = absorbed.get(n)
-            if (_attach_fused() and PASS1_STRUCTURED and fac is not None and fac[2] and fac[3].matches(T[n]) and max(self._D_in) >= 2 * PASS1_MIN_BOND):
+            if (_attach_fused() and PASS1_STRUCTURED and fac is not None and fac[3].matches(T[n]) and max(self._D_in) >= 2 * PASS1_MIN_BOND):
                 # the attach through the factors of the absorbed site (chain.hip: attach_through_factors): the native driver never forms
-                # the absorbed tensor of such a site; here it exists (apply_mpo made it) but the product takes the same two steps
+                # the absorbed tensor of such a site; here it exists (apply_mpo made it) but the product takes the same steps
                 Af, Wf = fac[0].contiguous(), fac[1].contiguous()
                 Dl0, ps, Dr0 = Af.shape
                 ba, po, bb, pi = Wf.shape
-                Tm = ops.mm(Af.view(Dl0 * ps, Dr0), self.C.contiguous().view(Dr0, bb * r))                       # (alpha, s, rb, r')
-                Wq = Wf.permute(0, 3, 1, 2).contiguous().view(1, ba * pi, ps * bb)               # [(l, t), (s, rb)]
-                A = ops.bmm(Wq, Tm.view(Dl0, ps * bb, r)).view(Dl, p * r)
+                if fac[2]:                                                                       # Hconj: MPS-major fused bonds
+                    Tm = ops.mm(Af.view(Dl0 * ps, Dr0), self.C.contiguous().view(Dr0, bb * r))                   # (alpha, s, rb, r')
+                    Wq = Wf.permute(0, 3, 1, 2).contiguous().view(1, ba * pi, ps * bb)           # [(l, t), (s, rb)]
+                    A = ops.bmm(Wq, Tm.view(Dl0, ps * bb, r)).view(Dl, p * r)
+                else:                                                                            # MPO-major: one product per rb, result moved to (l, alpha)
+                    Tm = torch.empty((Dl0 * ps, bb, r), dtype=torch.float64, device=dev)          # (alpha, s, rb, r')
+                    ops.bmm(Af.view(1, Dl0 * ps, Dr0), self.C.contiguous().view(bb, Dr0, r), out=Tm.permute(1, 0, 2))
+                    Wq = Wf.permute(0, 1, 3, 2).contiguous().view(1, ba * po, ps * bb)           # [(l, t), (s, rb)]
+                    Mt = ops.bmm(Wq, Tm.view(Dl0, ps * bb, r))                                   # (alpha, (l, t), r')
+                    A = Mt.view(Dl0, ba, po * r).permute(1, 0, 2).contiguous().view(Dl, p * r)
             else:
                 A = ops.mm(self.A[n].view(Dl * p, Dr), self.C).view(Dl, p * r)      # M_n (attach_AC)
             w, wsum = ops.weighted_sum(d2, ops.rows_norm2(A))
