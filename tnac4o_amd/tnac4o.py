@@ -17,18 +17,27 @@ import logging
 import os
 
 import numpy as np
+import functools
+
 import torch
 
 from . import mps, ops
 
 
+@functools.lru_cache(maxsize=64)
 def _bits(n):
+    # (memoised, read-only: a sweep asks for the same handful of tables four times per site)
     s = np.arange(2 ** n)[:, None]
-    return ((s >> np.arange(n)[None, :]) & 1).astype(np.int64)
+    out = ((s >> np.arange(n)[None, :]) & 1).astype(np.int64)
+    out.setflags(write=False)
+    return out
 
 
+@functools.lru_cache(maxsize=64)
 def _spins(n):
-    return 1 - 2 * _bits(n)
+    out = 1 - 2 * _bits(n)
+    out.setflags(write=False)
+    return out
 
 
 def _dev_f64(x):
@@ -361,31 +370,50 @@ class tnac4o:
             dmap = s % pd if pd > 1 else np.zeros(q, dtype=int)
         return Es, np.ascontiguousarray(E1), np.ascontiguousarray(E4), dmap, rmap, int(pd), int(br)
 
-    def _peps_factor_dev(self, ny, nx):
-        """(F, dmap, rmap, pd, br) as device tensors (K7, tn_peps_factor).  The seven small float tables of a cell travel in ONE
-        host-to-device copy and the two index maps in another (nine separate copies cost the sweep 45 ms of host time per chain)."""
+    def _peps_factors_dev(self, cells):
+        """[(F, dmap, rmap, pd, br)] as device tensors for a list of cells (K7, tn_peps_factor).  The seven small float tables of ALL the
+        cells travel in ONE host-to-device copy and their index maps in another (nine separate copies per cell cost the sweep 45 ms of
+        host time per chain in round 3; two per cell still 11 ms); the kernels run per cell on views of the two buffers."""
         keep = getattr(self, '_factor_keep', None)                 # set for the duration of one search_ground_state call
-        if keep is not None and (ny, nx) in keep:
-            return keep[(ny, nx)]
-        Es, E1, E4, dmap, rmap, pd, br = self._site_tables(ny, nx)
-        nl, nu = E1.shape[1], E4.shape[1]
-        parts = [np.ravel(Es), np.ravel(E1), np.ravel(E4), np.ravel(self.Xu[ny][nx][:nu]), np.ravel(self.Xl[ny][nx][:nl]),
-                 np.ravel(self.Xr[ny][nx]), np.ravel(self.Xd[ny][nx])]
-        sizes = [int(x.size) for x in parts]
-        pad = [(-n) % 2 for n in sizes]                         # keep every table 16-byte aligned inside the packed buffer
-        host = np.concatenate([np.concatenate([np.asarray(x, dtype=np.float64), np.zeros(k)]) for x, k in zip(parts, pad)])
-        dev = torch.as_tensor(host).cuda()
-        views, off = [], 0
-        for n, k in zip(sizes, pad):
-            views.append(dev[off:off + n])
-            off += n + k
-        q = int(np.size(Es))
-        maps = torch.as_tensor(np.concatenate([np.asarray(dmap, dtype=np.int32), np.asarray(rmap, dtype=np.int32)])).cuda()
-        dm, rm = maps[:q], maps[q:]
-        F = ops.peps_factor(views[0], views[1].view(q, nl), views[2].view(q, nu), views[3], views[4], views[5], views[6], dm, rm)
-        if keep is not None:
-            keep[(ny, nx)] = (F, dm, rm, pd, br)
-        return F, dm, rm, pd, br
+        out = [keep.get(c) if keep is not None else None for c in cells]
+        todo = [i for i, o in enumerate(out) if o is None]
+        if not todo:
+            return out
+        fparts, iparts, meta = [], [], []
+        for i in todo:
+            ny, nx = cells[i]
+            Es, E1, E4, dmap, rmap, pd, br = self._site_tables(ny, nx)
+            nl, nu = E1.shape[1], E4.shape[1]
+            parts = [np.ravel(Es), np.ravel(E1), np.ravel(E4), np.ravel(self.Xu[ny][nx][:nu]), np.ravel(self.Xl[ny][nx][:nl]),
+                     np.ravel(self.Xr[ny][nx]), np.ravel(self.Xd[ny][nx])]
+            sizes = [int(x.size) for x in parts]
+            for x, n in zip(parts, sizes):                      # every table stays 16-byte aligned inside the packed buffer
+                fparts.append(np.asarray(x, dtype=np.float64))
+                if n % 2:
+                    fparts.append(np.zeros(1))
+            q = int(np.size(Es))
+            iparts.append(np.asarray(dmap, dtype=np.int32))
+            iparts.append(np.asarray(rmap, dtype=np.int32))
+            meta.append((i, sizes, q, nl, nu, pd, br))
+        dev = torch.as_tensor(np.concatenate(fparts)).cuda()
+        maps = torch.as_tensor(np.concatenate(iparts)).cuda()
+        off = ioff = 0
+        for i, sizes, q, nl, nu, pd, br in meta:
+            views = []
+            for n in sizes:
+                views.append(dev[off:off + n])
+                off += n + (n % 2)
+            dm, rm = maps[ioff:ioff + q], maps[ioff + q:ioff + 2 * q]
+            ioff += 2 * q
+            F = ops.peps_factor(views[0], views[1].view(q, nl), views[2].view(q, nu), views[3], views[4], views[5], views[6], dm, rm)
+            out[i] = (F, dm, rm, pd, br)
+            if keep is not None:
+                keep[cells[i]] = out[i]
+        return out
+
+    def _peps_factor_dev(self, ny, nx):
+        """(F, dmap, rmap, pd, br) of one cell as device tensors."""
+        return self._peps_factors_dev([(ny, nx)])[0]
 
     def _mpo_site_dev(self, ny, nx):
         """Row-MPO site W[l,d,r,u] built on the device (K7, tn_mpo_from_factor)."""
@@ -402,8 +430,8 @@ class tnac4o:
 
     def _row_mpo(self, ny):
         At = mps.MPO(L=self.Nx)
-        for nx in range(self.Nx):
-            At.set_direct(self._mpo_site_dev(ny, nx), nx)
+        for nx, (F, dm, rm, pd, br) in enumerate(self._peps_factors_dev([(ny, nx) for nx in range(self.Nx)])):
+            At.set_direct(ops.mpo_from_factor(F, dm, rm, pd, br), nx)
         return At
 
     # ------------------------------------------------------------------------------------ sweeps (GPU)
