@@ -395,11 +395,18 @@ def test_peps_factor_and_mpo_builder(ops, rot):
             assert np.array_equal(host(dm.double()), dmap) and np.array_equal(host(rm.double()), rmap)
             np.testing.assert_allclose(host(Fd), F, rtol=4e-16 * 8, atol=0)
             np.testing.assert_allclose(host(s._mpo_site_dev(ny, nx)), s._mpo_site(ny, nx), rtol=1e-14, atol=0)
+        # the row form (all cells of a row through one packed copy) gives the per-cell results bit for bit
+        row = s._row_mpo(ny)
+        for nx in range(4):
+            assert torch.equal(row.W[nx], s._mpo_site_dev(ny, nx))
     J = gi.minimal_rmf()
     r = tnac4o_amd.tnac4o(mode='RMF', Nx=J['Nx'], Ny=J['Ny'], J=J, beta=2.0)
     for ny in range(r.Ny):
         for nx in range(r.Nx):
             np.testing.assert_allclose(host(r._mpo_site_dev(ny, nx)), r._mpo_site(ny, nx), rtol=1e-14, atol=0)
+        row = r._row_mpo(ny)
+        for nx in range(r.Nx):
+            assert torch.equal(row.W[nx], r._mpo_site_dev(ny, nx))
 
 
 def test_linalg_fuzz_against_numpy():
