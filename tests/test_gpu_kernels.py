@@ -834,6 +834,46 @@ def test_tiny_qr_single_workgroup(ops):
             assert np.abs(Q0.cpu().numpy() - Qh).max() <= 1e-11, name
 
 
+def test_q_accumulation_through_merged_reflectors(ops):
+    """Single-level tn_qr from two panels on applies the reflectors to Q four panels at a time (apply_merged_T_kernel: block back
+    substitution with the panels' T factors and the Gram matrix of the reflectors) -- against the panel-by-panel accumulation
+    (TN_QR_MERGED_Q=0): the same R bit for bit (the forward loop is untouched), Q to rounding, orthonormal, Q R = A; widths that are
+    not multiples of 32 or 128, both memory layouts, a graded matrix, and the pivoted truncating site factorisation."""
+    g = torch.Generator(device='cpu').manual_seed(23)
+    rn = lambda *sh: torch.randn(*sh, dtype=torch.float64, generator=g)
+    graded = rn(3000, 300) * torch.logspace(0, -12, 300, dtype=torch.float64)[None, :]
+    cases = [('2000x73', rn(2000, 73)), ('1500x200', rn(1500, 200)), ('4096x300', rn(4096, 300)), ('700x480', rn(700, 480)),
+             ('row-major view', rn(260, 2500).t()), ('wide', rn(600, 900)), ('graded', graded), ('129 columns', rn(5000, 129))]
+    for name, Th in cases:
+        T = Th.cuda()
+        m, n = T.shape
+        k = min(m, n)
+        Q, R = ops.qr(T)
+        Q0, R0 = _with_env('TN_QR_MERGED_Q', '0', lambda: ops.qr(T))
+        Qh, Rh, A = Q.cpu().numpy(), R.cpu().numpy(), Th.numpy()
+        sc = np.abs(A).max()
+        assert torch.equal(R, R0), name
+        assert np.abs(Qh.T @ Qh - np.eye(k)).max() < 2e-13, name
+        assert np.abs(Qh @ Rh - A).max() <= 2e-13 * sc, name
+        assert np.abs(Q0.cpu().numpy() - Qh).max() <= 1e-12, name
+    # pivoted, truncating (the first pass's factorisation): same rank, same permuted triangular factor, the bases agree to rounding
+    U = torch.linalg.qr(rn(768, 200))[0]
+    V = torch.linalg.qr(rn(16 * 150, 200))[0]
+    B = ((U * torch.logspace(0, -18, 200, dtype=torch.float64)[None, :]) @ V.t()).contiguous()
+    B = B[torch.argsort(B.norm(dim=1), descending=True)].contiguous().view(768, 16, 150).cuda()
+    outs = []
+    for mode in ('1', '0'):
+        info = {}
+        outs.append(_with_env('TN_QR_MERGED_Q', mode, lambda: ops.site_qr(1, B.clone(), None, rank_tol=1e-9, normalise=False, info=info,
+                                                                        frobenius_exit=True, pivot=True)) + (info,))
+    (Q1, R1, k1, _, i1), (Q2, R2, k2, _, i2) = outs
+    assert k1 == k2 and 64 < k1 < 200
+    assert torch.equal(R1, R2)
+    assert float((Q1 - Q2).abs().max()) <= 1e-12
+    Q1f = Q1.reshape(k1, -1)
+    assert float((Q1f @ Q1f.t() - torch.eye(k1, dtype=torch.float64, device='cuda')).abs().max()) < 2e-13
+
+
 def test_hard_panels_of_a_real_sweep(ops):
     """tests/golden/g12_hard_panels.npz: the panels of tn_qr that needed FOUR substitution passes in the boundary-MPS sweep of the
     headline instance (chimera L = 2048, chi = 64, seed 20260004; 11 of 6 025 panels, the nine of <= 4096 rows kept; condition numbers

@@ -1193,6 +1193,81 @@ __global__ __launch_bounds__(256) void swap_columns_dev_kernel(double* __restric
 // single-workgroup kernels -- while the device-filling update of everything to the right of it runs on `aux`.  Ordering:
 // aux waits for panel p's reflectors (ev.panel), the caller's stream waits for the wide update of panel p-1 before it touches
 // the columns of panel p+1 (ev.wide); W = Y T^T and the split-K scratch are double-buffered between the two streams.
+// ---- Q accumulation through merged reflectors (round 5) ---------------------------------------------------------------------
+// The single-level paths used to apply every 32-wide reflector to Q on its own: per panel a split-K product Y_p^T Q, its reduction and a
+// rank-32 update -- three launches and three passes over Q[j0:, j0:] per panel, ~35 us each in the pivoted factorisations of the first
+// pass (2 550 panels per sweep).  Here QMB / 32 consecutive panels act at once,
+//      H_1 ... H_q = I - Y_blk T_blk Y_blk^T,      T_blk^-1 = [[T_1^-1, Y_1^T Y_2, ...], [0, T_2^-1, ...], ...]
+// (block upper triangular: the inverse of dlarft's merged factor has the panels' own T_p^-1 on the diagonal and the blocks of the Gram
+// matrix G = Y_blk^T Y_blk above it), so X = T_blk (Y_blk^T Q) is a block back substitution,  X_q = T_q (Z_q - sum_{j > q} G_qj X_j),
+// done by ONE small launch per outer block; T_blk itself is never formed.  Per outer block: G, Z = Y_blk^T Q, the substitution, and a
+// rank-QMB update -- four products and three reductions less per four panels, a quarter of the passes over Q.
+constexpr int QMB = 128;
+// rows of an outer block above each panel's own top block must read as zero in the merged reflector (the workspace is reused)
+__global__ __launch_bounds__(256) void zero_above_panels_kernel(double* __restrict__ Y, int64_t rs, int64_t cs, int64_t k, int nb) {
+    const int64_t J0 = (int64_t)blockIdx.y * QMB;
+    const int bw = (int)((k - J0 < QMB) ? k - J0 : QMB);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < bw * bw; e += gridDim.x * 256) {
+        const int i = e / bw, j = e % bw;
+        if (i / nb < j / nb) Y[(J0 + i) * rs + (J0 + j) * cs] = 0.0;
+    }
+}
+// X (bw x nq, row-major) = T_blk Z by block back substitution; G: bw x bw row-major (pitch bw); T: the block's first panel factor
+// (b x b row-major each, pitch b, 32 x 32 doubles apart).  One workgroup = 32 columns of Z; per panel (last to first) the block row of G
+// and T_q are staged in LDS and the two small products run on the matrix cores: wave w owns the 16 x 16 tile (w / 2, w % 2) of the
+// 32 x 32 result.  (A first version with one thread per 4 x 1 entries and G read from memory inside the dependent loop took 85 us.)
+__global__ __launch_bounds__(256) void apply_merged_T_kernel(const double* __restrict__ Z, int64_t nq, const double* __restrict__ G, int bw,
+                                                             const double* __restrict__ T, int npan, double* __restrict__ X) {
+    __shared__ double xs[QMB][33];           // X so far (rows of the panels already substituted)
+    __shared__ double vs[32][33];            // Z_q - sum_j G_qj X_j
+    __shared__ double gs[32][QMB - 32 + 1];  // block row of G to the right of panel q
+    __shared__ double ts[32][33];            // T_q
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4, ti = wave >> 1, tj = wave & 1;
+    const int64_t c0 = (int64_t)blockIdx.x * 32;
+    for (int q = npan - 1; q >= 0; --q) {
+        const int r0 = q * 32, bq = (bw - r0 < 32) ? bw - r0 : 32, kr = bw - r0 - 32;       // kr: columns of G right of the panel (<= 96)
+        for (int e = tid; e < 32 * (kr > 0 ? kr : 0); e += 256) {
+            const int i = e / kr, j = e % kr;
+            gs[i][j] = (i < bq) ? G[(int64_t)(r0 + i) * bw + r0 + 32 + j] : 0.0;
+        }
+        for (int e = tid; e < 1024; e += 256) {
+            const int i = e >> 5, l = e & 31;
+            ts[i][l] = (i < bq && l < bq) ? T[(int64_t)q * 1024 + i * bq + l] : 0.0;
+        }
+        d4q acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + lk + 4 * r;
+            const int64_t c = c0 + 16 * tj + lr;
+            acc[r] = (i < bq && c < nq) ? Z[(int64_t)(r0 + i) * nq + c] : 0.0;
+        }
+        __syncthreads();
+        for (int kk = 0; kk < kr; kk += 4) {
+            const int k = kk + lk;
+            const double a = (k < kr) ? -gs[16 * ti + lr][k] : 0.0;
+            const double b = (k < kr) ? xs[r0 + 32 + k][16 * tj + lr] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vs[16 * ti + lk + 4 * r][16 * tj + lr] = acc[r];
+        __syncthreads();
+        d4q x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 4) {
+            const int k = kk + lk;
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(ts[16 * ti + lr][k], vs[k][16 * tj + lr], x, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xs[r0 + 16 * ti + lk + 4 * r][16 * tj + lr] = x[r];
+        __syncthreads();
+    }
+    for (int e = tid; e < bw * 32; e += 256) {
+        const int i = e >> 5, cc = e & 31;
+        if (c0 + cc < nq) X[(int64_t)i * nq + c0 + cc] = xs[i][cc];
+    }
+}
+
 struct LookaheadEvents {
     hipEvent_t panel[2] = {nullptr, nullptr}, wide[2] = {nullptr, nullptr};
     bool ok = false;
@@ -1636,6 +1711,29 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
         TN_CHECK_LAUNCH("assemble_R_init_Q_kernel");
     }
     Mat Qm = mat(Q, qrs, qcs);
+    // merged reflectors (see apply_merged_T_kernel): from two panels on, unless the small-matrix fold above already took the last one
+    // (TN_QR_MERGED_Q=0 keeps the panel-by-panel accumulation; read per call: the tests switch it)
+    const bool merged_q = wform && Q != nullptr && P >= 2 && fold_b == 0 && [] { const char* e = getenv("TN_QR_MERGED_Q"); return !(e && e[0] == '0'); }();
+    if (merged_q) {
+        const int nblk = (int)cdiv(k, QMB);
+        TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(zero_above_panels_kernel, dim3(16, (unsigned)nblk), dim3(256), 0, st, w.Y, yrs, ycs, k, nb));
+        TN_CHECK_LAUNCH("zero_above_panels_kernel");
+        for (int bi = nblk - 1; bi >= 0; --bi) {
+            const int64_t J0 = (int64_t)bi * QMB;
+            const int bw = (int)((k - J0 < QMB) ? k - J0 : QMB);
+            const int64_t mb = m - J0, nq = k - J0;
+            const int npan = (int)cdiv(bw, nb);
+            Mat Yb = sub(Ym, J0, J0), Qb = sub(Qm, J0, J0), Z = mat(w.Zo, nq, 1), X = mat(w.Zo2, nq, 1), Gm = mat(w.G, bw, 1);
+            if (npan > 1 && (rc = gemm(st, bw, bw, mb, 1.0, tr(Yb), Yb, 0.0, Gm, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+            // (the last block meets [Z; 0]: only its top bw rows are non-zero, the product over the rest adds zeros)
+            if ((rc = gemm(st, bw, nq, bi == nblk - 1 ? (int64_t)bw : mb, 1.0, tr(Yb), Qb, 0.0, Z, w.gemm_ws, w.gemm_ws_bytes))) return rc;
+            TN_PROF_LAUNCH(st, PROF_QR_AUX, hipLaunchKernelGGL(apply_merged_T_kernel, dim3((unsigned)cdiv(nq, 32)), dim3(256), 0, st, (const double*)Z.p, nq,
+                               (const double*)Gm.p, bw, (const double*)(w.T + (J0 / nb) * nb * nb), npan, X.p));
+            TN_CHECK_LAUNCH("apply_merged_T_kernel");
+            if ((rc = gemm(st, mb, nq, bw, -1.0, Yb, X, 1.0, Qb))) return rc;
+        }
+        return 0;
+    }
     for (int p = P - 1 - (fold_b > 0 ? 1 : 0); p >= 0; --p) {
         const int64_t j0 = (int64_t)p * nb;
         const int b = (int)((k - j0 < nb) ? k - j0 : nb);
