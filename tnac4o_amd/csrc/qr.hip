@@ -1145,9 +1145,27 @@ __global__ __launch_bounds__(256) void pivot_select_kernel(const double* __restr
     const bool isD = lane < b && !selfront;
     const bool mv1 = lane < b && st != lane;
     unsigned long long bD = 0ull, b1 = 0ull;
-    if (lane < 64) { bD = __ballot(isD); b1 = __ballot(mv1); }
-    if (isV) vpos[rankV] = st;
+    if (lane < 64) {
+        // safety net: the b selections must be b distinct trailing positions.  They feed the column moves of the next launch, where a
+        // wrong index would be an out-of-range access; a selection that is not a valid set (never seen; it would mean a published
+        // selection was not visible to this workgroup) stops the factorisation with an error mark instead (stamp < 0, read by the host)
+        bool dup = false;
+        for (int t = 0; t < b; ++t) { const int x = __shfl(st, t, 64); dup = dup || (t != lane && x == st); }
+        const bool wrong = lane < b && (st < 0 || st >= ntr || dup);
+        const unsigned long long bw = __ballot(wrong);
+        if (lane == 0) s_last = (bw != 0ull) ? 2 : 1;
+        bD = __ballot(isD); b1 = __ballot(mv1);
+    }
+    if (isV && rankV < 32) vpos[rankV] = st;
     __syncthreads();
+    if (s_last == 2) {
+        if (tid == 0) {
+            S->ticket = 0;
+            S->h.swap_n = 0; S->h.k_exit = j0; S->h.stamp = -(p + 1); S->h.dropped2 = 0.0; S->h.active = 0;
+            piv_post(mail, 0, j0, stamp);
+        }
+        return;
+    }
     const unsigned long long below = (lane < 64) ? ((1ull << lane) - 1ull) : 0ull;
     const int n1 = __popcll(b1), nD = __popcll(bD);
     if (mv1) { const int i = __popcll(b1 & below); S->dst[i] = j0 + lane; S->src[i] = j0 + st; }
@@ -1169,7 +1187,7 @@ __global__ __launch_bounds__(256) void swap_columns_dev_kernel(double* __restric
                                                                int* __restrict__ perm) {
     if (S->h.active == 0) return;
     const int ns = S->h.swap_n;
-    if (ns == 0) return;
+    if (ns <= 0 || ns > 64) return;
     if (blockIdx.x == gridDim.x - 1) {
         int old = 0;
         if ((int)threadIdx.x < ns) old = perm[S->src[threadIdx.x]];
@@ -1685,6 +1703,11 @@ static int qr_factor_impl(hipStream_t st, double* A, int64_t rs, int64_t cs, int
         if ((he = hipMemcpyAsync(hp, w.piv, 1024 + (size_t)n * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(he, "memcpy permutation");
         if ((he = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(he, "sync permutation");
         for (int64_t j = 0; j < n; ++j) pivot_perm_host[j] = hp[256 + j];
+        if (((const PivState*)hp)->h.stamp < 0) {
+            set_error("tn_qr: the device-side pivot selection of panel %d was not a valid set of columns (TN_PIVOT_DEVICE=0 selects on the host)",
+                      -((const PivState*)hp)->h.stamp - 1);
+            return 1;
+        }
         if (piv_stopped && dropped2_host) *dropped2_host = ((const PivState*)hp)->h.dropped2;
     }
     if (keff_host) *keff_host = k;
