@@ -130,7 +130,7 @@ int tn_qr_batched(double* A, int64_t rs, int64_t cs, int64_t m, int64_t n, doubl
  * C: k x n.  U: k x keep, S: keep values, Vt: keep x n are written for the first `keep` vectors only; buffers must
  * hold min(k, n, Dmax) vectors.  keep_host/discarded_host/sweeps_host/info_host are HOST pointers (may be NULL
  * except keep_host).  info: 0 converged, 1 sweep cap reached.
- * With up to 192 live vectors all Jacobi rounds run in ONE launch with the vectors resident in LDS (svdl_kernel: in-kernel barriers,
+ * With up to 256 live vectors all Jacobi rounds run in ONE launch with the vectors resident in LDS (svdl_kernel: in-kernel barriers,
  * within the co-residency budget of the panel step; TN_SVD_FUSED=0 keeps three launches per round): same results bit for bit.  A launch
  * in which a barrier gave up reports it, the rounds are redone as separate launches inside the same call and the stream stays off the
  * single-launch forms (message on stderr); nothing non-finite is returned. */

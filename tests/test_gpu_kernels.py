@@ -267,14 +267,16 @@ def _svd_case(k, n, seed, decay=0.25):
     return np.triu(A) if seed % 2 else A
 
 
-@pytest.mark.parametrize('shape', [(128, 200), (192, 600), (192, 900), (100, 100), (65, 65), (64, 700), (130, 70), (256, 500), (70, 3000)])
+@pytest.mark.parametrize('shape', [(128, 200), (192, 600), (192, 900), (100, 100), (65, 65), (64, 700), (130, 70), (256, 500), (70, 3000),
+                                   (256, 700, 0.05), (230, 1024, 0.06), (256, 256, 0.04), (200, 260, 0.02)])
 def test_svd_rounds_in_one_launch_bit_identical_to_separate_launches(ops, shape, monkeypatch):
     """All Jacobi rounds of a truncated SVD in ONE launch (svdl_kernel: the vectors resident in LDS, grid barriers between the
     phases) against three launches per round and a read-back per sweep (TN_SVD_FUSED=0): same arithmetic in the same order -- U, S,
-    V^T, the kept rank, the discarded weight and the number of sweeps agree bit for bit.  (Shapes with more than 192 live vectors or
-    more chunks than the co-residency budget holds stay on the separate launches in both runs.)"""
+    V^T, the kept rank, the discarded weight and the number of sweeps agree bit for bit.  (Shapes with more than 256 live vectors or
+    more chunks than the co-residency budget holds stay on the separate launches in both runs.)  A third entry is the decay rate of the
+    spectrum: the slow ones keep up to 256 vectors alive (the one-launch form's limit since round 5; 192 before)."""
     for seed in (1, 2):
-        T = dev(_svd_case(shape[0], shape[1], seed))
+        T = dev(_svd_case(shape[0], shape[1], seed, *shape[2:]))
         outs = []
         for mode in ('0', '1'):
             monkeypatch.setenv('TN_SVD_FUSED', mode)

@@ -1548,7 +1548,8 @@ int eig_small(hipStream_t st, const double* part, int nchunk, int nvec, int ngro
 // the spins are bounded, and a launch in which a barrier gave up says so in its status word (the caller redoes the rounds with the
 // three-launch form and takes the stream off the single-launch forms).  The barrier state cleans itself: all workgroups leave sooner
 // or later, the last one resets the counters.
-// Needs nvp <= 192 (LDS) and ceil(pitch / 64) + ng workgroups within the budget; otherwise the rounds stay separate launches.
+// Needs nvp <= 256 (LDS: 133 KB of vectors; 192 while the J of the pair being rotated was staged in the pool) and ceil(pitch / 64) + ng
+// workgroups within the budget; otherwise the rounds stay separate launches.
 // -DTN_CLOCKS: thread 0 of workgroup 0 (a chunk workgroup) accumulates the 100 MHz wall clock per phase over all launches:
 // [0] load  [1] Gram shares  [2] barrier  [3] wait for the eigenproblems  [4] rotation  [5] store + norms  [6] rounds  [7] launches
 #ifdef TN_CLOCKS
@@ -1637,8 +1638,7 @@ __global__ __launch_bounds__(512) void svdl_kernel(SvdlArgs a) {
     SvdlArgsK ak = (SvdlArgsK)__builtin_amdgcn_kernarg_segment_ptr();
     const bool chunk_wg = blk < a.ncw;
     const int c0 = blk * 64, grp = blk - a.ncw;
-    double* Xc = pool;                       // chunk workgroups: [nvp][XP]
-    double* Jl = pool + 3 * NB * P;          // ... and the J of the pair being rotated
+    double* Xc = pool;                       // chunk workgroups: [nvp][XP], nvp <= 256
     int nbar = 0, sweeps = 0;
     bool alive = ak != nullptr && ak->magic == SVDJ_MAGIC && ak->nvp == a.nvp && ak->pairs == a.pairs && ak->norms == a.norms && ak->Js == a.Js;
     bool converged = false;
@@ -1705,24 +1705,20 @@ __global__ __launch_bounds__(512) void svdl_kernel(SvdlArgs a) {
                     if (s_rot[z] == 0) continue;                    // (uniform) no rotation in this pair
                     const int b0 = s_pairs[2 * z], b1 = s_pairs[2 * z + 1];
                     auto prow = [&](int v) -> int { return v < W ? b0 * W + v : b1 * W + (v - W); };
-                    {
-                        gcd jsrc = (gcd)(a.Js + (int64_t)z * (NB * NB));
-                        double jv[8];
+                    // this lane's operands of J (64 x 64) come straight from memory (L2): 16 independent loads in flight, no staging in LDS --
+                    // the pool belongs to the vectors alone, up to 256 of them
+                    gcd jsrc = (gcd)(a.Js + (int64_t)z * (NB * NB));
+                    double ja[16];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) jv[u] = __hip_atomic_load(jsrc + tid + 512 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { const int e = tid + 512 * u; Jl[(e >> 6) * P + (e & 63)] = jv[u]; }
-                    }
-                    __syncthreads();
+                    for (int k4 = 0; k4 < 16; ++k4) ja[k4] = __hip_atomic_load(jsrc + (k4 * 4 + lk) * NB + ti * 16 + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // rows of the pair <- J^T rows (gemm_kernel's sequence over K = 64 vectors)
                     d4l acc0 = d4l{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
                     for (int k4 = 0; k4 < 16; ++k4) {
                         const int k = k4 * 4 + lk;
-                        const double fa = Jl[k * P + ti * 16 + li];
                         const int rk = prow(k);
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, Xc[rk * XP + tj0 * 16 + li], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, Xc[rk * XP + (tj0 + 1) * 16 + li], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[k4], Xc[rk * XP + tj0 * 16 + li], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[k4], Xc[rk * XP + (tj0 + 1) * 16 + li], acc1, 0, 0, 0);
                     }
                     __syncthreads();                                // every wave has read the old rows
 #pragma unroll
@@ -1819,7 +1815,7 @@ int svd_rounds_fused(hipStream_t st, const SvdRoundsJob& j) {
     static const int eig_naps = [] { const char* e = getenv("TN_SVDJ_NAPS"); return e ? atoi(e) : 2; }();
     const int slot = cholqr_stream_slot(st);
     if (slot >= CHOLQR_SLOTS) return 1;
-    if (2 * j.w != 64 || j.ng < 1 || j.ng > 32 || j.nr < 1 || j.nvp > 192) return 1;
+    if (2 * j.w != 64 || j.ng < 1 || j.ng > 32 || j.nr < 1 || j.nvp > 256) return 1;
     // the chunks of the kernel must be the splits the GEMM of the separate launches would use (gram_nchunk cuts at 64 up to L = 4096)
     int64_t kchunk = 0;
     const int nchunk = gemm_forced_split(j.L, j.nchunk, &kchunk);
