@@ -281,6 +281,7 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int64_t batch) {
     static const int target_wg = env_int("TN_GEMM_TARGETWG", 256);
     static const int min_chunk = env_int("TN_GEMM_MINCHUNK", 32);
     static const int smax = env_int("TN_GEMM_SMAX", 64);
+    static const int bigsplit_wgs = env_int("TN_GEMM_BIGSPLIT_WGS", 192), bigsplit_target = env_int("TN_GEMM_BIGSPLIT_TARGET", 512);
     const bool small = (double)M * (double)N * (double)K * (double)batch < (double)small_work;
     GemmPlan p;
     if (M > 64 && N > 64) {
@@ -300,8 +301,8 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int64_t batch) {
             if (s > smax) s = smax;
             p.s = s < 2 ? 1 : (int)s;
         }
-    } else if (wgs < 192 && K >= 512) {
-        int64_t s = cdiv(512, wgs);
+    } else if (wgs < bigsplit_wgs && K >= 512) {
+        int64_t s = cdiv(bigsplit_target, wgs);
         if (s > K / 128) s = K / 128;
         if (s > 64) s = 64;
         p.s = s < 2 ? 1 : (int)s;
