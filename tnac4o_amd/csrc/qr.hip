@@ -1231,39 +1231,50 @@ __global__ __launch_bounds__(256) void zero_above_panels_kernel(double* __restri
     }
 }
 // X (bw x nq, row-major) = T_blk Z by block back substitution; G: bw x bw row-major (pitch bw); T: the block's first panel factor
-// (b x b row-major each, pitch b, 32 x 32 doubles apart).  One workgroup = 32 columns of Z; per panel (last to first) the block row of G
-// and T_q are staged in LDS and the two small products run on the matrix cores: wave w owns the 16 x 16 tile (w / 2, w % 2) of the
-// 32 x 32 result.  (A first version with one thread per 4 x 1 entries and G read from memory inside the dependent loop took 85 us.)
+// (b x b row-major each, pitch b, 32 x 32 doubles apart).  One workgroup = 32 columns of Z; the block rows of G and the T_q are staged in
+// LDS and, panel by panel (last to first), the two small products run on the matrix cores: wave w owns the 16 x 16 tile (w / 2, w % 2)
+// of the 32 x 32 result.  (A first version with one thread per 4 x 1 entries and G read from memory inside the dependent loop took 85 us.)
 __global__ __launch_bounds__(256) void apply_merged_T_kernel(const double* __restrict__ Z, int64_t nq, const double* __restrict__ G, int bw,
                                                              const double* __restrict__ T, int npan, double* __restrict__ X) {
-    __shared__ double xs[QMB][33];           // X so far (rows of the panels already substituted)
-    __shared__ double vs[32][33];            // Z_q - sum_j G_qj X_j
-    __shared__ double gs[32][QMB - 32 + 1];  // block row of G to the right of panel q
-    __shared__ double ts[32][33];            // T_q
+    constexpr int NP = QMB / 32;
+    __shared__ double xs[QMB][33];                    // X so far (rows of the panels already substituted)
+    __shared__ double vs[32][33];                     // Z_q - sum_j G_qj X_j
+    __shared__ double gs[(NP - 1) * 32][QMB - 32 + 1];  // panel q's block row of G to the right of it: rows 32 q .. 32 q + 31, columns from 0
+    __shared__ double ts[NP][32][33];                 // T_q
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4, ti = wave >> 1, tj = wave & 1;
     const int64_t c0 = (int64_t)blockIdx.x * 32;
-    for (int q = npan - 1; q >= 0; --q) {
-        const int r0 = q * 32, bq = (bw - r0 < 32) ? bw - r0 : 32, kr = bw - r0 - 32;       // kr: columns of G right of the panel (<= 96)
-        for (int e = tid; e < 32 * (kr > 0 ? kr : 0); e += 256) {
-            const int i = e / kr, j = e % kr;
-            gs[i][j] = (i < bq) ? G[(int64_t)(r0 + i) * bw + r0 + 32 + j] : 0.0;
-        }
-        for (int e = tid; e < 1024; e += 256) {
-            const int i = e >> 5, l = e & 31;
-            ts[i][l] = (i < bq && l < bq) ? T[(int64_t)q * 1024 + i * bq + l] : 0.0;
-        }
-        d4q acc;
+    // everything the substitution reads goes to LDS / registers in ONE round of loads (the panels are then a chain of matrix-core steps and
+    // barriers only; staging per panel made four dependent memory round trips of it: 21 us per launch in the sweep)
+    for (int e = tid; e < (npan - 1) * 32 * (QMB - 32); e += 256) {
+        const int i = e / (QMB - 32), j = e % (QMB - 32);          // row i of the block, column 32 (q + 1) + j of G
+        const int q = i >> 5, col = 32 * (q + 1) + j;
+        gs[i][j] = (i < bw && col < bw) ? G[(int64_t)i * bw + col] : 0.0;
+    }
+    for (int e = tid; e < npan * 1024; e += 256) {
+        const int q = e >> 10, i = (e >> 5) & 31, l = e & 31;
+        const int bq = (bw - 32 * q < 32) ? bw - 32 * q : 32;
+        ts[q][i][l] = (i < bq && l < bq) ? T[(int64_t)q * 1024 + i * bq + l] : 0.0;
+    }
+    double zr[NP][4];
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = 16 * ti + lk + 4 * r;
+            const int i = 32 * q + 16 * ti + lk + 4 * r;
             const int64_t c = c0 + 16 * tj + lr;
-            acc[r] = (i < bq && c < nq) ? Z[(int64_t)(r0 + i) * nq + c] : 0.0;
+            zr[q][r] = (q < npan && i < bw && c < nq) ? Z[(int64_t)i * nq + c] : 0.0;
         }
-        __syncthreads();
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < NP; ++qq) {
+        const int q = NP - 1 - qq;
+        if (q >= npan) continue;                                   // (uniform)
+        const int r0 = q * 32, kr = bw - r0 - 32;                   // kr: columns of G right of the panel (<= 96; <= 0 for the last one)
+        d4q acc = {zr[q][0], zr[q][1], zr[q][2], zr[q][3]};
         for (int kk = 0; kk < kr; kk += 4) {
             const int k = kk + lk;
-            const double a = (k < kr) ? -gs[16 * ti + lr][k] : 0.0;
+            const double a = (k < kr) ? -gs[r0 + 16 * ti + lr][k] : 0.0;
             const double b = (k < kr) ? xs[r0 + 32 + k][16 * tj + lr] : 0.0;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
@@ -1274,7 +1285,7 @@ __global__ __launch_bounds__(256) void apply_merged_T_kernel(const double* __res
 #pragma unroll
         for (int kk = 0; kk < 32; kk += 4) {
             const int k = kk + lk;
-            x = __builtin_amdgcn_mfma_f64_16x16x4f64(ts[16 * ti + lr][k], vs[k][16 * tj + lr], x, 0, 0, 0);
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(ts[q][16 * ti + lr][k], vs[k][16 * tj + lr], x, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) xs[r0 + 16 * ti + lk + 4 * r][16 * tj + lr] = x[r];
