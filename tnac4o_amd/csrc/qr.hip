@@ -1185,9 +1185,14 @@ __global__ __launch_bounds__(256) void pivot_select_kernel(const double* __restr
 // (the workgroup after the last one applies the moves to the permutation: perm[dst] <- perm[src])
 __global__ __launch_bounds__(256) void swap_columns_dev_kernel(double* __restrict__ A, int64_t rs, int64_t cs, int64_t m, const PivState* __restrict__ S,
                                                                int* __restrict__ perm) {
-    if (S->h.active == 0) return;
-    const int ns = S->h.swap_n;
-    if (ns <= 0 || ns > 64) return;
+    // (header and move list are fetched together -- one memory round trip instead of two before the first row load; entries beyond swap_n
+    //  are stale but in range of the array and never used)
+    const int g = threadIdx.x >> 6;
+    int src[16], dst[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { src[i] = S->src[g * 16 + i]; dst[i] = S->dst[g * 16 + i]; }
+    const int active = S->h.active, ns = S->h.swap_n;
+    if (active == 0 || ns <= 0 || ns > 64) return;
     if (blockIdx.x == gridDim.x - 1) {
         int old = 0;
         if ((int)threadIdx.x < ns) old = perm[S->src[threadIdx.x]];
@@ -1195,16 +1200,15 @@ __global__ __launch_bounds__(256) void swap_columns_dev_kernel(double* __restric
         if ((int)threadIdx.x < ns) perm[S->dst[threadIdx.x]] = old;
         return;
     }
-    const int g = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const bool in = r < m;
     double* row = A + (in ? r : 0) * rs;
     double v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const int t = g * 16 + i; v[i] = (in && t < ns) ? row[(int64_t)S->src[t] * cs] : 0.0; }
+    for (int i = 0; i < 16; ++i) { const int t = g * 16 + i; v[i] = (in && t < ns) ? row[(int64_t)src[i] * cs] : 0.0; }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const int t = g * 16 + i; if (in && t < ns) row[(int64_t)S->dst[t] * cs] = v[i]; }
+    for (int i = 0; i < 16; ++i) { const int t = g * 16 + i; if (in && t < ns) row[(int64_t)dst[i] * cs] = v[i]; }
 }
 // Look-ahead (aux != nullptr, nb = 32): the trailing update of panel p is split.  The columns of the next panel (and the
 // panel's own) are updated on the caller's stream, which then factors panel p+1 right away -- a chain of latency-bound
