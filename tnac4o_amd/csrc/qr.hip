@@ -1248,17 +1248,32 @@ __global__ __launch_bounds__(256) void apply_merged_T_kernel(const double* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4, ti = wave >> 1, tj = wave & 1;
     const int64_t c0 = (int64_t)blockIdx.x * 32;
-    // everything the substitution reads goes to LDS / registers in ONE round of loads (the panels are then a chain of matrix-core steps and
-    // barriers only; staging per panel made four dependent memory round trips of it: 21 us per launch in the sweep)
-    for (int e = tid; e < (npan - 1) * 32 * (QMB - 32); e += 256) {
-        const int i = e / (QMB - 32), j = e % (QMB - 32);          // row i of the block, column 32 (q + 1) + j of G
-        const int q = i >> 5, col = 32 * (q + 1) + j;
-        gs[i][j] = (i < bw && col < bw) ? G[(int64_t)i * bw + col] : 0.0;
-    }
-    for (int e = tid; e < npan * 1024; e += 256) {
-        const int q = e >> 10, i = (e >> 5) & 31, l = e & 31;
-        const int bq = (bw - 32 * q < 32) ? bw - 32 * q : 32;
-        ts[q][i][l] = (i < bq && l < bq) ? T[(int64_t)q * 1024 + i * bq + l] : 0.0;
+    // everything the substitution reads goes to LDS / registers in ONE round of loads, issued back to back from fully unrolled loops with
+    // masks instead of data-dependent trip counts (a loop whose body is "load, store to LDS" waits for every load before it issues the
+    // next one: the per-panel staging spent 21 us of such round trips per launch in the sweep, a first "single round" version with
+    // runtime loop bounds 25); the panels are then a chain of matrix-core steps and barriers only
+    {
+        double gv[12][3], tv[NP * 4];
+#pragma unroll
+        for (int u1 = 0; u1 < 12; ++u1)
+#pragma unroll
+            for (int u2 = 0; u2 < 3; ++u2) {
+                const int i = (tid >> 5) + 8 * u1, j = (tid & 31) + 32 * u2;       // row i of the block, column 32 (q + 1) + j of G
+                const int col = 32 * ((i >> 5) + 1) + j;
+                gv[u1][u2] = (i < (npan - 1) * 32 && col < bw) ? G[(int64_t)i * bw + col] : 0.0;
+            }
+#pragma unroll
+        for (int u = 0; u < NP * 4; ++u) {
+            const int q = u >> 2, idx = (u & 3) * 256 + tid, i = idx >> 5, l = idx & 31;
+            const int bq = (bw - 32 * q < 32) ? bw - 32 * q : 32;
+            tv[u] = (q < npan && i < bq && l < bq) ? T[(int64_t)q * 1024 + i * bq + l] : 0.0;
+        }
+#pragma unroll
+        for (int u1 = 0; u1 < 12; ++u1)
+#pragma unroll
+            for (int u2 = 0; u2 < 3; ++u2) gs[(tid >> 5) + 8 * u1][(tid & 31) + 32 * u2] = gv[u1][u2];
+#pragma unroll
+        for (int u = 0; u < NP * 4; ++u) { const int idx = (u & 3) * 256 + tid; ts[u >> 2][idx >> 5][idx & 31] = tv[u]; }
     }
     double zr[NP][4];
 #pragma unroll
